@@ -1,0 +1,156 @@
+/* maskrcnn_hip.h — C ABI of libmaskrcnn_hip.so: the MI355X (gfx950) implementation of the
+ * Mask R-CNN inference hot path of delldu/MaskRCNN.
+ *
+ * This is the drop-in boundary. Every entry point takes plain device pointers, sizes and a HIP stream
+ * (no torch types), launches asynchronously on that stream, performs no allocation and no host
+ * synchronisation (safe inside hipGraph capture), and returns MRCNN_OK or a negative error code with
+ * a thread-local message in mrcnn_last_error(). Nothing here ever calls exit().
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the reference tree).
+ * The Python face (package `maskrcnn`: nms, CropFunction, _C.{nms,crop_forward,crop_backward}, and
+ * torch.ops.maskrcnn.*) is a thin binding over these symbols: see INTEGRATION.md.
+ */
+#ifndef MASKRCNN_HIP_H
+#define MASKRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRCNN_ABI_VERSION 1
+
+#define MRCNN_OK 0
+#define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
+#define MRCNN_ERR_UNSUPPORTED (-2)      /* valid request this build has no kernel for            */
+#define MRCNN_ERR_LAUNCH (-3)           /* hipLaunch / runtime error (message has hipGetErrorString) */
+
+typedef void* mrcnn_stream_t; /* a hipStream_t; NULL = the null stream */
+
+/* ABI version of the loaded library (== MRCNN_ABI_VERSION it was built with). */
+int mrcnn_abi_version(void);
+/* Message for the last non-OK return on this thread ("" if none). Never NULL. */
+const char* mrcnn_last_error(void);
+/* gfx target the device code was compiled for ("gfx950"). */
+const char* mrcnn_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * NMS — replaces  at::Tensor nms(const at::Tensor& dets, const float threshold)
+ *       c++ext/maskrcnn/csrc/nms.h:15-30, cpu path csrc/cpu/nms_cpu.cpp:11-79.
+ *
+ * Greedy NMS with the CPU path's exact arithmetic: areas (x2-x1+1)*(y2-y1+1), boxes visited in
+ * descending score order (ties: lower input index first), box j suppressed by a kept box i when
+ * inter/(area_i+area_j-inter) >= threshold (IEEE fp32, no FMA contraction; `>=`, not the CUDA
+ * path's `>`). Survivors are reported as ASCENDING INPUT INDICES (nms_cpu.cpp:69).
+ *
+ * S independent segments are processed by one launch (one workgroup per segment).
+ *   dets        [S][n_max] rows (y1,x1,y2,x2,score); element (s,i,c) at
+ *               dets[s*seg_stride + i*row_stride + c*col_stride]   (strides in elements)
+ *   seg_counts  int32[S] boxes in each segment (<= n_max), device memory; NULL = all n_max
+ *   class_ids   int32, element (s,i) at class_ids[s*n_max + i]; NULL = single class. When given,
+ *               a box only suppresses boxes of the same class: the one-pass form of the per-class
+ *               loop in MaskRCNN.mrn_refine (model.py:1454-1475).
+ *   keep_out    int64[S][n_max]: first counts_out[s] entries = kept indices ascending, rest = -1
+ *   counts_out  int32[S]
+ * Limits: 1 <= n_max <= mrcnn_nms_max_boxes() (on-chip path; LDS-resident).  S >= 1.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t mrcnn_nms_max_boxes(void);
+int mrcnn_nms_batched_f32(const float* dets, int32_t num_segments, int64_t n_max, int64_t seg_stride,
+                          int64_t row_stride, int64_t col_stride, const int32_t* seg_counts,
+                          const int32_t* class_ids, float threshold, int64_t* keep_out,
+                          int32_t* counts_out, mrcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * crop_and_resize ("RoIAlign") forward — replaces
+ *   void crop_forward(image, boxes, box_index, extrapolation_value, crop_height, crop_width, crops)
+ *   c++ext/maskrcnn/csrc/crop.h:14-34, cpu path csrc/cpu/crop_cpu.cpp:13-164.
+ *
+ *   image      fp32 [batch][depth][H][W]   (NCHW, contiguous)
+ *   boxes      fp32 [num_boxes][4] normalised (y1,x1,y2,x2)
+ *   box_index  int32[num_boxes] in [0,batch). An out-of-range index fills that box's crop with
+ *              extrapolation_value (the reference CPU path printf()s and exit(-1)s, crop_cpu.cpp:47-50;
+ *              its CUDA path silently skips, crop_cuda.cu:41-44).
+ *   crops      fp32 [num_boxes][depth][crop_height][crop_width], fully overwritten.
+ * Arithmetic is the reference's, op for op (one bilinear sample per bin, endpoint-inclusive grid,
+ * strict outside test, floorf/ceilf taps, a+(b-a)*t lerps, crop size 1 → box centre in double).
+ * ---------------------------------------------------------------------------------------------- */
+int mrcnn_crop_forward_f32(const float* image, int32_t batch, int32_t depth, int32_t height,
+                           int32_t width, const float* boxes, const int32_t* box_index,
+                           int32_t num_boxes, float extrapolation_value, int32_t crop_height,
+                           int32_t crop_width, float* crops, mrcnn_stream_t stream);
+
+/* crop_and_resize backward — replaces
+ *   void crop_backward(grads, boxes, box_index, grads_image)
+ *   c++ext/maskrcnn/csrc/crop.h:36-53, cpu path csrc/cpu/crop_cpu.cpp:167-265.
+ *   grads [num_boxes][depth][crop_h][crop_w] → grads_image [batch][depth][H][W] (zeroed here, then
+ *   accumulated with fp32 atomics: summation order differs from the serial CPU loop). */
+int mrcnn_crop_backward_f32(const float* grads, const float* boxes, const int32_t* box_index,
+                            int32_t num_boxes, int32_t batch, int32_t depth, int32_t height,
+                            int32_t width, int32_t crop_height, int32_t crop_width,
+                            float* grads_image, mrcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pyramid RoIAlign, channels-last — replaces the Python dispatcher
+ *   roi_align(inputs, pool_size, image_shape)   model.py:276-393
+ * (level = clamp(round_half_even(4 + log2(sqrt(h*w) / (224/sqrt(H_img*W_img)))), 2, 5), one
+ * crop_forward per level, concat, restore order) with one launch and no host synchronisation.
+ *
+ *   fm[l]      fp32 [batch][H_l][W_l][depth]  (NHWC), l = 0..3 for P2..P5; depth % 4 == 0
+ *   rois       fp32 [num_rois][4] normalised (y1,x1,y2,x2); roi r reads image roi_batch[r]
+ *              (roi_batch NULL → image r / rois_per_image).
+ *   out        fp32 [num_rois][pool][pool][depth] (NHWC), original roi order
+ *   levels_out int32[num_rois] (optional, may be NULL): the level 2..5 chosen per roi
+ * ---------------------------------------------------------------------------------------------- */
+int mrcnn_roi_align_pyramid_nhwc_f32(const float* const fm[4], const int32_t fm_h[4],
+                                     const int32_t fm_w[4], int32_t batch, int32_t depth,
+                                     const float* rois, const int32_t* roi_batch, int32_t num_rois,
+                                     int32_t rois_per_image, int32_t pool, float image_area,
+                                     float* out, int32_t* levels_out, mrcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused convolution + bias/BatchNorm affine + residual + ReLU, channels-last, fp32 MFMA implicit
+ * GEMM — the building block of Bottleneck.forward (model.py:190-211), the stem (model.py:223-226),
+ * FPN laterals/smoothing (model.py:145-157), RPN and head convolutions. No reference kernel exists
+ * for it (the reference calls nn.Conv2d / BatchNorm2d / ReLU / F.pad as separate modules).
+ *
+ *   y[b,oy,ox,co] = act( scale[co] * sum_{ky,kx,ci} x[b, oy*stride+ky-pad_top, ox*stride+kx-pad_left, ci]
+ *                                                  * w[co,ky,kx,ci]  + shift[co]  (+ residual) )
+ *   x        fp32 [batch][H][W][cin]           (NHWC)   cin % 4 == 0
+ *   w        fp32 [cout][kh][kw][cin]          (OHWI)
+ *   scale    fp32 [cout] or NULL (=1);  shift fp32 [cout] or NULL (=0)
+ *            (BN eval + conv bias folded by the caller: scale = g/sqrt(var+eps),
+ *             shift = (bias-mean)*scale + beta; kept as an fp32 epilogue, not folded into w)
+ *   residual fp32 [batch][OH/res_div][OW/res_div][cout] or NULL, added before the activation;
+ *            res_div = 1 (Bottleneck `out += residual`) or 2 (FPN top-down: nearest 2x upsample,
+ *            model.py:150-152)
+ *   relu     0/1
+ *   y        fp32 [batch][OH][OW][cout],  OH = (H + pad_top + pad_bottom - kh)/stride + 1, same for OW
+ * Zero padding is applied on the fly (SamePad2d, model.py:64-87, never materialised).
+ * ---------------------------------------------------------------------------------------------- */
+int mrcnn_conv_bn_act_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
+                               int32_t cin, const float* w, int32_t cout, int32_t kh, int32_t kw,
+                               int32_t stride, int32_t pad_top, int32_t pad_left, int32_t pad_bottom,
+                               int32_t pad_right, const float* scale, const float* shift,
+                               const float* residual, int32_t res_div, int32_t relu, float* y,
+                               mrcnn_stream_t stream);
+
+/* Zero-padded max-pool, NHWC fp32: [batch][H][W][C] -> [batch][OH][OW][C], OH = (H+pad_top+pad_bottom-k)/s+1.
+ * Covers the stem's SamePad2d(3,2) + MaxPool2d(3,2) (model.py:227-228; pads (0,1,0,1) on even sizes — the
+ * caller computes the pads with the reference's formula, model.py:75-87) and P6 = MaxPool2d(1,2)
+ * (model.py:109,161). Out-of-range taps read 0, exactly as F.pad(..., 'constant', 0) then max. C % 4 == 0. */
+int mrcnn_maxpool_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t channels,
+                           int32_t kernel, int32_t stride, int32_t pad_top, int32_t pad_left,
+                           int32_t pad_bottom, int32_t pad_right, float* y, mrcnn_stream_t stream);
+
+/* Layout conversions at the boundary (reference tensors are NCHW, model.py:1109). */
+int mrcnn_nchw_to_nhwc_f32(const float* x, int32_t batch, int32_t channels, int32_t height,
+                           int32_t width, int32_t channels_padded, float* y, mrcnn_stream_t stream);
+int mrcnn_nhwc_to_nchw_f32(const float* x, int32_t batch, int32_t channels, int32_t height,
+                           int32_t width, float* y, mrcnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MASKRCNN_HIP_H */

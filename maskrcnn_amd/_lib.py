@@ -1,0 +1,74 @@
+"""ctypes binding of libmaskrcnn_hip.so (the C ABI declared in include/maskrcnn_hip.h).
+
+There is no CPU fallback and no alternative backend: if the library is missing or does not export a
+declared symbol, importing this module raises — run `python maskrcnn_amd/build.py` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libmaskrcnn_hip.so")
+HEADER = os.path.join(os.path.dirname(PKG), "include", "maskrcnn_hip.h")
+
+c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+_SIGS = {
+    "mrcnn_abi_version": (ctypes.c_int, []),
+    "mrcnn_last_error": (ctypes.c_char_p, []),
+    "mrcnn_arch": (ctypes.c_char_p, []),
+    "mrcnn_nms_max_boxes": (c_i64, []),
+    "mrcnn_nms_batched_f32": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp,
+                                               c_f32, c_vp, c_vp, c_vp]),
+    "mrcnn_crop_forward_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32,
+                                                c_f32, c_i32, c_i32, c_vp, c_vp]),
+    "mrcnn_crop_backward_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                                 c_i32, c_i32, c_vp, c_vp]),
+    "mrcnn_roi_align_pyramid_nhwc_f32": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(c_i32),
+                                                          ctypes.POINTER(c_i32), c_i32, c_i32, c_vp,
+                                                          c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp,
+                                                          c_vp]),
+    "mrcnn_conv_bn_act_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32,
+                                                    c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp,
+                                                    c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "mrcnn_maxpool_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                                c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mrcnn_nchw_to_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mrcnn_nhwc_to_nchw_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+}
+
+
+def declared_symbols(header: str = HEADER) -> list[str]:
+    """Every function name include/maskrcnn_hip.h declares (used by the CPU export test)."""
+    text = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(mrcnn_[a-z0-9_]+)\s*\(", text)) - {"mrcnn_stream_t"})
+
+
+class MaskrcnnHipError(RuntimeError):
+    pass
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python maskrcnn_amd/build.py` (needs hipcc; cross-compiles for gfx950 without a GPU). "
+            "maskrcnn_amd has no CPU or PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise MaskrcnnHipError(f"libmaskrcnn_hip error {rc}: {lib.mrcnn_last_error().decode()}")

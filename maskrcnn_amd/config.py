@@ -1,0 +1,37 @@
+"""The constants the inference path reads (reference config.py:54-126,199-204), as a plain dataclass.
+Two fields are parameters here that the reference hard-codes: `pre_nms_limit` (500 at model.py:1345) and
+`proposal_count` (RPN_NMS_MAX_ROIS_NUM = 500, config.py:76) — BASELINE.json's metric is quoted at 1000
+proposals per image."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+
+@dataclass
+class InferenceConfig:
+    image_height: int = 1024            # IMAGE_MAX_DIM padded square (config.py:157-158)
+    image_width: int = 1024
+    backbone: str = "resnet101"         # hard-coded at model.py:985
+    backbone_strides: tuple = (4, 8, 16, 32, 64)
+    rpn_anchor_scales: tuple = (32, 64, 128, 256, 512)
+    rpn_anchor_ratios: tuple = (0.5, 1, 2)
+    rpn_anchor_stride: int = 1
+    rpn_nms_threshold: float = 0.7
+    pre_nms_limit: int = 500
+    proposal_count: int = 500
+    rpn_bbox_std_dev: tuple = (0.1, 0.1, 0.2, 0.2)
+    pool_size: int = 7
+    mask_pool_size: int = 14
+    detection_max_instances: int = 50
+    detection_min_confidence: float = 0.0   # CocoInferenceConfig (config.py:204): falsy → no filter
+    detection_nms_threshold: float = 0.3
+    num_classes: int = 81
+    mean_pixel: tuple = (123.7, 116.8, 103.9)
+    backbone_shapes: list = field(init=False)
+
+    def __post_init__(self):
+        if self.image_height % 64 or self.image_width % 64:  # model.py:978-983
+            raise ValueError("Image size must be dividable by 2 at least 6 times")
+        self.backbone_shapes = [(int(math.ceil(self.image_height / s)), int(math.ceil(self.image_width / s)))
+                                for s in self.backbone_strides]

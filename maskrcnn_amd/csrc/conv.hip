@@ -1,0 +1,294 @@
+// Fused convolution + per-channel affine (bias/BatchNorm) + residual + ReLU as an fp32 MFMA implicit GEMM
+// for gfx950, channels-last. The compute core of Bottleneck.forward (model.py:190-211), the stem
+// (model.py:223-226), the FPN lateral/smoothing convs (model.py:145-157), RPN and head convs.
+// The reference has no kernel for this (it chains nn.Conv2d / BatchNorm2d / ReLU / F.pad modules); this is
+// new work, designed for CDNA4:
+//   GEMM view   M = B*OH*OW output pixels, N = Cout, K = KH*KW*Cin with k = (ky*KW + kx)*Cin + ci.
+//   MFMA        v_mfma_f32_32x32x2_f32 — exact fp32 (bitwise an fmaf chain), 64 FLOP/clk/SIMD.
+//               A operand = pixels (rows), B operand = weights (cols): an accumulator register holds one
+//               output channel per lane, so epilogue loads/stores are 128-byte channel runs.
+//   LDS         A[BM][32+4] and B[BN][32+4] fp32 tiles, double buffered. Each lane fetches its operand
+//               with ONE ds_read_b128 per 8-deep k chunk: lane half h reads k = 8j+4h..+3 and MFMA step s
+//               contracts k = 8j+s (lanes 0-31) with k = 8j+4+s (lanes 32-63) — a k permutation applied
+//               identically to A and B. The +4 pad makes those reads bank-conflict free.
+//   im2col      on the fly from NHWC: a thread owns fixed tile rows and a fixed 16-byte k slot; zero
+//               padding (SamePad2d, model.py:64-87) is a predicate, never a padded copy.
+//   pipeline    global -> registers for tile t+1 issued before the MFMAs of tile t, written to the other
+//               LDS buffer after them; one barrier per k tile.
+//   XCD         consecutive tiles of one XCD (blockIdx % 8) walk N first inside a contiguous M range, so
+//               an activation tile is fetched into exactly one XCD's L2 and reused for every N tile/tap.
+//   epilogue    y = relu(acc*scale[c] + shift[c] + residual), residual optionally read at (oy/2, ox/2)
+//               (FPN nearest-neighbour upsample + add, model.py:150-152).
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+    const float* x;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    float* y;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
+    int M, K;  // GEMM sizes
+    int res_div, relu;
+    int tiles_m, tiles_n;
+};
+
+constexpr int BK = 32;
+constexpr int LDS_STRIDE = BK + 4;  // floats
+
+template <int BM, int BN>
+constexpr size_t conv_lds_bytes() {
+    return sizeof(float) * 2 * (BM + BN) * LDS_STRIDE;
+}
+
+// GENERIC: Cin % 32 != 0 (stem, Cin = 4): a k tile may straddle taps, each 16-byte slot decodes its own tap.
+template <int BM, int BN, int WM, int WN, bool GENERIC>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
+    constexpr int PA = BM / 32, PB = BN / 32;    // 16-byte slots per thread per k tile
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDS_STRIDE;
+
+    // ---- tile mapping: XCD x owns M tiles [x*tiles_m/8, (x+1)*tiles_m/8), N fastest -----------------
+    const int t = blockIdx.x;
+    const int xcd = t & 7, seq = t >> 3;
+    const int mt_lo = (xcd * p.tiles_m) >> 3, mt_hi = ((xcd + 1) * p.tiles_m) >> 3;
+    const int mt = mt_lo + seq / p.tiles_n;
+    const int nt = seq % p.tiles_n;
+    if (mt >= mt_hi) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int kq = tid & 7, r0 = tid >> 3;
+
+    // ---- per-thread row bookkeeping for the im2col gather ---------------------------------------------
+    int a_off[PA], a_iy[PA], a_ix[PA];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        if (m < p.M) {
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            a_iy[i] = oy * p.stride - p.pad_t;
+            a_ix[i] = ox * p.stride - p.pad_l;
+            a_off[i] = ((b * p.H + a_iy[i]) * p.W + a_ix[i]) * p.Cin;
+        } else {
+            a_iy[i] = -(1 << 24);  // never in range
+            a_ix[i] = 0;
+            a_off[i] = 0;
+        }
+    }
+    int b_off[PB];
+    bool b_ok[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        b_ok[i] = n < p.Cout;
+        b_off[i] = (b_ok[i] ? n : 0) * p.K + kq * 4;
+    }
+
+    float4 ra[PA], rb[PB];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        if constexpr (!GENERIC) {
+            const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;  // wave-uniform
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const int tap_off = (ky * p.W + kx) * p.Cin + c0 + kq * 4;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const bool ok = static_cast<unsigned>(a_iy[i] + ky) < static_cast<unsigned>(p.H) &&
+                                static_cast<unsigned>(a_ix[i] + kx) < static_cast<unsigned>(p.W);
+                ra[i] = ok ? *reinterpret_cast<const float4*>(p.x + a_off[i] + tap_off)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(p.w + b_off[i] + k0)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const int kk = k0 + kq * 4;
+            const bool kin = kk < p.K;
+            const int tap = kk / p.Cin, c = kk - tap * p.Cin;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const int tap_off = (ky * p.W + kx) * p.Cin + c;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const bool ok = kin &&
+                                static_cast<unsigned>(a_iy[i] + ky) < static_cast<unsigned>(p.H) &&
+                                static_cast<unsigned>(a_ix[i] + kx) < static_cast<unsigned>(p.W);
+                ra[i] = ok ? *reinterpret_cast<const float4*>(p.x + a_off[i] + tap_off)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                rb[i] = (b_ok[i] && kin) ? *reinterpret_cast<const float4*>(p.w + b_off[i] + k0)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* a = As + buf * BM * LDS_STRIDE + r0 * LDS_STRIDE + kq * 4;
+        float* b = Bs + buf * BN * LDS_STRIDE + r0 * LDS_STRIDE + kq * 4;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<float4*>(a + 32 * i * LDS_STRIDE) = ra[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<float4*>(b + 32 * i * LDS_STRIDE) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frag = (lane & 31) * LDS_STRIDE + (lane >> 5) * 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float* Ab = As + buf * BM * LDS_STRIDE + wm * WTM * LDS_STRIDE + frag;
+        const float* Bb = Bs + buf * BN * LDS_STRIDE + wn * WTN * LDS_STRIDE + frag;
+#pragma unroll
+        for (int j = 0; j < BK / 8; ++j) {
+            float4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_STRIDE + j * 8);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                b[i] = *reinterpret_cast<const float4*>(Bb + i * 32 * LDS_STRIDE + j * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float av = s == 0 ? a[i].x : s == 1 ? a[i].y : s == 2 ? a[i].z : a[i].w;
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn) {
+                        const float bv = s == 0 ? b[jn].x : s == 1 ? b[jn].y : s == 2 ? b[jn].z : b[jn].w;
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jn], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: affine + residual + ReLU, 128-byte channel runs per half-wave ------------------------
+    const int ln = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn * WTN + jn * 32 + ln;
+        const bool n_ok = n < p.Cout;
+        const float sc = (n_ok && p.scale) ? p.scale[n] : 1.0f;
+        const float sh = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (n_ok && m < p.M) {
+                    float v = acc[i][jn][r] * sc + sh;
+                    if (p.residual) {
+                        int64_t ri;
+                        if (p.res_div == 1) {
+                            ri = static_cast<int64_t>(m) * p.Cout + n;
+                        } else {
+                            const int b = m / ohw, rem = m - b * ohw;
+                            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                            const int rh = p.OH / p.res_div, rw = p.OW / p.res_div;
+                            ri = (static_cast<int64_t>(b * rh + oy / p.res_div) * rw + ox / p.res_div) *
+                                     p.Cout + n;
+                        }
+                        v += p.residual[ri];
+                    }
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    p.y[static_cast<int64_t>(m) * p.Cout + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    const int per_xcd = (p.tiles_m + 7) / 8;
+    const long long grid = 8LL * per_xcd * p.tiles_n;
+    if (grid > 0x7fffffffLL) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: grid too large");
+    constexpr size_t lds = conv_lds_bytes<BM, BN>();
+    auto set_attr = [&](const void* f) -> int {
+        if (lds <= 64 * 1024) return MRCNN_OK;
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds));
+        if (e != hipSuccess)
+            return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return MRCNN_OK;
+    };
+    if (generic) {
+        auto k = conv_igemm_f32<BM, BN, WM, WN, true>;
+        if (int rc = set_attr(reinterpret_cast<const void*>(k))) return rc;
+        hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
+    } else {
+        auto k = conv_igemm_f32<BM, BN, WM, WN, false>;
+        if (int rc = set_attr(reinterpret_cast<const void*>(k))) return rc;
+        hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
+    }
+    return mrcnn::check_launch("conv_igemm_f32");
+}
+
+}  // namespace
+
+extern "C" int mrcnn_conv_bn_act_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
+                                          int32_t cin, const float* w, int32_t cout, int32_t kh,
+                                          int32_t kw, int32_t stride, int32_t pad_top, int32_t pad_left,
+                                          int32_t pad_bottom, int32_t pad_right, const float* scale,
+                                          const float* shift, const float* residual, int32_t res_div,
+                                          int32_t relu, float* y, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x && w && y, "conv: null pointer");
+    MRCNN_REQUIRE(batch >= 1 && height >= 1 && width >= 1 && cin >= 4 && cin % 4 == 0 && cout >= 1,
+                  "conv: bad shape B=%d H=%d W=%d Cin=%d (Cin %% 4 == 0 required) Cout=%d", batch, height,
+                  width, cin, cout);
+    MRCNN_REQUIRE(kh >= 1 && kw >= 1 && stride >= 1 && pad_top >= 0 && pad_left >= 0 && pad_bottom >= 0 &&
+                      pad_right >= 0, "conv: bad kernel/stride/pad");
+    MRCNN_REQUIRE(residual == nullptr || res_div == 1 || res_div == 2, "conv: res_div must be 1 or 2");
+    ConvParams p;
+    p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw;
+    p.stride = stride; p.pad_t = pad_top; p.pad_l = pad_left;
+    p.OH = (height + pad_top + pad_bottom - kh) / stride + 1;
+    p.OW = (width + pad_left + pad_right - kw) / stride + 1;
+    MRCNN_REQUIRE(p.OH >= 1 && p.OW >= 1, "conv: empty output");
+    MRCNN_REQUIRE(residual == nullptr || res_div == 1 || (p.OH % 2 == 0 && p.OW % 2 == 0),
+                  "conv: res_div=2 needs even output size");
+    const long long M = 1LL * batch * p.OH * p.OW;
+    const long long K = 1LL * kh * kw * cin;
+    MRCNN_REQUIRE(1LL * batch * height * width * cin < (1LL << 31) && M * cout < (1LL << 31) &&
+                      K * cout < (1LL << 31) && M < (1LL << 31),
+                  "conv: tensor exceeds 2^31 elements (32-bit offsets)");
+    p.M = static_cast<int>(M);
+    p.K = static_cast<int>(K);
+    p.res_div = residual ? res_div : 1;
+    p.relu = relu;
+    const bool generic = (cin % BK) != 0;
+    hipStream_t s = mrcnn::as_stream(stream);
+    if (cout <= 32) return launch_conv<128, 32, 4, 1>(p, generic, s);
+    if (cout <= 64) return launch_conv<256, 64, 4, 1>(p, generic, s);
+    return launch_conv<128, 128, 2, 2>(p, generic, s);
+}

@@ -1,0 +1,294 @@
+"""Host-side mirror of the reference's nn graph on the hot path, executed with the fused HIP ops.
+
+Two faces:
+  * `reference_schema(arch)` — an nn.Module tree whose state_dict keys/shapes equal the reference
+    MaskRCNN's (fpn.C1.0.weight … mask.conv5.bias; model.py:97-131,174-189,214-270,596-607,724-740,
+    848-866), so a user's `mask_rcnn_coco.pth` loads unchanged. It carries parameters only.
+  * `Fused*` — inference blocks built from such a state_dict: BatchNorm (eval) and conv bias are folded
+    into an fp32 (scale, shift) epilogue, weights repacked OIHW → OHWI, activations channels-last. Every
+    convolution/GEMM runs in torch.ops.maskrcnn.conv_bn_act (libmaskrcnn_hip.so); there is no PyTorch
+    fallback.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+BN_EPS = 1e-3  # model.py:180,183,185,225,261,732,734,857-863
+LAYERS = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3]}  # model.py:219
+NUM_CLASSES = 81
+
+
+# --------------------------------------------------------------------------------------------------
+# state-dict schema (parameters only)
+# --------------------------------------------------------------------------------------------------
+class _Bottleneck(nn.Module):
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=stride)
+        self.bn1 = nn.BatchNorm2d(planes, eps=BN_EPS, momentum=0.01)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3)
+        self.bn2 = nn.BatchNorm2d(planes, eps=BN_EPS, momentum=0.01)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1)
+        self.bn3 = nn.BatchNorm2d(planes * 4, eps=BN_EPS, momentum=0.01)
+        self.downsample = downsample
+        self.stride = stride
+
+
+def _stage(inplanes, planes, blocks, stride):
+    down = None
+    if stride != 1 or inplanes != planes * 4:
+        down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, kernel_size=1, stride=stride),
+                             nn.BatchNorm2d(planes * 4, eps=BN_EPS, momentum=0.01))
+    layers = [_Bottleneck(inplanes, planes, stride, down)]
+    layers += [_Bottleneck(planes * 4, planes) for _ in range(1, blocks)]
+    return nn.Sequential(*layers)
+
+
+class _Holder(nn.Module):
+    pass
+
+
+def reference_schema(arch: str = "resnet101", num_classes: int = NUM_CLASSES) -> nn.Module:
+    """Parameter tree with the reference MaskRCNN's state_dict layout (R50: 596 keys… R101: 800)."""
+    l = LAYERS[arch]
+    net = _Holder()
+    fpn = _Holder()
+    # nn.Identity placeholders keep the Sequential indices of ReLU / SamePad2d / MaxPool2d
+    fpn.C1 = nn.Sequential(nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3),
+                           nn.BatchNorm2d(64, eps=BN_EPS, momentum=0.01), nn.Identity(), nn.Identity(),
+                           nn.Identity())
+    fpn.C2 = _stage(64, 64, l[0], 1)
+    fpn.C3 = _stage(256, 128, l[1], 2)
+    fpn.C4 = _stage(512, 256, l[2], 2)
+    fpn.C5 = _stage(1024, 512, l[3], 2)
+    for name, cin in (("P5", 2048), ("P4", 1024), ("P3", 512), ("P2", 256)):
+        setattr(fpn, name + "_conv1", nn.Conv2d(cin, 256, kernel_size=1))
+        setattr(fpn, name + "_conv2", nn.Sequential(nn.Identity(), nn.Conv2d(256, 256, kernel_size=3)))
+    net.fpn = fpn
+    rpn = _Holder()
+    rpn.conv_shared = nn.Conv2d(256, 512, kernel_size=3)
+    rpn.conv_class = nn.Conv2d(512, 6, kernel_size=1)
+    rpn.conv_bbox = nn.Conv2d(512, 12, kernel_size=1)
+    net.rpn = rpn
+    cl = _Holder()
+    cl.conv1 = nn.Conv2d(256, 1024, kernel_size=7)
+    cl.bn1 = nn.BatchNorm2d(1024, eps=BN_EPS, momentum=0.01)
+    cl.conv2 = nn.Conv2d(1024, 1024, kernel_size=1)
+    cl.bn2 = nn.BatchNorm2d(1024, eps=BN_EPS, momentum=0.01)
+    cl.linear_class = nn.Linear(1024, num_classes)
+    cl.linear_bbox = nn.Linear(1024, num_classes * 4)
+    net.classifier = cl
+    mk = _Holder()
+    for i in (1, 2, 3, 4):
+        setattr(mk, f"conv{i}", nn.Conv2d(256, 256, kernel_size=3))
+        setattr(mk, f"bn{i}", nn.BatchNorm2d(256, eps=BN_EPS))
+    mk.deconv = nn.ConvTranspose2d(256, 256, kernel_size=2, stride=2)
+    mk.conv5 = nn.Conv2d(256, num_classes, kernel_size=1)
+    net.mask = mk
+    return net
+
+
+def synthetic_state_dict(arch: str = "resnet50", seed: int = 0, bn_seed: int = 1) -> dict:
+    """Random weights of the reference architecture (no checkpoint is available offline):
+    the reference's init (model.py:1021-1035: Xavier-uniform convs, zero bias, N(0,0.01) linears) under
+    torch.manual_seed(seed), plus randomised BN statistics so the folded affine is non-trivial
+    (gamma~U(.5,1.5), beta~N(0,.1), mean~N(0,.1), var~U(.5,1.5), seed bn_seed)."""
+    rng_state = torch.get_rng_state()
+    torch.manual_seed(seed)
+    net = reference_schema(arch)
+    for m in net.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+            m.bias.data.zero_()
+        elif isinstance(m, nn.Linear):
+            m.weight.data.normal_(0, 0.01)
+            m.bias.data.zero_()
+    g = torch.Generator().manual_seed(bn_seed)
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    torch.set_rng_state(rng_state)
+    return {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+
+# --------------------------------------------------------------------------------------------------
+# folding / packing
+# --------------------------------------------------------------------------------------------------
+def fold_bn(sd: dict, conv: str, bn: str | None, device):
+    """(scale, shift) with y = scale * conv_nobias(x) + shift == BN_eval(conv(x) + bias).
+    scale = gamma / sqrt(var + eps), shift = (bias - mean) * scale + beta; kept as an fp32 epilogue
+    (not folded into the weights). Without BN: scale = None, shift = bias."""
+    bias = sd.get(conv + ".bias")
+    if bn is None:
+        return None, (None if bias is None else bias.float().contiguous().to(device))
+    gamma, beta = sd[bn + ".weight"].float(), sd[bn + ".bias"].float()
+    mean, var = sd[bn + ".running_mean"].float(), sd[bn + ".running_var"].float()
+    scale = gamma / torch.sqrt(var + BN_EPS)
+    b = bias.float() if bias is not None else torch.zeros_like(mean)
+    shift = (b - mean) * scale + beta
+    return scale.contiguous().to(device), shift.contiguous().to(device)
+
+
+def pack_weight(w_oihw: torch.Tensor, device, cin_pad: int | None = None) -> torch.Tensor:
+    """OIHW → OHWI (k = (ky*KW + kx)*Cin + ci contiguous per output channel), optional Cin zero-pad."""
+    w = w_oihw.float().permute(0, 2, 3, 1)
+    if cin_pad is not None and cin_pad > w.size(3):
+        w = torch.cat([w, w.new_zeros(*w.shape[:3], cin_pad - w.size(3))], dim=3)
+    return w.contiguous().to(device)
+
+
+class FusedConv:
+    """conv (+BN) (+ReLU) with SAME-style explicit padding, NHWC."""
+
+    def __init__(self, sd, conv, bn, device, stride=1, relu=False, same_pad_kernel: int | None = None,
+                 pad=(0, 0, 0, 0), cin_pad=None):
+        self.w = pack_weight(sd[conv + ".weight"], device, cin_pad)
+        self.scale, self.shift = fold_bn(sd, conv, bn, device)
+        self.stride, self.relu, self.same_k, self.pad = stride, relu, same_pad_kernel, pad
+
+    def __call__(self, x, residual=None, res_div=1, out=None):
+        pad = ops.same_pad(x.size(1), x.size(2), self.same_k, 1) if self.same_k else self.pad
+        return ops.conv_bn_act(x, self.w, self.scale, self.shift, self.stride, pad, self.relu, residual,
+                               res_div, out)
+
+
+class FusedBottleneck:
+    """Bottleneck.forward (model.py:190-211) via torch.ops.maskrcnn.bottleneck_forward."""
+
+    def __init__(self, p):
+        self.p = p
+
+    @classmethod
+    def from_state_dict(cls, sd, prefix, stride, device):
+        pre = (prefix + ".") if prefix and not prefix.endswith(".") else prefix
+        w1 = pack_weight(sd[pre + "conv1.weight"], device)
+        s1, t1 = fold_bn(sd, pre + "conv1", pre + "bn1", device)
+        w2 = pack_weight(sd[pre + "conv2.weight"], device)
+        s2, t2 = fold_bn(sd, pre + "conv2", pre + "bn2", device)
+        w3 = pack_weight(sd[pre + "conv3.weight"], device)
+        s3, t3 = fold_bn(sd, pre + "conv3", pre + "bn3", device)
+        wd = sdn = tdn = None
+        if (pre + "downsample.0.weight") in sd:
+            wd = pack_weight(sd[pre + "downsample.0.weight"], device)
+            sdn, tdn = fold_bn(sd, pre + "downsample.0", pre + "downsample.1", device)
+        return cls((w1, s1, t1, w2, s2, t2, w3, s3, t3, wd, sdn, tdn, int(stride)))
+
+    def __call__(self, x):
+        return torch.ops.maskrcnn.bottleneck_forward(x, *self.p)
+
+
+class FusedBackbone:
+    """ResNet-FPN trunk (model.py:133-168, 223-270): NCHW molded image → [P2..P6] NHWC."""
+
+    def __init__(self, sd, arch, device, prefix="fpn."):
+        l = LAYERS[arch]
+        self.device = device
+        self.stem = FusedConv(sd, prefix + "C1.0", prefix + "C1.1", device, stride=2, relu=True,
+                              pad=(3, 3, 3, 3), cin_pad=4)
+        self.stages = []
+        for name, n, stride in (("C2", l[0], 1), ("C3", l[1], 2), ("C4", l[2], 2), ("C5", l[3], 2)):
+            self.stages.append([FusedBottleneck.from_state_dict(sd, f"{prefix}{name}.{i}",
+                                                                stride if i == 0 else 1, device)
+                                for i in range(n)])
+        self.lateral = {k: FusedConv(sd, f"{prefix}P{k}_conv1", None, device) for k in (5, 4, 3, 2)}
+        self.smooth = {k: FusedConv(sd, f"{prefix}P{k}_conv2.1", None, device, same_pad_kernel=3)
+                       for k in (5, 4, 3, 2)}
+
+    def __call__(self, image_nchw):
+        x = ops.nchw_to_nhwc(image_nchw.contiguous(), 4)       # 3 → 4 channels (zero), 16-byte pixels
+        x = self.stem(x)                                        # conv7x7 s2 p3 + BN + ReLU
+        x = ops.maxpool(x, 3, 2, ops.same_pad(x.size(1), x.size(2), 3, 2))
+        cs = []
+        for blocks in self.stages:
+            for blk in blocks:
+                x = blk(x)
+            cs.append(x)
+        c2, c3, c4, c5 = cs
+        p5 = self.lateral[5](c5)
+        p4 = self.lateral[4](c4, residual=p5, res_div=2)        # + nearest-upsampled P5 (model.py:150)
+        p3 = self.lateral[3](c3, residual=p4, res_div=2)
+        p2 = self.lateral[2](c2, residual=p3, res_div=2)
+        p5, p4, p3, p2 = self.smooth[5](p5), self.smooth[4](p4), self.smooth[3](p3), self.smooth[2](p2)
+        p6 = ops.maxpool(p5, 1, 2)                              # model.py:109,161
+        return [p2, p3, p4, p5, p6]
+
+
+class FusedRPN:
+    """RPN.forward (model.py:609-649) per level; class (6) and bbox (12) 1x1 heads fused into one
+    18-channel GEMM. Returns NHWC [B,H,W,18]: channels 0-5 = (bg,fg) logits x 3 anchors, 6-17 = deltas."""
+
+    def __init__(self, sd, device, prefix="rpn."):
+        self.shared = FusedConv(sd, prefix + "conv_shared", None, device, relu=True, same_pad_kernel=3)
+        w = torch.cat([sd[prefix + "conv_class.weight"], sd[prefix + "conv_bbox.weight"]], 0)
+        self.w_head = pack_weight(w, device)
+        self.b_head = torch.cat([sd[prefix + "conv_class.bias"], sd[prefix + "conv_bbox.bias"]]).float() \
+            .contiguous().to(device)
+
+    def __call__(self, p):
+        return ops.conv_bn_act(self.shared(p), self.w_head, None, self.b_head)
+
+
+class FusedClassifier:
+    """Classifier.forward after roi_align (model.py:782-794). Input [R,7,7,256] NHWC; the 7x7 'valid'
+    conv is one GEMM with K = 7*7*256 (OHWI weight flattening == NHWC crop flattening)."""
+
+    def __init__(self, sd, device, prefix="classifier."):
+        w1 = pack_weight(sd[prefix + "conv1.weight"], device)  # [1024,7,7,256]
+        self.pool = w1.size(1)
+        self.w1 = w1.view(w1.size(0), 1, 1, -1)
+        self.s1, self.t1 = fold_bn(sd, prefix + "conv1", prefix + "bn1", device)
+        self.conv2 = FusedConv(sd, prefix + "conv2", prefix + "bn2", device, relu=True)
+        wl = torch.cat([sd[prefix + "linear_class.weight"], sd[prefix + "linear_bbox.weight"]], 0)
+        self.w_fc = wl.float().view(wl.size(0), 1, 1, wl.size(1)).contiguous().to(device)
+        self.b_fc = torch.cat([sd[prefix + "linear_class.bias"], sd[prefix + "linear_bbox.bias"]]) \
+            .float().contiguous().to(device)
+        self.num_classes = sd[prefix + "linear_class.weight"].size(0)
+
+    def __call__(self, pooled):
+        r = pooled.size(0)
+        x = ops.conv_bn_act(pooled.view(r, 1, 1, -1), self.w1, self.s1, self.t1, relu=True)
+        x = self.conv2(x)
+        y = ops.conv_bn_act(x, self.w_fc, None, self.b_fc).view(r, -1)
+        logits = y[:, :self.num_classes]
+        bbox = y[:, self.num_classes:].reshape(r, self.num_classes, 4)
+        return logits, bbox
+
+
+class FusedMask:
+    """Mask.forward after roi_align (model.py:894-914). Input [R,14,14,256] NHWC → [R,28,28,81] NHWC.
+    The 2x2 stride-2 transposed conv is one GEMM to 4*256 channels + a pixel shuffle; its ReLU rides in
+    the GEMM epilogue (it commutes with the shuffle)."""
+
+    def __init__(self, sd, device, prefix="mask."):
+        self.convs = [FusedConv(sd, f"{prefix}conv{i}", f"{prefix}bn{i}", device, relu=True,
+                                same_pad_kernel=3) for i in (1, 2, 3, 4)]
+        wt = sd[prefix + "deconv.weight"].float()  # [Cin, Cout, 2, 2]
+        cin, cout = wt.size(0), wt.size(1)
+        # GEMM output channel = (dy*2 + dx)*Cout + co
+        self.w_de = wt.permute(2, 3, 1, 0).reshape(4 * cout, 1, 1, cin).contiguous().to(device)
+        self.b_de = sd[prefix + "deconv.bias"].float().repeat(4).contiguous().to(device)
+        self.cout = cout
+        self.conv5 = FusedConv(sd, prefix + "conv5", None, device)
+
+    def __call__(self, pooled):
+        x = pooled
+        for c in self.convs:
+            x = c(x)
+        r, h, w, _ = x.shape
+        y = ops.conv_bn_act(x, self.w_de, None, self.b_de, relu=True)          # [R,h,w,4*C]
+        y = y.view(r, h, w, 2, 2, self.cout).permute(0, 1, 3, 2, 4, 5).reshape(r, 2 * h, 2 * w, self.cout)
+        return torch.sigmoid(self.conv5(y.contiguous()))
+
+
+__all__ = ["reference_schema", "synthetic_state_dict", "fold_bn", "pack_weight", "FusedConv",
+           "FusedBottleneck", "FusedBackbone", "FusedRPN", "FusedClassifier", "FusedMask", "LAYERS",
+           "BN_EPS"]

@@ -1,0 +1,299 @@
+"""torch.ops.maskrcnn.* — thin bindings of the C ABI (include/maskrcnn_hip.h) for torch tensors.
+
+Signatures mirror the reference's pybind module c++ext/maskrcnn/csrc/vision.cpp:11-15:
+    nms(Tensor dets, float threshold) -> Tensor                                   (nms.h:15)
+    crop_forward(image, boxes, box_index, extrapolation_value, crop_height, crop_width, crops) -> ()
+                                                                                    (crop.h:14-22)
+    crop_backward(grads, boxes, box_index, grads_image) -> ()                      (crop.h:36-41)
+plus functional / batched forms used by the sync-free pipeline.
+
+PyTorch is plumbing here: device memory, the current HIP stream, and the dispatcher. All arithmetic
+happens in libmaskrcnn_hip.so. CPU tensors are rejected (mirror of the reference's "Not compiled with
+GPU support", nms.h:24): this build is GPU-only by design.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from ._lib import MaskrcnnHipError, c_i32, c_vp, check, lib
+
+_LIB = torch.library.Library("maskrcnn", "DEF")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("maskrcnn_amd: Not compiled with CPU support (tensor is on %s); "
+                               "move tensors to the GPU" % t.device)
+
+
+# --------------------------------------------------------------------------------------------------
+# NMS
+# --------------------------------------------------------------------------------------------------
+def nms_batched(dets: torch.Tensor, threshold: float, seg_counts: torch.Tensor | None = None,
+                class_ids: torch.Tensor | None = None):
+    """dets [S, N, 5] fp32 (any strides) → (keep int64 [S, N] ascending indices padded with -1,
+    counts int32 [S]). No host synchronisation."""
+    _need_gpu(dets, seg_counts, class_ids)
+    if dets.dtype != torch.float32:
+        raise RuntimeError(f'"nms" GPU path implemented for Float only, got {dets.dtype}')
+    assert dets.dim() == 3 and dets.size(2) >= 5
+    s, n = dets.size(0), dets.size(1)
+    keep = torch.empty(s, n, dtype=torch.int64, device=dets.device)
+    counts = torch.empty(s, dtype=torch.int32, device=dets.device)
+    if seg_counts is not None:
+        assert seg_counts.dtype == torch.int32 and seg_counts.is_contiguous() and seg_counts.numel() == s
+    if class_ids is not None:
+        assert class_ids.dtype == torch.int32 and class_ids.is_contiguous() and class_ids.numel() == s * n
+    check(lib.mrcnn_nms_batched_f32(dets.data_ptr(), s, n, dets.stride(0), dets.stride(1),
+                                    dets.stride(2), _ptr(seg_counts), _ptr(class_ids),
+                                    float(threshold), keep.data_ptr(), counts.data_ptr(), _stream()))
+    return keep, counts
+
+
+def _nms(dets: torch.Tensor, threshold: float) -> torch.Tensor:
+    """Reference call shape: [N,5] → int64 [K] ascending input indices on dets.device.
+    (The data-dependent output length costs one 4-byte D2H read; use nms_batched to stay async.)"""
+    _need_gpu(dets)
+    if dets.numel() == 0:  # nms.h:20-21
+        return torch.empty(0, dtype=torch.int64, device=dets.device)
+    if dets.dim() != 2 or dets.size(1) < 5:
+        raise RuntimeError("nms: dets must be [N, 5]")
+    keep, counts = nms_batched(dets.unsqueeze(0), threshold)
+    return keep[0, :int(counts.item())]
+
+
+_LIB.define("nms(Tensor dets, float threshold) -> Tensor")
+_LIB.impl("nms", _nms, "CUDA")
+_LIB.impl("nms", lambda dets, threshold: _need_gpu(dets), "CPU")
+
+
+# --------------------------------------------------------------------------------------------------
+# crop_and_resize
+# --------------------------------------------------------------------------------------------------
+def _check_crop_inputs(image, boxes, box_index):
+    _need_gpu(image, boxes, box_index)
+    if image.dtype != torch.float32 or boxes.dtype != torch.float32:
+        raise RuntimeError("crop: expected scalar type Float for image and boxes")
+    if box_index.dtype != torch.int32:
+        raise RuntimeError("crop: expected scalar type Int for box_index")
+    if image.dim() != 4 or boxes.dim() != 2 or boxes.size(1) != 4 or box_index.numel() != boxes.size(0):
+        raise RuntimeError("crop: image [B,C,H,W], boxes [N,4], box_index [N] expected")
+
+
+def crop(image: torch.Tensor, boxes: torch.Tensor, box_index: torch.Tensor,
+         extrapolation_value: float, crop_height: int, crop_width: int) -> torch.Tensor:
+    """Functional form: returns a fresh [N, C, crop_height, crop_width] tensor."""
+    _check_crop_inputs(image, boxes, box_index)
+    image, boxes, box_index = image.contiguous(), boxes.contiguous(), box_index.contiguous()
+    b, c, h, w = image.shape
+    n = boxes.size(0)
+    crops = torch.empty(n, c, crop_height, crop_width, dtype=torch.float32, device=image.device)
+    check(lib.mrcnn_crop_forward_f32(image.data_ptr(), b, c, h, w, boxes.data_ptr(),
+                                     box_index.data_ptr(), n, float(extrapolation_value),
+                                     int(crop_height), int(crop_width), crops.data_ptr(), _stream()))
+    return crops
+
+
+def _crop_forward(image, boxes, box_index, extrapolation_value, crop_height, crop_width, crops):
+    """Out-param form of crop.h:14-22: `crops` is resized to [N,C,h,w] and overwritten
+    (crop_cpu.cpp:141-143)."""
+    _check_crop_inputs(image, boxes, box_index)
+    _need_gpu(crops)
+    if crops.dtype != torch.float32:
+        raise RuntimeError("crop_forward: expected scalar type Float for crops")
+    image, boxes, box_index = image.contiguous(), boxes.contiguous(), box_index.contiguous()
+    b, c, h, w = image.shape
+    n = boxes.size(0)
+    crops.resize_(n, c, crop_height, crop_width)
+    check(lib.mrcnn_crop_forward_f32(image.data_ptr(), b, c, h, w, boxes.data_ptr(),
+                                     box_index.data_ptr(), n, float(extrapolation_value),
+                                     int(crop_height), int(crop_width), crops.data_ptr(), _stream()))
+
+
+def _crop_backward(grads, boxes, box_index, grads_image):
+    _need_gpu(grads, boxes, box_index, grads_image)
+    if grads.dtype != torch.float32 or boxes.dtype != torch.float32 or grads_image.dtype != torch.float32:
+        raise RuntimeError("crop_backward: expected scalar type Float")
+    if box_index.dtype != torch.int32:
+        raise RuntimeError("crop_backward: expected scalar type Int for box_index")
+    if not grads_image.is_contiguous() or grads_image.dim() != 4:
+        raise RuntimeError("crop_backward: grads_image must be a contiguous [B,C,H,W] tensor")
+    grads, boxes, box_index = grads.contiguous(), boxes.contiguous(), box_index.contiguous()
+    b, c, h, w = grads_image.shape
+    n, gc, ch, cw = grads.shape
+    if gc != c:
+        raise RuntimeError("crop_backward: channel mismatch")
+    check(lib.mrcnn_crop_backward_f32(grads.data_ptr(), boxes.data_ptr(), box_index.data_ptr(), n, b,
+                                      c, h, w, ch, cw, grads_image.data_ptr(), _stream()))
+
+
+_LIB.define("crop_forward(Tensor image, Tensor boxes, Tensor box_index, float extrapolation_value, "
+            "int crop_height, int crop_width, Tensor(a!) crops) -> ()")
+_LIB.impl("crop_forward", _crop_forward, "CUDA")
+_LIB.impl("crop_forward", lambda image, *a: _need_gpu(image), "CPU")
+_LIB.define("crop_backward(Tensor grads, Tensor boxes, Tensor box_index, Tensor(a!) grads_image) -> ()")
+_LIB.impl("crop_backward", _crop_backward, "CUDA")
+_LIB.impl("crop_backward", lambda grads, *a: _need_gpu(grads), "CPU")
+_LIB.define("crop(Tensor image, Tensor boxes, Tensor box_index, float extrapolation_value, "
+            "int crop_height, int crop_width) -> Tensor")
+_LIB.impl("crop", crop, "CUDA")
+_LIB.impl("crop", lambda image, *a: _need_gpu(image), "CPU")
+
+
+def roi_align_pyramid(feature_maps, rois: torch.Tensor, pool: int, image_area: float,
+                      rois_per_image: int | None = None, roi_batch: torch.Tensor | None = None,
+                      return_levels: bool = False):
+    """model.py:276-393 in one launch on channels-last maps.
+
+    feature_maps: [P2,P3,P4,P5], each a contiguous fp32 [B, H_l, W_l, C] (NHWC) tensor.
+    rois [R,4] normalised. Returns [R, pool, pool, C] (NHWC) in roi order (+ int32 levels)."""
+    assert len(feature_maps) == 4
+    _need_gpu(rois, roi_batch, *feature_maps)
+    rois = rois.contiguous()
+    b, _, _, c = feature_maps[0].shape
+    for fm in feature_maps:
+        assert fm.is_contiguous() and fm.dtype == torch.float32 and fm.size(0) == b and fm.size(3) == c
+    r = rois.size(0)
+    out = torch.empty(r, pool, pool, c, dtype=torch.float32, device=rois.device)
+    levels = torch.empty(r, dtype=torch.int32, device=rois.device) if return_levels else None
+    ptrs = (c_vp * 4)(*[fm.data_ptr() for fm in feature_maps])
+    hs = (c_i32 * 4)(*[fm.size(1) for fm in feature_maps])
+    ws = (c_i32 * 4)(*[fm.size(2) for fm in feature_maps])
+    if roi_batch is not None:
+        assert roi_batch.dtype == torch.int32 and roi_batch.is_contiguous()
+    check(lib.mrcnn_roi_align_pyramid_nhwc_f32(ptrs, hs, ws, b, c, rois.data_ptr(), _ptr(roi_batch), r,
+                                               int(rois_per_image or 0), int(pool),
+                                               float(image_area), out.data_ptr(), _ptr(levels),
+                                               _stream()))
+    return (out, levels) if return_levels else out
+
+
+__all__ = ["nms_batched", "crop", "roi_align_pyramid", "MaskrcnnHipError"]
+
+
+# --------------------------------------------------------------------------------------------------
+# conv + BN + ReLU (+ residual), channels-last
+# --------------------------------------------------------------------------------------------------
+def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
+                shift: torch.Tensor | None, stride: int = 1, pad=(0, 0, 0, 0), relu: bool = False,
+                residual: torch.Tensor | None = None, res_div: int = 1,
+                out: torch.Tensor | None = None) -> torch.Tensor:
+    """y = act(scale * conv(x, w) + shift + residual).
+
+    x [B,H,W,Cin] NHWC fp32 contiguous; w [Cout,KH,KW,Cin] (OHWI) contiguous; scale/shift [Cout] or
+    None; pad = (top, left, bottom, right) zero padding applied on the fly; residual [B,OH/res_div,
+    OW/res_div,Cout]. Returns y [B,OH,OW,Cout] NHWC."""
+    _need_gpu(x, w, scale, shift, residual)
+    assert x.dtype == torch.float32 and w.dtype == torch.float32
+    assert x.is_contiguous() and w.is_contiguous() and x.dim() == 4 and w.dim() == 4
+    b, h, wd, cin = x.shape
+    cout, kh, kw, wcin = w.shape
+    if wcin != cin:
+        raise RuntimeError(f"conv_bn_act: weight Cin {wcin} != input Cin {cin}")
+    pt, pl, pb, pr = [int(v) for v in pad]
+    oh = (h + pt + pb - kh) // stride + 1
+    ow = (wd + pl + pr - kw) // stride + 1
+    if out is None:
+        out = torch.empty(b, oh, ow, cout, dtype=torch.float32, device=x.device)
+    else:
+        assert out.is_contiguous() and tuple(out.shape) == (b, oh, ow, cout)
+    for t in (scale, shift):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == cout)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.dtype == torch.float32
+        assert tuple(residual.shape) == (b, oh // res_div, ow // res_div, cout), \
+            f"residual {tuple(residual.shape)} vs output {(b, oh, ow, cout)} / {res_div}"
+    check(lib.mrcnn_conv_bn_act_nhwc_f32(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout, kh, kw,
+                                         int(stride), pt, pl, pb, pr, _ptr(scale), _ptr(shift),
+                                         _ptr(residual), int(res_div), int(bool(relu)),
+                                         out.data_ptr(), _stream()))
+    return out
+
+
+def _conv_bn_act_op(x, w, scale, shift, stride, pad, relu, residual, res_div):
+    return conv_bn_act(x, w, scale, shift, stride, pad, relu, residual, res_div)
+
+
+_LIB.define("conv_bn_act(Tensor x, Tensor w, Tensor? scale, Tensor? shift, int stride, int[] pad, "
+            "bool relu, Tensor? residual, int res_div) -> Tensor")
+_LIB.impl("conv_bn_act", _conv_bn_act_op, "CUDA")
+_LIB.impl("conv_bn_act", lambda x, *a: _need_gpu(x), "CPU")
+
+
+def same_pad(size_a: int, size_b: int, kernel: int, stride: int):
+    """SamePad2d (model.py:64-87) as (top, left, bottom, right) for a [.., size_a, size_b] (H, W) input.
+    The reference computes the LAST-dim pad from size(2) and vice versa (its width/height names are
+    swapped); reproduced as written — it only matters when H and W need different pad amounts."""
+    import math
+    out_a = math.ceil(float(size_a) / float(stride))
+    out_b = math.ceil(float(size_b) / float(stride))
+    pad_a = max((out_a - 1) * stride + kernel - size_a, 0)
+    pad_b = max((out_b - 1) * stride + kernel - size_b, 0)
+    a_lo, b_lo = pad_a // 2, pad_b // 2
+    # F.pad(input, (a_lo, a_hi, b_lo, b_hi)): first pair → last dim (W), second pair → H
+    return (b_lo, a_lo, pad_b - b_lo, pad_a - a_lo)
+
+
+def maxpool(x: torch.Tensor, kernel: int, stride: int, pad=(0, 0, 0, 0)) -> torch.Tensor:
+    """Zero-padded max-pool on NHWC fp32 (stem pool: kernel 3, stride 2, pad = same_pad(H, W, 3, 2);
+    P6: kernel 1, stride 2)."""
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 4
+    b, h, w, c = x.shape
+    pt, pl, pb, pr = [int(v) for v in pad]
+    oh = (h + pt + pb - kernel) // stride + 1
+    ow = (w + pl + pr - kernel) // stride + 1
+    y = torch.empty(b, oh, ow, c, dtype=torch.float32, device=x.device)
+    check(lib.mrcnn_maxpool_nhwc_f32(x.data_ptr(), b, h, w, c, int(kernel), int(stride), pt, pl, pb, pr,
+                                     y.data_ptr(), _stream()))
+    return y
+
+
+def nchw_to_nhwc(x: torch.Tensor, channels_padded: int | None = None) -> torch.Tensor:
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 4
+    b, c, h, w = x.shape
+    cp = int(channels_padded or c)
+    y = torch.empty(b, h, w, cp, dtype=torch.float32, device=x.device)
+    check(lib.mrcnn_nchw_to_nhwc_f32(x.data_ptr(), b, c, h, w, cp, y.data_ptr(), _stream()))
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 4
+    b, h, w, c = x.shape
+    y = torch.empty(b, c, h, w, dtype=torch.float32, device=x.device)
+    check(lib.mrcnn_nhwc_to_nchw_f32(x.data_ptr(), b, c, h, w, y.data_ptr(), _stream()))
+    return y
+
+
+def bottleneck_forward(x, w1, s1, t1, w2, s2, t2, w3, s3, t3, wd, sd, td, stride: int):
+    """Bottleneck.forward (model.py:190-211) on NHWC: conv1 1x1 (stride) + BN + ReLU → SamePad(3,1) +
+    conv2 3x3 + BN + ReLU → conv3 1x1 + BN, + residual (identity or 1x1-stride downsample + BN), ReLU.
+    Four (three without downsample) fused conv launches; BN/bias are (scale, shift) epilogues."""
+    h = conv_bn_act(x, w1, s1, t1, stride=stride, relu=True)
+    pad = same_pad(h.size(1), h.size(2), 3, 1)
+    h = conv_bn_act(h, w2, s2, t2, stride=1, pad=pad, relu=True)
+    res = x if wd is None else conv_bn_act(x, wd, sd, td, stride=stride, relu=False)
+    return conv_bn_act(h, w3, s3, t3, stride=1, relu=True, residual=res)
+
+
+_LIB.define("bottleneck_forward(Tensor x, Tensor w1, Tensor s1, Tensor t1, Tensor w2, Tensor s2, "
+            "Tensor t2, Tensor w3, Tensor s3, Tensor t3, Tensor? wd, Tensor? sd, Tensor? td, "
+            "int stride) -> Tensor")
+_LIB.impl("bottleneck_forward", bottleneck_forward, "CUDA")
+_LIB.impl("bottleneck_forward", lambda x, *a: _need_gpu(x), "CPU")
+
+__all__ += ["conv_bn_act", "same_pad", "maxpool", "nchw_to_nhwc", "nhwc_to_nchw", "bottleneck_forward"]

@@ -1,0 +1,178 @@
+"""Batched, host-sync-free counterpart of MaskRCNN.predict (reference model.py:1140-1203).
+
+    trunk (C1-C5 + FPN) → RPN → proposal decode + NMS → RoIAlign 7x7 → classifier head
+          → per-class NMS + top-k → RoIAlign 14x14 → mask head
+
+Differences from the reference, all by design:
+  * any batch size (the reference is batch-1 everywhere: model.py:296,1321,1349);
+  * fixed shapes: every image carries `proposal_count` proposal slots and `detection_max_instances`
+    detection slots, zero-padded, with int32 valid counts — so there is no nonzero()/unique()/item()
+    host synchronisation anywhere and the whole step can be captured in a hipGraph;
+  * the Python per-class loop (model.py:1454-1475) is one class-aware NMS launch per batch;
+  * activations are channels-last (NHWC) between the NCHW boundary and the outputs.
+Heavy work (convs/GEMMs, RoIAlign, NMS) runs in libmaskrcnn_hip.so; torch does device memory, streams
+and the small elementwise/top-k glue (softmax over pairs, top-k, gathers, box decode).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import modules, ops
+from .anchors import pyramid_anchors
+from .config import InferenceConfig
+
+
+def boxes_refine(boxes: torch.Tensor, deltas: torch.Tensor) -> torch.Tensor:
+    """data.py:124-148, same fp32 op order, on [..., 4] tensors."""
+    height = boxes[..., 2] - boxes[..., 0]
+    width = boxes[..., 3] - boxes[..., 1]
+    center_y = boxes[..., 0] + 0.5 * height
+    center_x = boxes[..., 1] + 0.5 * width
+    center_y = center_y + deltas[..., 0] * height
+    center_x = center_x + deltas[..., 1] * width
+    height = height * torch.exp(deltas[..., 2])
+    width = width * torch.exp(deltas[..., 3])
+    y1 = center_y - 0.5 * height
+    x1 = center_x - 0.5 * width
+    return torch.stack([y1, x1, y1 + height, x1 + width], dim=-1)
+
+
+@dataclass
+class Detections:
+    """Fixed-shape result for a batch of B images (D = detection_max_instances)."""
+    class_ids: torch.Tensor   # int64 [B, D]   0 in unused slots
+    scores: torch.Tensor      # fp32  [B, D]
+    boxes: torch.Tensor       # fp32  [B, D, 4] pixel (y1,x1,y2,x2), integral-valued
+    counts: torch.Tensor      # int32 [B] valid detections per image
+    masks: torch.Tensor | None  # fp32 [B, D, 28, 28, num_classes] (NHWC) sigmoid masks
+
+    def packed(self) -> torch.Tensor:
+        """[B, D, 6] fp32 (class_id, score, y1, x1, y2, x2): the all-gather payload."""
+        return torch.cat([self.class_ids.float().unsqueeze(-1), self.scores.unsqueeze(-1), self.boxes], -1)
+
+
+class MaskRCNNInference:
+    def __init__(self, state_dict: dict, cfg: InferenceConfig | None = None, device="cuda:0"):
+        self.cfg = cfg or InferenceConfig()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("MaskRCNNInference runs on the GPU only (no CPU path)")
+        c = self.cfg
+        self.backbone = modules.FusedBackbone(state_dict, c.backbone, self.device)
+        self.rpn = modules.FusedRPN(state_dict, self.device)
+        self.classifier = modules.FusedClassifier(state_dict, self.device)
+        self.mask = modules.FusedMask(state_dict, self.device)
+        self.anchors = pyramid_anchors(c).to(self.device)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.std = torch.tensor(c.rpn_bbox_std_dev, **f32)
+        h, w = c.image_height, c.image_width
+        self.norm = torch.tensor([h, w, h, w], **f32)
+        self.image_area = float(h * w)
+
+    # ---------------------------------------------------------------- stage 1: proposals
+    def rpn_heads(self, fms):
+        """rpn_detect (model.py:1294-1304) → fg scores [B,A], deltas [B,A,4], A = 261888 at 1024^2."""
+        b = fms[0].size(0)
+        logits, deltas = [], []
+        for p in fms:
+            y = self.rpn(p)                                   # [B,H,W,18]
+            logits.append(y[..., :6].reshape(b, -1, 2))       # NHWC == permute(0,2,3,1) of model.py:627
+            deltas.append(y[..., 6:].reshape(b, -1, 4))
+        logits, deltas = torch.cat(logits, 1), torch.cat(deltas, 1)
+        return torch.softmax(logits, dim=2)[..., 1], deltas
+
+    def proposals(self, scores, deltas):
+        """rpn_refine (model.py:1307-1382), batched. → rois [B,P,4] normalised (zero beyond count),
+        counts int32 [B], plus the dets handed to NMS (for parity tests)."""
+        c = self.cfg
+        k = min(c.pre_nms_limit, self.anchors.size(0))
+        top, order = scores.topk(k, dim=1, sorted=True)                  # model.py:1345-1348
+        d = deltas.gather(1, order.unsqueeze(-1).expand(-1, -1, 4)) * self.std   # :1341,1349
+        boxes = boxes_refine(self.anchors[order], d)                     # :1350-1354
+        hi = self.norm.view(1, 1, 4)
+        boxes = torch.minimum(torch.maximum(boxes, torch.zeros_like(boxes)), hi.expand_as(boxes))  # :1358
+        dets = torch.cat([boxes, top.unsqueeze(-1)], dim=2).contiguous()
+        keep, counts = ops.nms_batched(dets, c.rpn_nms_threshold)        # :1364, score order == index order
+        p = min(c.proposal_count, k)
+        counts = counts.clamp(max=p)                                     # keep[:proposal_count] :1366
+        idx = keep[:, :p]
+        valid = idx >= 0
+        rois = boxes.gather(1, idx.clamp(min=0).unsqueeze(-1).expand(-1, -1, 4)) / self.norm  # :1367-1374
+        rois = torch.where(valid.unsqueeze(-1), rois, torch.zeros_like(rois))
+        return rois, counts, dets
+
+    # ---------------------------------------------------------------- stage 2: detections
+    def detections(self, rois, roi_counts, logits, bbox, windows):
+        """mrn_refine (model.py:1389-1487), batched and sync-free.
+        rois [B,P,4]; logits [B*P,C]; bbox [B*P,C,4]; windows [B,4] pixel (y1,x1,y2,x2)."""
+        c = self.cfg
+        b, p, _ = rois.shape
+        probs = torch.softmax(logits, dim=1)                              # model.py:791
+        class_scores, class_ids = probs.max(dim=1)                        # :1407,1414
+        deltas = bbox.gather(1, class_ids.view(-1, 1, 1).expand(-1, 1, 4)).squeeze(1)   # :1415
+        refined = boxes_refine(rois.reshape(-1, 4), deltas * self.std)    # :1418-1422
+        boxes = (refined * self.norm).view(b, p, 4)                       # :1426
+        w = windows.to(boxes.dtype).view(b, 1, 4)
+        lo = torch.stack([w[..., 0], w[..., 1], w[..., 0], w[..., 1]], -1)
+        hi = torch.stack([w[..., 2], w[..., 3], w[..., 2], w[..., 3]], -1)
+        boxes = torch.round(torch.minimum(torch.maximum(boxes, lo), hi))  # :1429-1432
+        class_ids = class_ids.view(b, p)
+        class_scores = class_scores.view(b, p)
+        slot = torch.arange(p, device=rois.device).view(1, p)
+        valid = (class_ids > 0) & (slot < roi_counts.view(b, 1))          # :1437 (+ padded slots)
+        if c.detection_min_confidence:
+            valid = valid & (class_scores >= c.detection_min_confidence)  # :1441-1442
+        # per-class NMS (:1454-1475) as ONE class-aware pass per image; excluded slots get a unique
+        # negative class so they neither suppress nor are suppressed
+        cls = torch.where(valid, class_ids, -(slot + 1).expand(b, p)).to(torch.int32).contiguous()
+        dets = torch.cat([boxes, class_scores.unsqueeze(-1)], dim=2).contiguous()
+        keep, _ = ops.nms_batched(dets, c.detection_nms_threshold, class_ids=cls)
+        kept = torch.zeros(b, p + 1, dtype=torch.bool, device=rois.device)
+        kept.scatter_(1, keep + 1, True)                                   # -1 padding lands in column 0
+        kept = kept[:, 1:] & valid
+        d = min(c.detection_max_instances, p)
+        masked = torch.where(kept, class_scores, torch.full_like(class_scores, -1.0))
+        top, idx = masked.topk(d, dim=1, sorted=True)                     # :1478-1480
+        ok = top >= 0
+        counts = ok.sum(dim=1).to(torch.int32)
+        out_ids = torch.where(ok, class_ids.gather(1, idx), torch.zeros_like(idx))
+        out_scores = torch.where(ok, top, torch.zeros_like(top))
+        out_boxes = boxes.gather(1, idx.unsqueeze(-1).expand(-1, -1, 4))
+        out_boxes = torch.where(ok.unsqueeze(-1), out_boxes, torch.zeros_like(out_boxes))
+        return out_ids, out_scores, out_boxes, counts
+
+    # ---------------------------------------------------------------- whole step
+    @torch.no_grad()
+    def predict(self, images: torch.Tensor, windows: torch.Tensor, with_masks: bool = True,
+                return_intermediates: bool = False):
+        """images [B,3,H,W] fp32 NCHW, already molded (resized/padded, mean-subtracted: model.py:1102-1110);
+        windows [B,4] pixel (y1,x1,y2,x2) of the un-padded image area."""
+        c = self.cfg
+        assert images.is_cuda and images.dtype == torch.float32
+        b = images.size(0)
+        assert tuple(images.shape[1:]) == (3, c.image_height, c.image_width)
+        fms = self.backbone(images)                                        # [P2..P6] NHWC
+        scores, deltas = self.rpn_heads(fms)
+        rois, roi_counts, rpn_dets = self.proposals(scores, deltas)
+        p = rois.size(1)
+        flat = rois.reshape(-1, 4).contiguous()
+        pooled = ops.roi_align_pyramid(fms[:4], flat, c.pool_size, self.image_area, rois_per_image=p)
+        logits, bbox = self.classifier(pooled)
+        ids, det_scores, boxes, counts = self.detections(rois, roi_counts, logits, bbox,
+                                                         windows.to(self.device))
+        masks = None
+        if with_masks:
+            d = boxes.size(1)
+            # the reference divides all four coordinates by h (model.py:1188), which is only right for
+            # square inputs; here (y,x) are divided by (h,w)
+            mrois = (boxes / self.norm).reshape(-1, 4).contiguous()
+            mp = ops.roi_align_pyramid(fms[:4], mrois, c.mask_pool_size, self.image_area, rois_per_image=d)
+            m = self.mask(mp)
+            masks = m.view(b, d, m.size(1), m.size(2), m.size(3))
+        det = Detections(ids, det_scores, boxes, counts, masks)
+        if return_intermediates:
+            return det, dict(feature_maps=fms, rpn_scores=scores, rpn_deltas=deltas, rois=rois,
+                             roi_counts=roi_counts, rpn_dets=rpn_dets, logits=logits, bbox=bbox)
+        return det

@@ -1,0 +1,138 @@
+"""GPU parity tests (-m gpu) for the fused conv+BN+ReLU implicit-GEMM kernel and its helpers against
+a torch CPU fp32 reference of the same op (this is the floating-point kernel: tolerance 1e-4 abs, the
+bound BASELINE.json's north_star states, at controlled input scale: x ~ N(0,1), Xavier weights)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    import maskrcnn_amd  # noqa: F401
+    return torch.device("cuda:0")
+
+
+def _ref_conv(x_nchw, w_oihw, scale, shift, stride, pad, relu, residual_nchw=None, res_div=1):
+    pt, pl, pb, pr = pad
+    y = F.conv2d(F.pad(x_nchw, (pl, pr, pt, pb)), w_oihw, None, stride=stride)
+    if scale is not None:
+        y = y * scale.view(1, -1, 1, 1)
+    if shift is not None:
+        y = y + shift.view(1, -1, 1, 1)
+    if residual_nchw is not None:
+        r = residual_nchw if res_div == 1 else F.interpolate(residual_nchw, scale_factor=res_div)
+        y = y + r
+    return F.relu(y) if relu else y
+
+
+CASES = [
+    # (B, H, W, Cin, Cout, k, stride, pad, relu, residual(0/1/2), affine)
+    (2, 16, 16, 64, 64, 1, 1, (0, 0, 0, 0), True, 0, True),       # C2 conv1
+    (2, 16, 16, 64, 64, 3, 1, (1, 1, 1, 1), True, 0, True),       # C2 conv2
+    (2, 16, 16, 64, 256, 1, 1, (0, 0, 0, 0), True, 1, True),      # C2 conv3 + residual
+    (2, 16, 16, 256, 128, 1, 2, (0, 0, 0, 0), True, 0, True),     # C3 conv1 stride 2
+    (1, 16, 16, 256, 512, 1, 2, (0, 0, 0, 0), False, 0, True),    # C3 downsample
+    (1, 8, 8, 512, 512, 3, 1, (1, 1, 1, 1), True, 0, True),       # C5 conv2, K = 4608
+    (1, 8, 8, 2048, 512, 1, 1, (0, 0, 0, 0), True, 0, True),      # C5 conv1, K = 2048
+    (1, 8, 8, 2048, 256, 1, 1, (0, 0, 0, 0), False, 0, False),    # P5 lateral (bias only)
+    (2, 16, 16, 1024, 256, 1, 1, (0, 0, 0, 0), False, 2, False),  # P4 lateral + 2x-upsampled residual
+    (1, 32, 32, 256, 256, 3, 1, (1, 1, 1, 1), False, 0, False),   # FPN smoothing
+    (1, 16, 16, 256, 512, 3, 1, (1, 1, 1, 1), True, 0, False),    # RPN shared
+    (1, 16, 16, 512, 18, 1, 1, (0, 0, 0, 0), False, 0, False),    # RPN class+bbox heads fused, N = 18
+    (2, 64, 64, 4, 64, 7, 2, (3, 3, 3, 3), True, 0, True),        # stem, Cin padded 3 -> 4 (generic K)
+    (3, 13, 11, 32, 48, 3, 1, (1, 1, 1, 1), True, 1, True),       # ragged: odd sizes, N % 32 != 0
+    (1, 9, 7, 32, 40, 3, 2, (0, 0, 1, 1), False, 0, True),        # asymmetric SAME pad (0,0,1,1)
+    (37, 1, 1, 12544, 1024, 1, 1, (0, 0, 0, 0), True, 0, True),   # classifier conv1 as GEMM (K = 7*7*256)
+    (300, 1, 1, 1024, 405, 1, 1, (0, 0, 0, 0), False, 0, False),  # class + bbox FC fused (N = 81 + 324)
+    (1, 5, 5, 32, 8, 3, 1, (1, 1, 1, 1), False, 0, False),        # tiny M = 25
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c[:7]))
+def test_conv_bn_act_vs_torch_cpu(dev, case):
+    from maskrcnn_amd import ops
+    b, h, w, cin, cout, k, stride, pad, relu, res, affine = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(b, cin, h, w, generator=g)
+    fan = cin * k * k
+    wt = (torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * math.sqrt(6.0 / (fan + cout * k * k))
+    scale = (torch.rand(cout, generator=g) + 0.5) if affine else None
+    shift = torch.randn(cout, generator=g) * 0.1
+    oh = (h + pad[0] + pad[2] - k) // stride + 1
+    ow = (w + pad[1] + pad[3] - k) // stride + 1
+    residual = None
+    if res:
+        residual = torch.randn(b, cout, oh // res, ow // res, generator=g)
+    want = _ref_conv(x, wt, scale, shift, stride, pad, relu, residual, max(res, 1))
+    to_nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    got = ops.conv_bn_act(to_nhwc(x), to_nhwc(wt), None if scale is None else scale.to(dev),
+                          shift.to(dev), stride, pad, relu,
+                          None if residual is None else to_nhwc(residual), max(res, 1))
+    got = got.permute(0, 3, 1, 2).cpu()
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item()
+    assert err <= TOL, f"max abs err {err:.3e}"
+
+
+def test_conv_exactness_identity(dev):
+    """A = I check with asymmetric data: a 1x1 conv with identity weights must copy x bit for bit, and
+    a permutation weight must permute channels exactly (catches fragment/row-col mapping slips)."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 9, 10, 64, generator=g).to(dev)
+    eye = torch.eye(64).view(64, 1, 1, 64).contiguous().to(dev)
+    assert torch.equal(ops.conv_bn_act(x, eye, None, None), x)
+    perm = torch.randperm(64, generator=g)
+    pw = torch.eye(64)[perm].view(64, 1, 1, 64).contiguous().to(dev)
+    assert torch.equal(ops.conv_bn_act(x, pw, None, None), x[..., perm.to(dev)])
+    # integer-valued data: every product/sum exact in fp32 → must match the CPU bit for bit
+    xi = torch.randint(-4, 5, (1, 64, 12, 12), generator=g).float()
+    wi = torch.randint(-3, 4, (96, 64, 3, 3), generator=g).float()
+    want = F.conv2d(xi, wi, padding=1)
+    got = ops.conv_bn_act(xi.permute(0, 2, 3, 1).contiguous().to(dev),
+                          wi.permute(0, 2, 3, 1).contiguous().to(dev), None, None, 1, (1, 1, 1, 1))
+    assert torch.equal(got.permute(0, 3, 1, 2).cpu(), want)
+
+
+def test_bottleneck_golden(dev):
+    """Reference Bottleneck modules (weights stored in the fixture) vs the fused op."""
+    from maskrcnn_amd import modules
+    z = load_golden("graph_small")
+    for i in range(int(z["n_bottleneck"])):
+        sd = {k[len(f"b{i}_sd_"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"b{i}_sd_")}
+        x = torch.from_numpy(z[f"b{i}_x"])
+        cin = x.size(1)
+        if cin % 4:
+            continue
+        blk = modules.FusedBottleneck.from_state_dict(sd, "", int(z[f"b{i}_stride"]), dev)
+        y = blk(x.permute(0, 2, 3, 1).contiguous().to(dev)).permute(0, 3, 1, 2).cpu()
+        err = (y - torch.from_numpy(z[f"b{i}_y"])).abs().max().item()
+        assert err <= TOL, (i, err)
+
+
+def test_maxpool_and_layout(dev):
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(2)
+    for (b, c, h, w) in [(2, 64, 16, 16), (1, 8, 9, 12), (1, 4, 7, 7)]:
+        x = torch.randn(b, c, h, w, generator=g)  # signed: the zero pad must take part in the max
+        pad = ops.same_pad(h, w, 3, 2)
+        want = F.max_pool2d(F.pad(x, (pad[1], pad[3], pad[0], pad[2])), 3, 2)
+        xn = ops.nchw_to_nhwc(x.to(dev))
+        assert torch.equal(xn.cpu(), x.permute(0, 2, 3, 1))
+        got = ops.nhwc_to_nchw(ops.maxpool(xn, 3, 2, pad)).cpu()
+        assert torch.equal(got, want)
+        p6 = ops.nhwc_to_nchw(ops.maxpool(xn, 1, 2)).cpu()
+        assert torch.equal(p6, x[:, :, ::2, ::2])
+    x3 = torch.randn(2, 3, 10, 6, generator=g)
+    y = ops.nchw_to_nhwc(x3.to(dev), 4).cpu()
+    assert torch.equal(y[..., :3], x3.permute(0, 2, 3, 1)) and bool((y[..., 3] == 0).all())
+    assert ops.same_pad(8, 8, 3, 2) == (0, 0, 1, 1) and ops.same_pad(8, 8, 3, 1) == (1, 1, 1, 1)

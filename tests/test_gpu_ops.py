@@ -1,0 +1,235 @@
+"""GPU parity tests (-m gpu): the HIP path (through the C ABI in libmaskrcnn_hip.so) against the CPU
+oracle and the committed golden vectors. NMS keep indices and crop/RoIAlign activations are compared
+BIT-EXACT (the kernels restate the reference's fp32 op order with FP contraction off); crop_backward
+(atomic accumulation order) within 1e-5 abs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    import maskrcnn_amd  # noqa: F401  must load libmaskrcnn_hip.so or fail loudly
+    return torch.device("cuda:0")
+
+
+def _cases(z):
+    i = 0
+    while f"c{i}_tag" in z.files:
+        yield i, str(z[f"c{i}_tag"])
+        i += 1
+
+
+def _rand_dets(g, n, extent=600.0, spread=10.0):
+    k = max(1, n // 10)
+    centres = torch.rand(k, 2, generator=g) * extent
+    c = centres[torch.randint(0, k, (n,), generator=g)] + torch.randn(n, 2, generator=g) * spread
+    hw = torch.exp(torch.rand(n, 2, generator=g) * 2.5 + 2.0)
+    b = torch.cat([c - hw / 2, c + hw / 2], 1).clamp(0, extent)
+    s = (torch.randperm(n, generator=g).float() + torch.rand(n, generator=g) * 0.5) / n  # distinct
+    return torch.cat([b, s[:, None]], 1)
+
+
+# ---------------------------------------------------------------------------------------------- NMS
+def test_nms_golden(dev):
+    import maskrcnn
+    z = load_golden("nms")
+    for i, tag in _cases(z):
+        dets = torch.from_numpy(z[f"c{i}_dets"])
+        if dets.dtype == torch.float64:
+            with pytest.raises(RuntimeError):
+                maskrcnn.nms(dets.to(dev), float(z[f"c{i}_thr"]))
+            continue
+        keep = maskrcnn.nms(dets.to(dev), float(z[f"c{i}_thr"]))
+        assert keep.dtype == torch.int64 and keep.device.type == "cuda"
+        assert np.array_equal(keep.cpu().numpy(), z[f"c{i}_keep"]), tag
+    z = load_golden("nms_strided")
+    wide = torch.from_numpy(z["wide"]).to(dev)
+    assert np.array_equal(maskrcnn.nms(wide[:, 1:6], float(z["thr"])).cpu().numpy(), z["keep"])
+    assert maskrcnn.nms(torch.zeros(0, 5, device=dev), 0.5).numel() == 0
+
+
+def test_nms_random_vs_oracle(dev, oracle):
+    import maskrcnn
+    g = torch.Generator().manual_seed(7)
+    for n in (1, 5, 64, 65, 255, 256, 257, 777, 1000, 1024, 1025, 2048, 3000, 4096):
+        for thr in (0.3, 0.7):
+            d = _rand_dets(g, n)
+            want = oracle.nms(d, thr)
+            got = maskrcnn.nms(d.to(dev), thr).cpu()
+            assert torch.equal(got, want), (n, thr)
+    with pytest.raises(RuntimeError):
+        maskrcnn.nms(_rand_dets(g, 5000).to(dev), 0.5)  # beyond the on-chip path: loud, not wrong
+
+
+def test_nms_ties_and_specials(dev, oracle):
+    import maskrcnn
+    g = torch.Generator().manual_seed(8)
+    d = _rand_dets(g, 300)
+    d[:, 4] = torch.randint(0, 5, (300,), generator=g).float() / 4  # heavy ties → index order
+    d[7, 4] = float("nan")
+    d[9, 4] = float("inf")
+    d[11, 4] = -0.0
+    d[12, 4] = 0.0
+    d[20, :4] = torch.tensor([5., 5., 3., 3.])  # degenerate
+    d[21, 0] = float("nan")
+    assert torch.equal(maskrcnn.nms(d.to(dev), 0.5).cpu(), oracle.nms(d, 0.5))
+
+
+def test_nms_batched_class_aware(dev, oracle):
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(9)
+    S, N = 8, 1000
+    dets = torch.stack([_rand_dets(g, N) for _ in range(S)])
+    counts = torch.tensor([1000, 999, 512, 1, 0, 64, 65, 300], dtype=torch.int32)
+    cls = torch.randint(1, 9, (S, N), generator=g, dtype=torch.int32)
+    keep, cnt = ops.nms_batched(dets.to(dev), 0.3, counts.to(dev), cls.to(dev))
+    keep, cnt = keep.cpu(), cnt.cpu()
+    for s in range(S):
+        n = int(counts[s])
+        want = oracle.nms(dets[s, :n], 0.3, class_ids=cls[s, :n]) if n else torch.empty(0, dtype=torch.int64)
+        assert int(cnt[s]) == want.numel(), s
+        assert torch.equal(keep[s, :want.numel()], want), s
+        assert bool((keep[s, want.numel():] == -1).all())
+
+
+def test_nms_properties_full_size(dev):
+    """BASELINE size (1000 proposals x 8 images): size-independent properties."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(10)
+    S, N = 8, 1000
+    dets = torch.stack([_rand_dets(g, N, extent=1024.0) for _ in range(S)]).to(dev)
+    keep, cnt = ops.nms_batched(dets, 0.7)
+    for s in range(S):
+        k = keep[s, :int(cnt[s])]
+        assert bool((k[1:] > k[:-1]).all())  # ascending input indices
+        kept = dets[s, k]
+        keep2, cnt2 = ops.nms_batched(kept.unsqueeze(0).contiguous(), 0.7)
+        assert int(cnt2[0]) == k.numel()  # idempotence: survivors do not suppress each other
+        # the top-scoring box always survives
+        assert int(dets[s, :, 4].argmax()) in set(k.tolist())
+
+
+# --------------------------------------------------------------------------------------------- crop
+def test_crop_forward_golden(dev):
+    import maskrcnn
+    z = load_golden("crop_forward")
+    for i, tag in _cases(z):
+        extrap, ch, cw = z[f"c{i}_args"]
+        img = torch.from_numpy(z[f"c{i}_image"]).to(dev)
+        boxes = torch.from_numpy(z[f"c{i}_boxes"]).to(dev)
+        ind = torch.from_numpy(z[f"c{i}_ind"]).to(dev)
+        got = maskrcnn.CropFunction(int(ch), int(cw), float(extrap))(img, boxes, ind)
+        assert np.array_equal(got.cpu().numpy(), z[f"c{i}_crops"]), tag
+        # out-param form of crop.h:14-22: any float tensor, resized by the callee
+        crops = torch.zeros_like(img)
+        maskrcnn._C.crop_forward(img, boxes, ind, float(extrap), int(ch), int(cw), crops)
+        assert np.array_equal(crops.cpu().numpy(), z[f"c{i}_crops"]), tag
+
+
+def _rand_boxes(g, n, lo, hi, spill=False):
+    c = torch.rand(n, 2, generator=g)
+    hw = torch.exp(torch.rand(n, 2, generator=g) * (np.log(hi) - np.log(lo)) + np.log(lo))
+    b = torch.cat([c - hw / 2, c + hw / 2], 1)
+    return b if spill else b.clamp(0, 1)
+
+
+def test_crop_forward_random_vs_oracle(dev, oracle):
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for (b, c, h, w, n, ch, cw) in [(1, 256, 64, 64, 50, 7, 7), (2, 33, 37, 19, 40, 14, 14),
+                                    (3, 8, 128, 96, 64, 28, 28), (1, 4, 9, 9, 30, 1, 1),
+                                    (1, 300, 16, 16, 10, 3, 5), (2, 16, 32, 32, 33, 64, 2)]:
+        img = torch.randn(b, c, h, w, generator=g)
+        boxes = _rand_boxes(g, n, 0.02, 0.9, spill=True)
+        ind = torch.randint(0, b, (n,), generator=g, dtype=torch.int32)
+        want = oracle.crop_forward(img, boxes, ind, 0.25, ch, cw)
+        got = ops.crop(img.to(dev), boxes.to(dev), ind.to(dev), 0.25, ch, cw)
+        assert torch.equal(got.cpu(), want), (b, c, h, w, n, ch, cw)
+
+
+def test_crop_config2_microbench_shape(dev, oracle):
+    """BASELINE config 2: 256 RoIs x 256 ch x 14x14 on P2 (256x256 map), SURVEY §8d inputs."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(1234)
+    fm = torch.randn(1, 256, 256, 256, generator=g)
+    c = torch.rand(256, 2, generator=g)
+    hw = torch.rand(256, 2, generator=g) * 0.10 + 0.02
+    boxes = torch.cat([c - hw / 2, c + hw / 2], 1).clamp(0, 1)
+    ind = torch.zeros(256, dtype=torch.int32)
+    want = oracle.crop_forward(fm, boxes, ind, 0.0, 14, 14)
+    got = ops.crop(fm.to(dev), boxes.to(dev), ind.to(dev), 0.0, 14, 14)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_crop_bad_index_and_dtypes(dev):
+    from maskrcnn_amd import ops
+    img = torch.arange(32, dtype=torch.float32, device=dev).view(1, 2, 4, 4)
+    boxes = torch.tensor([[0., 0., 1., 1.]], device=dev)
+    out = ops.crop(img, boxes, torch.tensor([3], dtype=torch.int32, device=dev), -7.0, 2, 2)
+    assert bool((out == -7.0).all())  # documented GPU behaviour: extrapolation value, no exit()
+    with pytest.raises(RuntimeError):
+        ops.crop(img, boxes, torch.tensor([0], dtype=torch.int64, device=dev), 0.0, 2, 2)
+    with pytest.raises(RuntimeError):
+        ops.crop(img.half(), boxes, torch.tensor([0], dtype=torch.int32, device=dev), 0.0, 2, 2)
+    with pytest.raises(RuntimeError):
+        ops.crop(img.cpu(), boxes.cpu(), torch.tensor([0], dtype=torch.int32), 0.0, 2, 2)
+
+
+def test_crop_backward_vs_oracle(dev, oracle):
+    import maskrcnn
+    z = load_golden("crop_backward")
+    grads, boxes, ind = (torch.from_numpy(z[k]) for k in ("grads", "boxes", "ind"))
+    gi = torch.full(z["grads_image"].shape, 3.0, device=dev)  # must be zeroed by the callee
+    maskrcnn._C.crop_backward(grads.to(dev), boxes.to(dev), ind.to(dev), gi)
+    np.testing.assert_allclose(gi.cpu().numpy(), z["grads_image"], rtol=0, atol=1e-5)
+    # autograd through CropFunction == crop_backward
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(2, 6, 10, 12, generator=g).to(dev).requires_grad_(True)
+    bx = _rand_boxes(g, 9, 0.1, 0.8, spill=True)
+    ix = torch.randint(0, 2, (9,), generator=g, dtype=torch.int32)
+    out = maskrcnn.CropFunction(7, 7, 0)(img, bx.to(dev), ix.to(dev))
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go.to(dev))
+    want = oracle.crop_backward(go, bx, ix, img.shape)
+    np.testing.assert_allclose(img.grad.cpu().numpy(), want.numpy(), rtol=0, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------- pyramid RoIAlign
+def test_roi_align_pyramid_golden(dev):
+    from maskrcnn_amd import ops
+    z = load_golden("roi_align")
+    fms = [torch.from_numpy(z[f"fm{i}"]).to(dev).permute(0, 2, 3, 1).contiguous() for i in range(4)]
+    boxes = torch.from_numpy(z["boxes"]).to(dev)
+    area = float(z["image_shape"][0] * z["image_shape"][1])
+    for pool in (7, 14):
+        got = ops.roi_align_pyramid(fms, boxes, pool, area, rois_per_image=boxes.size(0))
+        assert np.array_equal(got.permute(0, 3, 1, 2).cpu().numpy(), z[f"pooled{pool}"])
+
+
+def test_roi_align_pyramid_batched_vs_oracle(dev, oracle):
+    """1000 proposals/img x 2 images x 256 ch on a 512x512 pyramid vs per-image oracle roi_align."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(77)
+    B, R, C = 2, 1000, 256
+    shape = (512, 512, 3)
+    fms = [torch.randn(B, C, 512 // s, 512 // s, generator=g) for s in (4, 8, 16, 32)]
+    rois = _rand_boxes(g, B * R, 0.02, 0.6)
+    rois[:4] = torch.tensor([[0.1, 0.1, 0.1, 0.5], [0.5, 0.5, 0.4, 0.4], [0., 0., 1., 1.],
+                             [0.2, 0.2, 0.2, 0.2]])  # zero / negative area, whole image
+    nhwc = [f.to(dev).permute(0, 2, 3, 1).contiguous() for f in fms]
+    got, levels = ops.roi_align_pyramid(nhwc, rois.to(dev), 7, float(shape[0] * shape[1]),
+                                        rois_per_image=R, return_levels=True)
+    got = got.permute(0, 3, 1, 2).cpu()
+    for b in range(B):
+        r = rois[b * R:(b + 1) * R]
+        ok = (r[:, 2] > r[:, 0]) & (r[:, 3] > r[:, 1])  # reference level is UB for area <= 0
+        want_lv = oracle.roi_levels(r, shape)
+        assert torch.equal(levels[b * R:(b + 1) * R].cpu()[ok], want_lv[ok])
+        want = oracle.roi_align(r[ok], [f[b:b + 1] for f in fms], 7, shape)
+        assert torch.equal(got[b * R:(b + 1) * R][ok], want)

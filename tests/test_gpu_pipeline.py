@@ -1,0 +1,160 @@
+"""GPU parity tests (-m gpu) of the whole inference step against the CPU oracle (oracle.predict and its
+stages), on a reduced configuration the oracle finishes in seconds (256x256 images, ResNet-50-FPN,
+synthetic weights). Stage by stage, each stage fed with the HIP path's own upstream output so that a
+1-ulp exp() difference upstream cannot flip a downstream discrete decision:
+  trunk activations  : <= 1e-4 * max(1, max|activation|)  (fp32 MFMA vs CPU summation order, ~60 layers)
+  NMS keep sets      : bit-exact on the dets actually handed to NMS
+  detections         : identical class ids / boxes / scores (scores 1e-6)
+  masks              : <= 1e-4 abs
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    assert torch.cuda.is_available()
+    from maskrcnn_amd import modules
+    from maskrcnn_amd.config import InferenceConfig
+    from maskrcnn_amd.pipeline import MaskRCNNInference
+    dev = torch.device("cuda:0")
+    cfg = InferenceConfig(image_height=256, image_width=256, backbone="resnet50", pre_nms_limit=300,
+                          proposal_count=200, detection_max_instances=20)
+    sd = modules.synthetic_state_dict("resnet50", seed=0, bn_seed=1)
+    # give the heads some spread so that several classes / detections appear with random weights
+    g = torch.Generator().manual_seed(5)
+    sd["classifier.linear_class.weight"] = torch.randn(81, 1024, generator=g) * 0.05
+    sd["classifier.linear_class.bias"] = torch.randn(81, generator=g) * 0.5
+    sd["classifier.linear_bbox.weight"] = torch.randn(324, 1024, generator=g) * 0.02
+    sd["rpn.conv_bbox.bias"] = torch.randn(12, generator=g) * 0.3
+    b = 2
+    images = torch.randint(0, 256, (b, 256, 256, 3), generator=g).float() - torch.tensor(cfg.mean_pixel)
+    images = images.permute(0, 3, 1, 2).contiguous()
+    windows = torch.tensor([[0., 0., 256., 256.], [32., 0., 224., 256.]])
+    # Random weights saturate the softmaxes (all scores == 1.0 → order undefined) and blow the box deltas
+    # up. Calibrate the four head layers so scores are distinct and boxes sane; this only rescales the
+    # synthetic weights, both paths then see the same state_dict.
+    for _ in range(8):
+        net = MaskRCNNInference(sd, cfg, dev)
+        det, mid = net.predict(images.to(dev), windows.to(dev), with_masks=True, return_intermediates=True)
+        sc = mid["rpn_scores"].double().clamp(1e-7, 1 - 1e-7)
+        sat = torch.log(sc / (1 - sc)).std().item()  # std of the fg-bg logit difference
+        dstd, lstd, bstd = mid["rpn_deltas"].std().item(), mid["logits"].std().item(), mid["bbox"].std().item()
+        done = True
+        if sat > 2.0:
+            sd["rpn.conv_class.weight"] = sd["rpn.conv_class.weight"] * (1.0 / sat)
+            done = False
+        if dstd > 1.0:
+            sd["rpn.conv_bbox.weight"] = sd["rpn.conv_bbox.weight"] * (0.5 / dstd)
+            done = False
+        if lstd > 3.0:
+            sd["classifier.linear_class.weight"] = sd["classifier.linear_class.weight"] * (2.0 / lstd)
+            done = False
+        if bstd > 1.0:
+            sd["classifier.linear_bbox.weight"] = sd["classifier.linear_bbox.weight"] * (0.5 / bstd)
+            done = False
+        if done:
+            break
+    torch.cuda.synchronize()
+    return dict(cfg=cfg, sd=sd, net=net, images=images, windows=windows, det=det, mid=mid, b=b)
+
+
+def _ocfg(oracle, cfg):
+    return oracle.Cfg(cfg.image_height, cfg.image_width, PRE_NMS_LIMIT=cfg.pre_nms_limit,
+                      RPN_NMS_MAX_ROIS_NUM=cfg.proposal_count,
+                      DETECTION_MAX_INSTANCES=cfg.detection_max_instances)
+
+
+def test_trunk_and_rpn_activations(setup, oracle):
+    s = setup
+    for b in range(s["b"]):
+        fms = oracle.fpn_forward(s["images"][b:b + 1], s["sd"], "resnet50")
+        for lvl, (want, got) in enumerate(zip(fms, s["mid"]["feature_maps"])):
+            got = got[b].permute(2, 0, 1).cpu()
+            tol = 1e-4 * max(1.0, want.abs().max().item())
+            err = (got - want[0]).abs().max().item()
+            assert err <= tol, f"P{lvl + 2}: err {err:.3e} > {tol:.3e}"
+        _, rpn_class, rpn_bbox = oracle.rpn_detect(fms, s["sd"])
+        assert rpn_class.shape[1] == s["mid"]["rpn_scores"].shape[1]
+        assert (s["mid"]["rpn_scores"][b].cpu() - rpn_class[0, :, 1]).abs().max().item() <= 1e-4
+        tol = 1e-4 * max(1.0, rpn_bbox.abs().max().item())
+        assert (s["mid"]["rpn_deltas"][b].cpu() - rpn_bbox[0]).abs().max().item() <= tol
+
+
+def test_proposals_stage(setup, oracle):
+    s = setup
+    ocfg = _ocfg(oracle, s["cfg"])
+    anchors = oracle.anchors_for(ocfg)
+    assert torch.equal(anchors, s["net"].anchors.cpu())
+    for b in range(s["b"]):
+        scores = s["mid"]["rpn_scores"][b].cpu()
+        rpn_class = torch.stack([1 - scores, scores], 1).unsqueeze(0)
+        rois, dets = oracle.rpn_refine(rpn_class, s["mid"]["rpn_deltas"][b].cpu().unsqueeze(0), anchors,
+                                       ocfg, return_dets=True)
+        got_dets = s["mid"]["rpn_dets"][b].cpu()
+        assert torch.allclose(got_dets, dets, rtol=0, atol=1e-3)  # exp() ulp differences only
+        # bit-exact NMS on the dets the HIP path actually used
+        keep = oracle.nms(got_dets, ocfg.RPN_NMS_THRESHOLD)[:ocfg.RPN_NMS_MAX_ROIS_NUM]
+        n = int(s["mid"]["roi_counts"][b])
+        assert n == keep.numel()
+        want = got_dets[keep, :4] / torch.tensor([256., 256., 256., 256.])
+        assert torch.equal(s["mid"]["rois"][b, :n].cpu(), want)
+        assert bool((s["mid"]["rois"][b, n:] == 0).all())
+
+
+def test_classifier_and_detections_stage(setup, oracle):
+    s = setup
+    ocfg = _ocfg(oracle, s["cfg"])
+    p = s["mid"]["rois"].size(1)
+    total = 0
+    for b in range(s["b"]):
+        n = int(s["mid"]["roi_counts"][b])
+        rois = s["mid"]["rois"][b, :n].cpu()
+        fms = [f[b:b + 1].permute(0, 3, 1, 2).cpu().contiguous() for f in s["mid"]["feature_maps"][:4]]
+        logits, probs, bbox = oracle.classifier_forward(fms, rois, s["sd"], ocfg)
+        got_logits = s["mid"]["logits"][b * p:b * p + n].cpu()
+        got_bbox = s["mid"]["bbox"][b * p:b * p + n].cpu()
+        assert (got_logits - logits).abs().max().item() <= 1e-4 * max(1.0, logits.abs().max().item())
+        assert (got_bbox - bbox).abs().max().item() <= 1e-4 * max(1.0, bbox.abs().max().item())
+        # detections from the HIP path's own head outputs
+        gp = torch.softmax(got_logits, dim=1)
+        cls, sc, bx = oracle.mrn_refine(rois, gp, got_bbox, tuple(s["windows"][b].tolist()), ocfg)
+        k = int(s["det"].counts[b])
+        if cls is None:
+            assert k == 0
+            continue
+        assert k == cls.size(1)
+        total += k
+        assert torch.equal(s["det"].class_ids[b, :k].cpu(), cls[0])
+        assert torch.equal(s["det"].boxes[b, :k].cpu(), bx[0])
+        assert torch.allclose(s["det"].scores[b, :k].cpu(), sc[0], rtol=0, atol=1e-6)
+        assert bool((s["det"].class_ids[b, k:] == 0).all())
+    assert total > 0, "test configuration produced no detections"
+
+
+def test_mask_stage(setup, oracle):
+    s = setup
+    ocfg = _ocfg(oracle, s["cfg"])
+    for b in range(s["b"]):
+        k = int(s["det"].counts[b])
+        if k == 0:
+            continue
+        fms = [f[b:b + 1].permute(0, 3, 1, 2).cpu().contiguous() for f in s["mid"]["feature_maps"][:4]]
+        boxes = s["det"].boxes[b, :k].cpu()
+        want = oracle.mask_forward(fms, boxes / 256.0, s["sd"], ocfg)        # [k,81,28,28]
+        got = s["det"].masks[b, :k].permute(0, 3, 1, 2).cpu()
+        assert (got - want).abs().max().item() <= 1e-4
+
+
+def test_batch_independence_and_determinism(setup):
+    """Images are independent (frozen BN): running image 1 alone reproduces its slice of the batch."""
+    s = setup
+    dev = s["net"].device
+    det = s["net"].predict(s["images"][1:2].to(dev), s["windows"][1:2].to(dev))
+    k = int(det.counts[0])
+    assert k == int(s["det"].counts[1])
+    assert torch.equal(det.class_ids[0], s["det"].class_ids[1])
+    assert torch.equal(det.boxes[0], s["det"].boxes[1])
+    assert torch.equal(det.scores[0], s["det"].scores[1])
