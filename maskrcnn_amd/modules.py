@@ -154,11 +154,12 @@ class FusedConv:
         self.w = pack_weight(sd[conv + ".weight"], device, cin_pad)
         self.scale, self.shift = fold_bn(sd, conv, bn, device)
         self.stride, self.relu, self.same_k, self.pad = stride, relu, same_pad_kernel, pad
+        self.algo_cin = sd[conv + ".weight"].size(1)  # un-padded Cin for FLOP accounting
 
     def __call__(self, x, residual=None, res_div=1, out=None):
         pad = ops.same_pad(x.size(1), x.size(2), self.same_k, 1) if self.same_k else self.pad
         return ops.conv_bn_act(x, self.w, self.scale, self.shift, self.stride, pad, self.relu, residual,
-                               res_div, out)
+                               res_div, out, self.algo_cin)
 
 
 class FusedBottleneck:

@@ -185,10 +185,15 @@ __all__ = ["nms_batched", "crop", "roi_align_pyramid", "MaskrcnnHipError"]
 # --------------------------------------------------------------------------------------------------
 # conv + BN + ReLU (+ residual), channels-last
 # --------------------------------------------------------------------------------------------------
+# When set to a list, every conv launch appends (start_event, end_event, algorithmic_flops, (M, N, K)) —
+# HIP events recorded on the launch stream; used by bench.py's roofline pass, never in the timed region.
+CONV_PROFILE: list | None = None
+
+
 def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
                 shift: torch.Tensor | None, stride: int = 1, pad=(0, 0, 0, 0), relu: bool = False,
                 residual: torch.Tensor | None = None, res_div: int = 1,
-                out: torch.Tensor | None = None) -> torch.Tensor:
+                out: torch.Tensor | None = None, algo_cin: int | None = None) -> torch.Tensor:
     """y = act(scale * conv(x, w) + shift + residual).
 
     x [B,H,W,Cin] NHWC fp32 contiguous; w [Cout,KH,KW,Cin] (OHWI) contiguous; scale/shift [Cout] or
@@ -214,10 +219,18 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
         assert residual.is_contiguous() and residual.dtype == torch.float32
         assert tuple(residual.shape) == (b, oh // res_div, ow // res_div, cout), \
             f"residual {tuple(residual.shape)} vs output {(b, oh, ow, cout)} / {res_div}"
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.mrcnn_conv_bn_act_nhwc_f32(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout, kh, kw,
                                          int(stride), pt, pl, pb, pr, _ptr(scale), _ptr(shift),
                                          _ptr(residual), int(res_div), int(bool(relu)),
                                          out.data_ptr(), _stream()))
+    if prof is not None:
+        e1.record()
+        m, k = b * oh * ow, kh * kw * (algo_cin or cin)  # algorithmic: 2*MACs of the un-padded conv
+        prof.append((e0, e1, 2.0 * m * k * cout, (m, cout, k)))
     return out
 
 
