@@ -10,7 +10,8 @@ Sources of truth used here (nothing of theirs is copied into the repo — only i
     c++ext/maskrcnn/__init__.py:21-45 does (that file's legacy autograd.Function cannot run on
     torch >= 1.5).
 
-Usage:  python tests/golden/make_golden.py      (rewrites every fixture; deterministic)
+Usage:  python tests/golden/make_golden.py [nms crop roi_align anchors graph refine schema]
+        (no argument: rewrite every fixture; deterministic)
 """
 import contextlib
 import ctypes
@@ -386,14 +387,43 @@ def gen_refine(rconfig, rmodel):
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+def gen_schema(rconfig, rmodel):
+    """state_dict layout of the reference MaskRCNN (R101, hard-coded at model.py:985) and of a
+    ResNet('resnet50') trunk: key names + shapes only (no weights)."""
+
+    class Cfg0(rconfig.CocoInferenceConfig):
+        GPU_COUNT = 0
+
+    tmp = tempfile.mkdtemp(prefix="golden_logs_")
+    net = rmodel.MaskRCNN(config=Cfg0(), model_dir=tmp)
+    sd = net.state_dict()
+    keys = list(sd.keys())
+    shapes = [list(sd[k].shape) + [-1] * (4 - sd[k].dim()) for k in keys]
+    r50 = rmodel.ResNet("resnet50", stage5=True).state_dict()
+    save("schema", keys=np.array(keys), shapes=np.array(shapes, dtype=np.int64),
+         r50_trunk_keys=np.array(list(r50.keys())))
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
+    only = set(sys.argv[1:])
+    want = lambda n: not only or n in only
     refc, rconfig, rutils, rdata, rmodel = load_reference()
-    gen_nms(refc)
-    gen_crop(refc)
-    gen_roi_align(rmodel)
-    gen_anchors_boxes(rconfig, rutils, rdata)
-    gen_graph(rmodel)
-    gen_refine(rconfig, rmodel)
+    if want("nms"):
+        gen_nms(refc)
+    if want("crop"):
+        gen_crop(refc)
+    if want("roi_align"):
+        gen_roi_align(rmodel)
+    if want("anchors"):
+        gen_anchors_boxes(rconfig, rutils, rdata)
+    if want("graph"):
+        gen_graph(rmodel)
+    if want("refine"):
+        gen_refine(rconfig, rmodel)
+    if want("schema"):
+        gen_schema(rconfig, rmodel)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,138 @@
+"""CPU tests of the host logic: state-dict schema vs the reference's (golden), anchors, BN folding, SAME
+padding, the sharding helper and the world_size-2 gloo all-gather of detections."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_state_dict_schema_matches_reference():
+    """A reference checkpoint (mask_rcnn_coco.pth layout) must load into our parameter tree unchanged."""
+    from maskrcnn_amd import modules
+    z = load_golden("schema")
+    keys = [str(k) for k in z["keys"]]
+    assert len(keys) == 800  # 800 keys for R101
+    sd = modules.reference_schema("resnet101").state_dict()
+    assert list(sd.keys()) == keys
+    for k, shp in zip(keys, z["shapes"]):
+        assert list(sd[k].shape) == [int(v) for v in shp if v >= 0], k
+    r50 = modules.reference_schema("resnet50").state_dict()
+    trunk = [k[len("fpn."):] for k in r50 if k.startswith("fpn.C")]
+    assert trunk == [str(k) for k in z["r50_trunk_keys"]]
+
+
+def test_synthetic_state_dict_is_deterministic():
+    from maskrcnn_amd import modules
+    a = modules.synthetic_state_dict("resnet50", 0, 1)
+    b = modules.synthetic_state_dict("resnet50", 0, 1)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert float(a["fpn.C2.0.bn1.running_var"].min()) >= 0.5
+
+
+def test_anchors_match_oracle_and_known_answers(oracle):
+    from maskrcnn_amd.anchors import pyramid_anchors
+    from maskrcnn_amd.config import InferenceConfig
+    a = pyramid_anchors(InferenceConfig())
+    assert tuple(a.shape) == (261888, 4)  # model.py:1019
+    assert torch.equal(a, oracle.anchors_for(oracle.Cfg()))
+    small = pyramid_anchors(InferenceConfig(image_height=256, image_width=384))
+    assert torch.equal(small, oracle.anchors_for(oracle.Cfg(256, 384)))
+    with pytest.raises(ValueError):
+        InferenceConfig(image_height=1000, image_width=1024)  # model.py:978-983
+
+
+def test_fold_bn_equals_batchnorm_eval():
+    from maskrcnn_amd import modules
+    g = torch.Generator().manual_seed(0)
+    c = 16
+    sd = {"c.weight": torch.randn(c, 8, 1, 1, generator=g), "c.bias": torch.randn(c, generator=g),
+          "b.weight": torch.rand(c, generator=g) + 0.5, "b.bias": torch.randn(c, generator=g),
+          "b.running_mean": torch.randn(c, generator=g), "b.running_var": torch.rand(c, generator=g) + 0.5}
+    s, t = modules.fold_bn(sd, "c", "b", "cpu")
+    x = torch.randn(2, 8, 5, 5, generator=g)
+    want = F.batch_norm(F.conv2d(x, sd["c.weight"], sd["c.bias"]), sd["b.running_mean"], sd["b.running_var"],
+                        sd["b.weight"], sd["b.bias"], False, 0.0, 1e-3)
+    got = F.conv2d(x, sd["c.weight"]) * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)
+    assert (got - want).abs().max().item() < 1e-5
+    s2, t2 = modules.fold_bn(sd, "c", None, "cpu")
+    assert s2 is None and torch.equal(t2, sd["c.bias"])
+    w = modules.pack_weight(torch.arange(2 * 3 * 2 * 2.).view(2, 3, 2, 2), "cpu", cin_pad=4)
+    assert tuple(w.shape) == (2, 2, 2, 4) and bool((w[..., 3] == 0).all())
+    assert float(w[1, 0, 1, 2]) == float(torch.arange(24.).view(2, 3, 2, 2)[1, 2, 0, 1])
+
+
+def test_same_pad_matches_golden():
+    from maskrcnn_amd import ops
+    z = load_golden("graph_small")
+    for k, s, h, w, top, bottom, left, right in z["same_pad"]:
+        assert ops.same_pad(int(h), int(w), int(k), int(s)) == (top, left, bottom, right)
+
+
+def test_shard_range_partitions_the_batch():
+    from maskrcnn_amd.dist import shard_range
+    for gb, world in ((64, 8), (8, 1), (10, 4), (3, 8)):
+        spans = [shard_range(gb, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == gb
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mdist", os.path.join(ROOT, "maskrcnn_amd", "dist.py"))
+    mdist = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mdist)
+    r, _, w = mdist.init_from_env(backend="gloo")
+    b_local, d = 4, 50
+    lo, hi = mdist.shard_range(world * b_local, r, w)
+    # detections whose content encodes the global image index
+    packed = torch.zeros(b_local, d, 6)
+    counts = torch.zeros(b_local, dtype=torch.int32)
+    for i, gi in enumerate(range(lo, hi)):
+        packed[i, :, 0] = gi
+        packed[i, :, 1] = torch.arange(d) / d
+        counts[i] = gi + 1
+    gp, gc = mdist.all_gather_detections(packed, counts)
+    mdist.barrier()
+    t = mdist.max_over_ranks(float(r + 1), "cpu")
+    q.put((r, gp[:, 0, 0].tolist(), gc.tolist(), t))
+    torch.distributed.destroy_process_group()
+
+
+def test_all_gather_detections_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, ids, counts, t in res:
+        assert ids == [float(i) for i in range(8)]      # rank-major == global image order
+        assert counts == [i + 1 for i in range(8)]
+        assert t == 2.0                                   # max over ranks
