@@ -24,6 +24,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvParams {
     const float* x;
@@ -36,6 +37,7 @@ struct ConvParams {
     int M, K;  // GEMM sizes
     int res_div, relu;
     int tiles_m, tiles_n;
+    unsigned x_bytes, w_bytes, y_bytes, r_bytes;  // buffer-descriptor ranges (< 4 GiB each)
 };
 
 constexpr int BK = 32;
@@ -47,7 +49,7 @@ constexpr size_t conv_lds_bytes() {
 }
 
 // GENERIC: Cin % 32 != 0 (stem, Cin = 4): a k tile may straddle taps, each 16-byte slot decodes its own tap.
-template <int BM, int BN, int WM, int WN, bool GENERIC>
+template <int BM, int BN, int WM, int WN, bool GENERIC, int RES>
 __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
@@ -98,23 +100,40 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     }
 
     float4 ra[PA], rb[PB];
+    // Predication without branches: loads go through raw buffer descriptors (hardware range check); an
+    // out-of-image tap / out-of-range row gets a byte offset beyond num_records and returns zeros. The
+    // compiler therefore issues every load of a tile back to back and nothing waits on them until
+    // store_tile, after the MFMAs of the current tile.
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    auto bload = [](const __amdgpu_buffer_rsrc_t& r, unsigned byte_off) -> float4 {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(byte_off), 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                           __uint_as_float(v.w));
+    };
+    int t_c0 = 0, t_ky = 0, t_kx = 0;  // (tap, channel) of the NEXT tile to load — wave-uniform, incremental
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
         if constexpr (!GENERIC) {
-            const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;  // wave-uniform
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
-            const int tap_off = (ky * p.W + kx) * p.Cin + c0 + kq * 4;
+            const int ky = t_ky, kx = t_kx;
+            const int tap_off = (ky * p.W + kx) * p.Cin + t_c0 + kq * 4;
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
                 const bool ok = static_cast<unsigned>(a_iy[i] + ky) < static_cast<unsigned>(p.H) &&
                                 static_cast<unsigned>(a_ix[i] + kx) < static_cast<unsigned>(p.W);
-                ra[i] = ok ? *reinterpret_cast<const float4*>(p.x + a_off[i] + tap_off)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[i] = bload(x_rsrc, ok ? static_cast<unsigned>(a_off[i] + tap_off) * 4u : OOB);
             }
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(p.w + b_off[i] + k0)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[i] = bload(w_rsrc, b_ok[i] ? static_cast<unsigned>(b_off[i] + k0) * 4u : OOB);
+            t_c0 += BK;
+            if (t_c0 >= p.Cin) {
+                t_c0 = 0;
+                if (++t_kx == p.KW) { t_kx = 0; ++t_ky; }
+            }
         } else {
             const int kk = k0 + kq * 4;
             const bool kin = kk < p.K;
@@ -126,13 +145,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
                 const bool ok = kin &&
                                 static_cast<unsigned>(a_iy[i] + ky) < static_cast<unsigned>(p.H) &&
                                 static_cast<unsigned>(a_ix[i] + kx) < static_cast<unsigned>(p.W);
-                ra[i] = ok ? *reinterpret_cast<const float4*>(p.x + a_off[i] + tap_off)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                ra[i] = bload(x_rsrc, ok ? static_cast<unsigned>(a_off[i] + tap_off) * 4u : OOB);
             }
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                rb[i] = (b_ok[i] && kin) ? *reinterpret_cast<const float4*>(p.w + b_off[i] + k0)
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[i] = bload(w_rsrc, (b_ok[i] && kin) ? static_cast<unsigned>(b_off[i] + k0) * 4u : OOB);
         }
     };
     auto store_tile = [&](int buf) {
@@ -190,36 +207,61 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     }
 
     // ---- epilogue: affine + residual + ReLU, 128-byte channel runs per half-wave ------------------------
+    // Branch-free: stores and residual loads go through buffer descriptors, out-of-tile rows/channels get
+    // an out-of-range offset (loads return 0, stores are dropped). Per 32x32 accumulator tile the 16
+    // residual loads are issued together, then the 16 stores. RES: 0 none, 1 same size, 2 half size (FPN).
     const int ln = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual), 0, p.r_bytes, 0x00020000);
+    float sc[TN], sh[TN];
+    unsigned ncol[TN];  // byte offset of the lane's channel, or OOB
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
         const int n = n0 + wn * WTN + jn * 32 + ln;
         const bool n_ok = n < p.Cout;
-        const float sc = (n_ok && p.scale) ? p.scale[n] : 1.0f;
-        const float sh = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+        sc[jn] = (n_ok && p.scale) ? p.scale[n] : 1.0f;
+        sh[jn] = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+        ncol[jn] = n_ok ? static_cast<unsigned>(n) * 4u : OOB;
+    }
+    const int rh = p.OH >> 1, rw = p.OW >> 1;
+    const unsigned row_bytes = static_cast<unsigned>(p.Cout) * 4u;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * WTM + i * 32 + 4 * lh;  // rows mb + (r&3) + 8*(r>>2)
+        unsigned yrow[16], rrow[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            const bool ok = m < p.M;
+            yrow[r] = ok ? static_cast<unsigned>(m) * row_bytes : OOB;
+            if constexpr (RES == 1) {
+                rrow[r] = yrow[r];
+            } else if constexpr (RES == 2) {
+                const int mm = ok ? m : 0;
+                const int b = mm / ohw, rem = mm - b * ohw;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                rrow[r] = ok ? static_cast<unsigned>((b * rh + (oy >> 1)) * rw + (ox >> 1)) * row_bytes : OOB;
+            }
+        }
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            float rv[16];
+            if constexpr (RES != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // OOB in either term must stay OOB: saturating add via max
+                    const unsigned off = (rrow[r] | ncol[jn]) >= OOB ? OOB : rrow[r] + ncol[jn];
+                    rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, static_cast<int>(off), 0, 0));
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (n_ok && m < p.M) {
-                    float v = acc[i][jn][r] * sc + sh;
-                    if (p.residual) {
-                        int64_t ri;
-                        if (p.res_div == 1) {
-                            ri = static_cast<int64_t>(m) * p.Cout + n;
-                        } else {
-                            const int b = m / ohw, rem = m - b * ohw;
-                            const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                            const int rh = p.OH / p.res_div, rw = p.OW / p.res_div;
-                            ri = (static_cast<int64_t>(b * rh + oy / p.res_div) * rw + ox / p.res_div) *
-                                     p.Cout + n;
-                        }
-                        v += p.residual[ri];
-                    }
-                    if (p.relu) v = v > 0.f ? v : 0.f;
-                    p.y[static_cast<int64_t>(m) * p.Cout + n] = v;
-                }
+                float v = acc[i][jn][r] * sc[jn] + sh[jn];
+                if constexpr (RES != 0) v += rv[r];
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                const unsigned off = (yrow[r] | ncol[jn]) >= OOB ? OOB : yrow[r] + ncol[jn];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(off), 0, 0);
             }
         }
     }
@@ -241,15 +283,22 @@ int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
             return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
         return MRCNN_OK;
     };
-    if (generic) {
-        auto k = conv_igemm_f32<BM, BN, WM, WN, true>;
-        if (int rc = set_attr(reinterpret_cast<const void*>(k))) return rc;
-        hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
-    } else {
-        auto k = conv_igemm_f32<BM, BN, WM, WN, false>;
-        if (int rc = set_attr(reinterpret_cast<const void*>(k))) return rc;
-        hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
-    }
+    const int res = p.residual ? p.res_div : 0;
+    auto go = [&](auto kern) -> int {
+        if (int rc = set_attr(reinterpret_cast<const void*>(kern))) return rc;
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
+        return MRCNN_OK;
+    };
+    int rc;
+    if (generic)
+        rc = res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, true, 0>)
+           : res == 1 ? go(conv_igemm_f32<BM, BN, WM, WN, true, 1>)
+                      : go(conv_igemm_f32<BM, BN, WM, WN, true, 2>);
+    else
+        rc = res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, false, 0>)
+           : res == 1 ? go(conv_igemm_f32<BM, BN, WM, WN, false, 1>)
+                      : go(conv_igemm_f32<BM, BN, WM, WN, false, 2>);
+    if (rc) return rc;
     return mrcnn::check_launch("conv_igemm_f32");
 }
 
@@ -279,12 +328,16 @@ extern "C" int mrcnn_conv_bn_act_nhwc_f32(const float* x, int32_t batch, int32_t
                   "conv: res_div=2 needs even output size");
     const long long M = 1LL * batch * p.OH * p.OW;
     const long long K = 1LL * kh * kw * cin;
-    MRCNN_REQUIRE(1LL * batch * height * width * cin < (1LL << 31) && M * cout < (1LL << 31) &&
-                      K * cout < (1LL << 31) && M < (1LL << 31),
-                  "conv: tensor exceeds 2^31 elements (32-bit offsets)");
+    MRCNN_REQUIRE(1LL * batch * height * width * cin < (1LL << 30) && M * cout < (1LL << 30) &&
+                      K * cout < (1LL << 30) && M < (1LL << 31),
+                  "conv: tensor too large (each tensor < 2^30 elements: 32-bit buffer byte offsets)");
     p.M = static_cast<int>(M);
     p.K = static_cast<int>(K);
     p.res_div = residual ? res_div : 1;
+    p.x_bytes = static_cast<unsigned>(4LL * batch * height * width * cin);
+    p.w_bytes = static_cast<unsigned>(4LL * K * cout);
+    p.y_bytes = static_cast<unsigned>(4LL * M * cout);
+    p.r_bytes = residual ? static_cast<unsigned>(4LL * M * cout / (p.res_div * p.res_div)) : 0u;
     p.relu = relu;
     const bool generic = (cin % BK) != 0;
     hipStream_t s = mrcnn::as_stream(stream);
