@@ -21,6 +21,8 @@
 //               (FPN nearest-neighbour upsample + add, model.py:150-152).
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -40,21 +42,21 @@ struct ConvParams {
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;  // buffer-descriptor ranges (< 4 GiB each)
 };
 
-constexpr int BK = 32;
-constexpr int LDS_STRIDE = BK + 4;  // floats
-
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 constexpr size_t conv_lds_bytes() {
-    return sizeof(float) * 2 * (BM + BN) * LDS_STRIDE;
+    return sizeof(float) * 2 * (BM + BN) * (BK + 4);
 }
 
 // GENERIC: Cin % 32 != 0 (stem, Cin = 4): a k tile may straddle taps, each 16-byte slot decodes its own tap.
-template <int BM, int BN, int WM, int WN, bool GENERIC, int RES>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
+template <int BM, int BN, int WM, int WN, int BK, bool GENERIC, int RES>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
+    constexpr int LDS_STRIDE = BK + 4;           // floats; keeps ds_read_b128 conflict-free (BK = 16 or 32)
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
-    constexpr int PA = BM / 32, PB = BN / 32;    // 16-byte slots per thread per k tile
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
+    constexpr int TPR = BK / 4;                  // threads (16-byte slots) per tile row
+    constexpr int RPP = 256 / TPR;               // tile rows covered per pass of the 256 threads
+    constexpr int PA = BM / RPP, PB = BN / RPP;  // 16-byte slots per thread per k tile
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1, "4 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * BM * LDS_STRIDE;
@@ -70,14 +72,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int kq = tid & 7, r0 = tid >> 3;
+    const int kq = tid % TPR, r0 = tid / TPR;
 
     // ---- per-thread row bookkeeping for the im2col gather ---------------------------------------------
     int a_off[PA], a_iy[PA], a_ix[PA];
     const int ohw = p.OH * p.OW;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int m = m0 + r0 + 32 * i;
+        const int m = m0 + r0 + RPP * i;
         if (m < p.M) {
             const int b = m / ohw, rem = m - b * ohw;
             const int oy = rem / p.OW, ox = rem - oy * p.OW;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     bool b_ok[PB];
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-        const int n = n0 + r0 + 32 * i;
+        const int n = n0 + r0 + RPP * i;
         b_ok[i] = n < p.Cout;
         b_off[i] = (b_ok[i] ? n : 0) * p.K + kq * 4;
     }
@@ -156,9 +158,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
         float* a = As + buf * BM * LDS_STRIDE + r0 * LDS_STRIDE + kq * 4;
         float* b = Bs + buf * BN * LDS_STRIDE + r0 * LDS_STRIDE + kq * 4;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) *reinterpret_cast<float4*>(a + 32 * i * LDS_STRIDE) = ra[i];
+        for (int i = 0; i < PA; ++i) *reinterpret_cast<float4*>(a + RPP * i * LDS_STRIDE) = ra[i];
 #pragma unroll
-        for (int i = 0; i < PB; ++i) *reinterpret_cast<float4*>(b + 32 * i * LDS_STRIDE) = rb[i];
+        for (int i = 0; i < PB; ++i) *reinterpret_cast<float4*>(b + RPP * i * LDS_STRIDE) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -169,41 +171,65 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- main loop: software-pipelined over 8-deep k chunks, ONE barrier per k tile ------------------
+    // The barrier for tile t+1 sits BEFORE the last chunk of tile t: by then the fragments of that last
+    // chunk are already in registers, so its 4*TM*TN MFMAs cover the barrier skew and the LDS latency of the
+    // first fragments of tile t+1 (issued right after the barrier). Global loads for tile t+2 are issued
+    // at the same point and land in LDS one full tile later.
     const int nk = (p.K + BK - 1) / BK;
+    constexpr int NCH = BK / 8;
     load_tile(0);
     store_tile(0);
     __syncthreads();
+    if (nk > 1) load_tile(1);
 
     const int frag = (lane & 31) * LDS_STRIDE + (lane >> 5) * 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const float* Ab = As + buf * BM * LDS_STRIDE + wm * WTM * LDS_STRIDE + frag;
-        const float* Bb = Bs + buf * BN * LDS_STRIDE + wn * WTN * LDS_STRIDE + frag;
+    const float* Aw = As + wm * WTM * LDS_STRIDE + frag;
+    const float* Bw = Bs + wn * WTN * LDS_STRIDE + frag;
+    float4 fa[2][TM], fb[2][TN];
+    auto read_frags = [&](int slot, int buf, int j) {
 #pragma unroll
-        for (int j = 0; j < BK / 8; ++j) {
-            float4 a[TM], b[TN];
+        for (int i = 0; i < TM; ++i)
+            fa[slot][i] = *reinterpret_cast<const float4*>(Aw + buf * BM * LDS_STRIDE + i * 32 * LDS_STRIDE + j * 8);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_STRIDE + j * 8);
+        for (int i = 0; i < TN; ++i)
+            fb[slot][i] = *reinterpret_cast<const float4*>(Bw + buf * BN * LDS_STRIDE + i * 32 * LDS_STRIDE + j * 8);
+    };
+    auto mfma_chunk = [&](int slot) {
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
-                b[i] = *reinterpret_cast<const float4*>(Bb + i * 32 * LDS_STRIDE + j * 8);
+        for (int s = 0; s < 4; ++s) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int i = 0; i < TM; ++i) {
+                const float4 a = fa[slot][i];
+                const float av = s == 0 ? a.x : s == 1 ? a.y : s == 2 ? a.z : a.w;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float av = s == 0 ? a[i].x : s == 1 ? a[i].y : s == 2 ? a[i].z : a[i].w;
-#pragma unroll
-                    for (int jn = 0; jn < TN; ++jn) {
-                        const float bv = s == 0 ? b[jn].x : s == 1 ? b[jn].y : s == 2 ? b[jn].z : b[jn].w;
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jn], 0, 0, 0);
-                    }
+                for (int jn = 0; jn < TN; ++jn) {
+                    const float4 b = fb[slot][jn];
+                    const float bv = s == 0 ? b.x : s == 1 ? b.y : s == 2 ? b.z : b.w;
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jn], 0, 0, 0);
                 }
             }
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
+    };
+    read_frags(0, 0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int cur = j & 1;
+            if (j + 1 < NCH) {
+                read_frags(cur ^ 1, buf, j + 1);
+            } else {
+                if (kt + 1 < nk) store_tile(buf ^ 1);   // registers hold tile kt+1 (loaded one tile ago)
+                __syncthreads();
+                if (kt + 1 < nk) {
+                    if (kt + 2 < nk) load_tile(kt + 2);
+                    read_frags(cur ^ 1, buf ^ 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the last chunk's MFMAs AFTER the barrier
+            }
+            mfma_chunk(cur);
+        }
     }
 
     // ---- epilogue: affine + residual + ReLU, 128-byte channel runs per half-wave ------------------------
@@ -267,14 +293,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK>
 int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const int per_xcd = (p.tiles_m + 7) / 8;
     const long long grid = 8LL * per_xcd * p.tiles_n;
     if (grid > 0x7fffffffLL) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: grid too large");
-    constexpr size_t lds = conv_lds_bytes<BM, BN>();
+    constexpr size_t lds = conv_lds_bytes<BM, BN, BK>();
     auto set_attr = [&](const void* f) -> int {
         if (lds <= 64 * 1024) return MRCNN_OK;
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -291,13 +317,13 @@ int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
     };
     int rc;
     if (generic)
-        rc = res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, true, 0>)
-           : res == 1 ? go(conv_igemm_f32<BM, BN, WM, WN, true, 1>)
-                      : go(conv_igemm_f32<BM, BN, WM, WN, true, 2>);
+        rc = res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 0>)
+           : res == 1 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 1>)
+                      : go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 2>);
     else
-        rc = res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, false, 0>)
-           : res == 1 ? go(conv_igemm_f32<BM, BN, WM, WN, false, 1>)
-                      : go(conv_igemm_f32<BM, BN, WM, WN, false, 2>);
+        rc = res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 0>)
+           : res == 1 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 1>)
+                      : go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 2>);
     if (rc) return rc;
     return mrcnn::check_launch("conv_igemm_f32");
 }
@@ -339,9 +365,16 @@ extern "C" int mrcnn_conv_bn_act_nhwc_f32(const float* x, int32_t batch, int32_t
     p.y_bytes = static_cast<unsigned>(4LL * M * cout);
     p.r_bytes = residual ? static_cast<unsigned>(4LL * M * cout / (p.res_div * p.res_div)) : 0u;
     p.relu = relu;
-    const bool generic = (cin % BK) != 0;
+    const bool generic = (cin % 32) != 0;
     hipStream_t s = mrcnn::as_stream(stream);
-    if (cout <= 32) return launch_conv<128, 32, 4, 1>(p, generic, s);
-    if (cout <= 64) return launch_conv<256, 64, 4, 1>(p, generic, s);
-    return launch_conv<128, 128, 2, 2>(p, generic, s);
+    static const int force = getenv("MRCNN_CONV_TILE") ? atoi(getenv("MRCNN_CONV_TILE")) : 0;  // tuning aid
+    if (cout <= 32) return launch_conv<128, 32, 4, 1, 32>(p, generic, s);
+    if (cout <= 64) return launch_conv<256, 64, 4, 1, 32>(p, generic, s);
+    // big tile (256x128, BK 16: 25% fewer LDS/global bytes per MFMA) once there is enough work to fill the chip
+    const long long big_tiles = ((M + 255) / 256) * ((cout + 127) / 128);
+    // measured on MI355X (round 1): no gain over 128x128 even on the largest layers (133.5 vs 133.2 TFLOP/s),
+    // a loss on mid-size ones; kept selectable for tuning only.
+    const bool use_big = force == 2 && big_tiles >= 1 && !generic;
+    if (use_big) return launch_conv<256, 128, 2, 2, 16>(p, generic, s);
+    return launch_conv<128, 128, 2, 2, 32>(p, generic, s);
 }
