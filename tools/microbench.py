@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Microbenchmarks of the two non-conv hot ops, HIP-event timed on the launch stream.
+
+  * RoIAlign (BASELINE config 2): 256 RoIs x 256 ch x 14x14 on one FPN level, NCHW drop-in entry point and
+    the NHWC pyramid kernel; roofline = compulsory bytes (output + touched map once + boxes) / time vs 8 TB/s.
+  * NMS: µs per call at N = 500 / 1000 / 2000 (threshold 0.7) and the batched 8 x 1000 form; latency-bound.
+Prints one JSON object per line."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from maskrcnn_amd import ops  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+
+
+def timeit(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # µs
+
+
+def main():
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1234)
+    for hl in (256, 128, 64, 32):
+        fm = torch.randn(1, 256, hl, hl, generator=g).to(dev)
+        c = torch.rand(256, 2, generator=g)
+        hw = torch.rand(256, 2, generator=g) * 0.10 + 0.02
+        boxes = torch.cat([c - hw / 2, c + hw / 2], 1).clamp(0, 1).to(dev)
+        ind = torch.zeros(256, dtype=torch.int32, device=dev)
+        out_bytes = 256 * 256 * 14 * 14 * 4
+        algo = out_bytes + fm.numel() * 4 + 256 * 20
+        us = timeit(lambda: ops.crop(fm, boxes, ind, 0.0, 14, 14))
+        print(json.dumps({"op": "crop_forward_nchw", "level_hw": hl, "rois": 256, "us": round(us, 2),
+                          "algorithmic_MB": round(algo / 1e6, 2), "GBps": round(algo / us / 1e3, 1),
+                          "frac_of_8TBps": round(algo / us / 1e3 / HBM_PEAK_GBS, 4)}), flush=True)
+    # NHWC pyramid kernel, 8 images x 1000 rois x 7x7 (the classifier-head call of the pipeline)
+    fms = [torch.randn(8, 1024 // s, 1024 // s, 256, generator=g).to(dev) for s in (4, 8, 16, 32)]
+    c = torch.rand(8000, 2, generator=g)
+    hw = torch.exp(torch.rand(8000, 2, generator=g) * 3.4 - 3.9)
+    rois = torch.cat([c - hw / 2, c + hw / 2], 1).clamp(0, 1).to(dev)
+    for pool in (7, 14):
+        n = 8000 if pool == 7 else 400
+        us = timeit(lambda: ops.roi_align_pyramid(fms, rois[:n], pool, 1024.0 * 1024.0, rois_per_image=n // 8))
+        out_bytes = n * pool * pool * 256 * 4
+        print(json.dumps({"op": "roi_align_pyramid_nhwc", "pool": pool, "rois": n, "us": round(us, 2),
+                          "output_MB": round(out_bytes / 1e6, 1),
+                          "GBps_out_plus_4taps": round(out_bytes * 5 / us / 1e3, 1)}), flush=True)
+    for n in (500, 1000, 2000, 4096):
+        k = max(1, n // 10)
+        centres = torch.rand(k, 2, generator=g) * 1024
+        cc = centres[torch.randint(0, k, (n,), generator=g)] + torch.randn(n, 2, generator=g) * 12
+        wh = torch.exp(torch.rand(n, 2, generator=g) * 2.5 + 2.0)
+        d = torch.cat([cc - wh / 2, cc + wh / 2, torch.rand(n, 1, generator=g)], 1).to(dev).unsqueeze(0)
+        us = timeit(lambda: ops.nms_batched(d, 0.7), iters=30)
+        keep, cnt = ops.nms_batched(d, 0.7)
+        print(json.dumps({"op": "nms", "segments": 1, "n": n, "threshold": 0.7, "kept": int(cnt[0]),
+                          "us": round(us, 1)}), flush=True)
+    d8 = torch.stack([torch.cat([torch.rand(1000, 2, generator=g) * 900,
+                                 torch.rand(1000, 2, generator=g) * 900, torch.rand(1000, 1, generator=g)], 1)
+                      for _ in range(8)])
+    d8[..., 2:4] = d8[..., :2] + torch.exp(torch.rand(8, 1000, 2, generator=g) * 2.5 + 2.0)
+    d8 = d8.to(dev)
+    us = timeit(lambda: ops.nms_batched(d8, 0.7), iters=30)
+    _, cnt = ops.nms_batched(d8, 0.7)
+    print(json.dumps({"op": "nms", "segments": 8, "n": 1000, "threshold": 0.7,
+                      "kept_mean": float(cnt.float().mean()), "us": round(us, 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
