@@ -136,6 +136,22 @@ int mrcnn_conv_bn_act_nhwc_f32(const float* x, int32_t batch, int32_t height, in
                                const float* residual, int32_t res_div, int32_t relu, float* y,
                                mrcnn_stream_t stream);
 
+/* Same contract as mrcnn_conv_bn_act_nhwc_f32, but the contraction runs on fp16-operand MFMA
+ * (v_mfma_f32_32x32x16_f16, fp32 accumulate). x, residual and y stay fp32 in HBM; x is converted while it is
+ * staged to LDS. The caller prepares the weights once as fp16 planes [cout][kh][kw][cin]:
+ *     w_hi = fp16(w),   w_lo = fp16(w - fp32(w_hi))
+ *   products = 1   plain fp16 operands, x_hi*w_hi (BASELINE config 5's "fp16 MFMA path"); w_lo may be NULL.
+ *                  Error ~2^-11 relative per term: does NOT meet the 1e-4 bar of the fp32 path.
+ *   products = 3   error-compensated split x_hi*w_hi + x_hi*w_lo + x_lo*w_hi: every product exact in fp32,
+ *                  fp32 accumulation, ~2^-21 relative per term (fp32-grade) for |x|, |w| < 65504.
+ * cin % 8 == 0 (the stem pads 3 -> 8 channels). */
+int mrcnn_conv_bn_act_nhwc_f16mfma(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                   const void* w_hi, const void* w_lo, int32_t cout, int32_t kh, int32_t kw,
+                                   int32_t stride, int32_t pad_top, int32_t pad_left, int32_t pad_bottom,
+                                   int32_t pad_right, const float* scale, const float* shift,
+                                   const float* residual, int32_t res_div, int32_t relu, int32_t products,
+                                   float* y, mrcnn_stream_t stream);
+
 /* Zero-padded max-pool, NHWC fp32: [batch][H][W][C] -> [batch][OH][OW][C], OH = (H+pad_top+pad_bottom-k)/s+1.
  * Covers the stem's SamePad2d(3,2) + MaxPool2d(3,2) (model.py:227-228; pads (0,1,0,1) on even sizes — the
  * caller computes the pads with the reference's formula, model.py:75-87) and P6 = MaxPool2d(1,2)

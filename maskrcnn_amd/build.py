@@ -26,6 +26,7 @@ SOURCES = {
     "nms.hip": ["-ffp-contract=off"],
     "crop.hip": ["-ffp-contract=off"],
     "conv.hip": [],
+    "conv_f16.hip": [],
     "misc.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-fno-fast-math",

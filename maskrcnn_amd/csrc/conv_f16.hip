@@ -1,0 +1,391 @@
+// Fused convolution + affine + residual + ReLU on fp16-operand MFMA (v_mfma_f32_32x32x16_f16, fp32
+// accumulate) for gfx950, channels-last. Same GEMM view, tile order, im2col predication and epilogue as
+// conv.hip (the exact-fp32 kernel); what changes is the contraction:
+//
+//   PRODUCTS = 1   plain fp16 operands (BASELINE config 5's "fp16 MFMA path"): x_hi * w_hi.
+//   PRODUCTS = 3   error-compensated split, fp32-grade accuracy at the fp16 MFMA rate / 3:
+//                      x = x_hi + x_lo,  w = w_hi + w_lo   (hi = fp16(v), lo = fp16(v - hi): 22 mantissa bits)
+//                      x*w ~= x_hi*w_hi + x_hi*w_lo + x_lo*w_hi        (dropped x_lo*w_lo <= 2^-22 |x*w|)
+//                  every fp16 x fp16 product is exact in fp32 and the sum accumulates in fp32, so the result
+//                  differs from an fp32 fmaf chain by ~2^-21 relative per term (valid for |x|,|w| < 65504).
+//
+// Activations stay fp32 in HBM (so RoIAlign / residuals / the boundary see the same tensors as the fp32
+// path); they are split into hi/lo fp16 planes while being staged to LDS. Weights are split once by the caller.
+//   LDS       per plane [rows][32 halves] = 64-byte rows, 16-byte chunks XOR-swizzled by (row>>2)&3 so that the
+//             ds_read_b128 fragment reads (16 rows x one chunk per lane group) hit 16 distinct slots — no padding,
+//             64 KiB per workgroup (PRODUCTS = 3, 128x128 tile) → two workgroups per CU.
+//   MFMA      lane l holds A[row = l&31][k = 8*(l>>5) .. +7] (8 halves = one ds_read_b128) and the same for B;
+//             a k tile of 32 is two 16-deep steps; per step and 32x32 tile: PRODUCTS MFMAs of 32 cycles.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+struct ConvParamsH {
+    const float* x;
+    const _Float16* w_hi;
+    const _Float16* w_lo;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    float* y;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
+    int M, K;
+    int res_div, relu;
+    int tiles_m, tiles_n;
+    unsigned x_bytes, w_bytes, y_bytes, r_bytes;
+};
+
+constexpr int BK = 32;          // k elements per tile
+constexpr int ROW_BYTES = 64;   // 32 halves
+
+template <int BM, int BN, int PRODUCTS>
+constexpr size_t lds_bytes() {
+    return static_cast<size_t>(2) * (BM + BN) * ROW_BYTES * (PRODUCTS == 3 ? 2 : 1);
+}
+
+__device__ __forceinline__ unsigned pack2(_Float16 a, _Float16 b) {
+    f16x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <int BM, int BN, int WM, int WN, int PRODUCTS, bool GENERIC, int RES>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParamsH p) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int PA = BM / 32;           // fp32 float4 slots per thread per k tile (8 threads per row)
+    constexpr int PB = BN / 64;           // fp16 16-byte chunks per thread per plane per k tile (4 threads per row)
+    constexpr int NPL = PRODUCTS == 3 ? 2 : 1;  // planes per operand (hi [, lo])
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [buf][plane][rows][64 B]
+    constexpr int A_PLANE = BM * ROW_BYTES, B_PLANE = BN * ROW_BYTES;
+    constexpr int A_BUF = A_PLANE * NPL, B_BUF = B_PLANE * NPL;
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + 2 * A_BUF;
+
+    const int t = blockIdx.x;
+    const int xcd = t & 7, seq = t >> 3;
+    const int mt_lo = (xcd * p.tiles_m) >> 3, mt_hi = ((xcd + 1) * p.tiles_m) >> 3;
+    const int mt = mt_lo + seq / p.tiles_n;
+    const int nt = seq % p.tiles_n;
+    if (mt >= mt_hi) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ln = lane & 31, lh = lane >> 5;
+    const int ohw = p.OH * p.OW;
+
+    // ---- A (activations, fp32 in HBM): 8 threads per row, 4 consecutive k each --------------------------
+    const int kq = tid & 7, ar0 = tid >> 3;
+    int a_off[PA], a_iy[PA], a_ix[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + ar0 + 32 * i;
+        if (m < p.M) {
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            a_iy[i] = oy * p.stride - p.pad_t;
+            a_ix[i] = ox * p.stride - p.pad_l;
+            a_off[i] = ((b * p.H + a_iy[i]) * p.W + a_ix[i]) * p.Cin;
+        } else {
+            a_iy[i] = -(1 << 24);
+            a_ix[i] = 0;
+            a_off[i] = 0;
+        }
+    }
+    // ---- B (weights, fp16 planes): 4 threads per row, 8 consecutive k (16 B) each ----------------------
+    const int bc = tid & 3, br0 = tid >> 2;
+    int b_off[PB];
+    bool b_ok[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int n = n0 + br0 + 64 * i;
+        b_ok[i] = n < p.Cout;
+        b_off[i] = (b_ok[i] ? n : 0) * p.K + bc * 8;  // halves
+    }
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wh_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(p.w_hi), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wl_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16*>(PRODUCTS == 3 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
+
+    u32x4 ra[PA];        // 4 fp32 activations per slot (raw bits)
+    u32x4 rb[NPL][PB];   // 8 fp16 weights per slot per plane
+    int t_c0 = 0, t_ky = 0, t_kx = 0;
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        if constexpr (!GENERIC) {
+            const int ky = t_ky, kx = t_kx;
+            const int tap_off = (ky * p.W + kx) * p.Cin + t_c0 + kq * 4;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const bool ok = static_cast<unsigned>(a_iy[i] + ky) < static_cast<unsigned>(p.H) &&
+                                static_cast<unsigned>(a_ix[i] + kx) < static_cast<unsigned>(p.W);
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(
+                    x_rsrc, static_cast<int>(ok ? static_cast<unsigned>(a_off[i] + tap_off) * 4u : OOB), 0, 0);
+            }
+            t_c0 += BK;
+            if (t_c0 >= p.Cin) {
+                t_c0 = 0;
+                if (++t_kx == p.KW) { t_kx = 0; ++t_ky; }
+            }
+        } else {
+            const int kk = k0 + kq * 4;
+            const bool kin = kk < p.K;
+            const int tap = kk / p.Cin, c = kk - tap * p.Cin;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const int tap_off = (ky * p.W + kx) * p.Cin + c;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const bool ok = kin &&
+                                static_cast<unsigned>(a_iy[i] + ky) < static_cast<unsigned>(p.H) &&
+                                static_cast<unsigned>(a_ix[i] + kx) < static_cast<unsigned>(p.W);
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(
+                    x_rsrc, static_cast<int>(ok ? static_cast<unsigned>(a_off[i] + tap_off) * 4u : OOB), 0, 0);
+            }
+        }
+        const bool kin_b = (k0 + bc * 8) < p.K;  // K % 8 == 0
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const unsigned off = (b_ok[i] && kin_b) ? static_cast<unsigned>(b_off[i] + k0) * 2u : OOB;
+            rb[0][i] = __builtin_amdgcn_raw_buffer_load_b128(wh_rsrc, static_cast<int>(off), 0, 0);
+            if constexpr (PRODUCTS == 3)
+                rb[1][i] = __builtin_amdgcn_raw_buffer_load_b128(wl_rsrc, static_cast<int>(off), 0, 0);
+        }
+    };
+    // swizzled byte offset of 16-byte chunk c of row r inside a plane
+    auto chunk_off = [](int r, int c) { return r * ROW_BYTES + ((c ^ ((r >> 2) & 3)) << 4); };
+    auto store_tile = [&](int buf) {
+        unsigned char* a = As + buf * A_BUF;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int r = ar0 + 32 * i;
+            const float v0 = __uint_as_float(ra[i].x), v1 = __uint_as_float(ra[i].y);
+            const float v2 = __uint_as_float(ra[i].z), v3 = __uint_as_float(ra[i].w);
+            const _Float16 h0 = static_cast<_Float16>(v0), h1 = static_cast<_Float16>(v1);
+            const _Float16 h2 = static_cast<_Float16>(v2), h3 = static_cast<_Float16>(v3);
+            const int off = chunk_off(r, kq >> 1) + (kq & 1) * 8;
+            u32x2 hi = {pack2(h0, h1), pack2(h2, h3)};
+            *reinterpret_cast<u32x2*>(a + off) = hi;
+            if constexpr (PRODUCTS == 3) {
+                const _Float16 l0 = static_cast<_Float16>(v0 - static_cast<float>(h0));
+                const _Float16 l1 = static_cast<_Float16>(v1 - static_cast<float>(h1));
+                const _Float16 l2 = static_cast<_Float16>(v2 - static_cast<float>(h2));
+                const _Float16 l3 = static_cast<_Float16>(v3 - static_cast<float>(h3));
+                u32x2 lo = {pack2(l0, l1), pack2(l2, l3)};
+                *reinterpret_cast<u32x2*>(a + A_PLANE + off) = lo;
+            }
+        }
+        unsigned char* b = Bs + buf * B_BUF;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int off = chunk_off(br0 + 64 * i, bc);
+            *reinterpret_cast<u32x4*>(b + off) = rb[0][i];
+            if constexpr (PRODUCTS == 3) *reinterpret_cast<u32x4*>(b + B_PLANE + off) = rb[1][i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addressing: rows are multiples of 32 plus ln, so the swizzle term depends on the lane only
+    const int sw = (ln >> 2) & 3;
+    const unsigned char* Aw = As + (wm * WTM + ln) * ROW_BYTES;
+    const unsigned char* Bw = Bs + (wn * WTN + ln) * ROW_BYTES;
+    f16x8 fa[NPL][TM], fb[NPL][TN];
+    auto read_frags = [&](int buf, int ks) {
+        const int co = ((ks * 2 + lh) ^ sw) << 4;
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[pl][i] = *reinterpret_cast<const f16x8*>(Aw + buf * A_BUF + pl * A_PLANE +
+                                                            i * 32 * ROW_BYTES + co);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                fb[pl][i] = *reinterpret_cast<const f16x8*>(Bw + buf * B_BUF + pl * B_PLANE +
+                                                            i * 32 * ROW_BYTES + co);
+        }
+    };
+    auto mfma_step = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                if constexpr (PRODUCTS == 3) {  // small terms first
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[0][jn], acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[1][jn], acc[i][jn], 0, 0, 0);
+                }
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][jn], acc[i][jn], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        read_frags(buf, 0);
+        mfma_step();
+        read_frags(buf, 1);
+        mfma_step();
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (identical to conv.hip): affine + residual + ReLU through buffer descriptors ----------
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual), 0, p.r_bytes, 0x00020000);
+    float sc[TN], sh[TN];
+    unsigned ncol[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn * WTN + jn * 32 + ln;
+        const bool n_ok = n < p.Cout;
+        sc[jn] = (n_ok && p.scale) ? p.scale[n] : 1.0f;
+        sh[jn] = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+        ncol[jn] = n_ok ? static_cast<unsigned>(n) * 4u : OOB;
+    }
+    const int rh = p.OH >> 1, rw = p.OW >> 1;
+    const unsigned row_bytes = static_cast<unsigned>(p.Cout) * 4u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * WTM + i * 32 + 4 * lh;
+        unsigned yrow[16], rrow[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            const bool ok = m < p.M;
+            yrow[r] = ok ? static_cast<unsigned>(m) * row_bytes : OOB;
+            if constexpr (RES == 1) {
+                rrow[r] = yrow[r];
+            } else if constexpr (RES == 2) {
+                const int mm = ok ? m : 0;
+                const int b = mm / ohw, rem = mm - b * ohw;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                rrow[r] = ok ? static_cast<unsigned>((b * rh + (oy >> 1)) * rw + (ox >> 1)) * row_bytes : OOB;
+            }
+        }
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            float rv[16];
+            if constexpr (RES != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned off = (rrow[r] | ncol[jn]) >= OOB ? OOB : rrow[r] + ncol[jn];
+                    rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, static_cast<int>(off), 0, 0));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][jn][r] * sc[jn] + sh[jn];
+                if constexpr (RES != 0) v += rv[r];
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                const unsigned off = (yrow[r] | ncol[jn]) >= OOB ? OOB : yrow[r] + ncol[jn];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(off), 0, 0);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int PRODUCTS>
+int launch(ConvParamsH p, bool generic, hipStream_t stream) {
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.Cout + BN - 1) / BN;
+    const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
+    if (grid > 0x7fffffffLL) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv_f16: grid too large");
+    constexpr size_t lds = lds_bytes<BM, BN, PRODUCTS>();
+    const int res = p.residual ? p.res_div : 0;
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               static_cast<int>(lds));
+            if (e != hipSuccess)
+                return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv_f16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
+        return MRCNN_OK;
+    };
+    int rc;
+    if (generic)
+        rc = res == 0 ? go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, true, 0>)
+           : res == 1 ? go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, true, 1>)
+                      : go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, true, 2>);
+    else
+        rc = res == 0 ? go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, false, 0>)
+           : res == 1 ? go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, false, 1>)
+                      : go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, false, 2>);
+    if (rc) return rc;
+    return mrcnn::check_launch("conv_igemm_f16");
+}
+
+template <int PRODUCTS>
+int dispatch(const ConvParamsH& p, bool generic, hipStream_t s) {
+    if (p.Cout <= 64) return launch<256, 64, 4, 1, PRODUCTS>(p, generic, s);
+    return launch<128, 128, 2, 2, PRODUCTS>(p, generic, s);
+}
+
+}  // namespace
+
+extern "C" int mrcnn_conv_bn_act_nhwc_f16mfma(const float* x, int32_t batch, int32_t height, int32_t width,
+                                              int32_t cin, const void* w_hi, const void* w_lo, int32_t cout,
+                                              int32_t kh, int32_t kw, int32_t stride, int32_t pad_top,
+                                              int32_t pad_left, int32_t pad_bottom, int32_t pad_right,
+                                              const float* scale, const float* shift, const float* residual,
+                                              int32_t res_div, int32_t relu, int32_t products, float* y,
+                                              mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x && w_hi && y, "conv_f16: null pointer");
+    MRCNN_REQUIRE(products == 1 || (products == 3 && w_lo), "conv_f16: products must be 1, or 3 with w_lo");
+    MRCNN_REQUIRE(batch >= 1 && height >= 1 && width >= 1 && cin >= 8 && cin % 8 == 0 && cout >= 1,
+                  "conv_f16: bad shape B=%d H=%d W=%d Cin=%d (Cin %% 8 == 0 required) Cout=%d", batch, height,
+                  width, cin, cout);
+    MRCNN_REQUIRE(kh >= 1 && kw >= 1 && stride >= 1 && pad_top >= 0 && pad_left >= 0 && pad_bottom >= 0 &&
+                      pad_right >= 0, "conv_f16: bad kernel/stride/pad");
+    MRCNN_REQUIRE(residual == nullptr || res_div == 1 || res_div == 2, "conv_f16: res_div must be 1 or 2");
+    ConvParamsH p;
+    p.x = x; p.w_hi = static_cast<const _Float16*>(w_hi); p.w_lo = static_cast<const _Float16*>(w_lo);
+    p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw;
+    p.stride = stride; p.pad_t = pad_top; p.pad_l = pad_left;
+    p.OH = (height + pad_top + pad_bottom - kh) / stride + 1;
+    p.OW = (width + pad_left + pad_right - kw) / stride + 1;
+    MRCNN_REQUIRE(p.OH >= 1 && p.OW >= 1, "conv_f16: empty output");
+    MRCNN_REQUIRE(residual == nullptr || res_div == 1 || (p.OH % 2 == 0 && p.OW % 2 == 0),
+                  "conv_f16: res_div=2 needs even output size");
+    const long long M = 1LL * batch * p.OH * p.OW;
+    const long long K = 1LL * kh * kw * cin;
+    MRCNN_REQUIRE(1LL * batch * height * width * cin < (1LL << 30) && M * cout < (1LL << 30) &&
+                      K * cout < (1LL << 30) && M < (1LL << 31),
+                  "conv_f16: tensor too large (each tensor < 2^30 elements: 32-bit buffer byte offsets)");
+    p.M = static_cast<int>(M);
+    p.K = static_cast<int>(K);
+    p.res_div = residual ? res_div : 1;
+    p.relu = relu;
+    p.x_bytes = static_cast<unsigned>(4LL * batch * height * width * cin);
+    p.w_bytes = static_cast<unsigned>(2LL * K * cout);
+    p.y_bytes = static_cast<unsigned>(4LL * M * cout);
+    p.r_bytes = residual ? static_cast<unsigned>(4LL * M * cout / (p.res_div * p.res_div)) : 0u;
+    const bool generic = (cin % BK) != 0;
+    hipStream_t s = mrcnn::as_stream(stream);
+    return products == 3 ? dispatch<3>(p, generic, s) : dispatch<1>(p, generic, s);
+}

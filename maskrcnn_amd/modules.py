@@ -146,31 +146,76 @@ def pack_weight(w_oihw: torch.Tensor, device, cin_pad: int | None = None) -> tor
     return w.contiguous().to(device)
 
 
+PRECISIONS = ("f32", "f16x3", "f16")
+
+
+class ConvWeight:
+    """A packed conv/GEMM weight [Cout,KH,KW,Cin] (OHWI) for one of the contraction modes:
+       f32    exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)                      — the default, parity mode
+       f16x3  fp16-operand MFMA, error-compensated 3-product split          — fp32-grade accuracy (~2^-21)
+       f16    fp16-operand MFMA, plain (BASELINE config 5's fp16 MFMA path) — ~2^-11 per term"""
+
+    def __init__(self, w_ohwi: torch.Tensor, precision: str = "f32"):
+        assert precision in PRECISIONS, precision
+        self.precision = precision
+        self.shape = tuple(w_ohwi.shape)
+        if precision == "f32":
+            self.w = w_ohwi.contiguous()
+        else:
+            cin = w_ohwi.size(3)
+            if cin % 8:  # fp16 kernel loads 8 halves at a time
+                w_ohwi = torch.cat([w_ohwi, w_ohwi.new_zeros(*w_ohwi.shape[:3], 8 - cin % 8)], dim=3)
+            self.w_hi, self.w_lo = ops.split_f16(w_ohwi.contiguous())
+            if precision == "f16":
+                self.w_lo = None
+        self.cin = (self.w if precision == "f32" else self.w_hi).size(3)
+
+    def conv(self, x, scale, shift, stride=1, pad=(0, 0, 0, 0), relu=False, residual=None, res_div=1,
+             algo_cin=None):
+        if self.precision == "f32":
+            return ops.conv_bn_act(x, self.w, scale, shift, stride, pad, relu, residual, res_div, None,
+                                   algo_cin)
+        return ops.conv_bn_act_f16mfma(x, self.w_hi, self.w_lo, scale, shift, stride, pad, relu, residual,
+                                       res_div, 3 if self.precision == "f16x3" else 1, algo_cin)
+
+
 class FusedConv:
     """conv (+BN) (+ReLU) with SAME-style explicit padding, NHWC."""
 
     def __init__(self, sd, conv, bn, device, stride=1, relu=False, same_pad_kernel: int | None = None,
-                 pad=(0, 0, 0, 0), cin_pad=None):
-        self.w = pack_weight(sd[conv + ".weight"], device, cin_pad)
+                 pad=(0, 0, 0, 0), cin_pad=None, precision="f32"):
+        self.w = ConvWeight(pack_weight(sd[conv + ".weight"], device, cin_pad), precision)
         self.scale, self.shift = fold_bn(sd, conv, bn, device)
         self.stride, self.relu, self.same_k, self.pad = stride, relu, same_pad_kernel, pad
         self.algo_cin = sd[conv + ".weight"].size(1)  # un-padded Cin for FLOP accounting
 
-    def __call__(self, x, residual=None, res_div=1, out=None):
+    def __call__(self, x, residual=None, res_div=1):
         pad = ops.same_pad(x.size(1), x.size(2), self.same_k, 1) if self.same_k else self.pad
-        return ops.conv_bn_act(x, self.w, self.scale, self.shift, self.stride, pad, self.relu, residual,
-                               res_div, out, self.algo_cin)
+        return self.w.conv(x, self.scale, self.shift, self.stride, pad, self.relu, residual, res_div,
+                           self.algo_cin)
 
 
 class FusedBottleneck:
-    """Bottleneck.forward (model.py:190-211) via torch.ops.maskrcnn.bottleneck_forward."""
+    """Bottleneck.forward (model.py:190-211): conv1 1x1 (stride) + BN + ReLU → SamePad(3,1) + conv2 3x3 + BN +
+    ReLU → conv3 1x1 + BN, + residual (identity or 1x1-stride downsample + BN), ReLU. In f32 mode this is
+    torch.ops.maskrcnn.bottleneck_forward; the fp16-MFMA modes run the same four fused conv launches."""
 
-    def __init__(self, p):
-        self.p = p
+    def __init__(self, p, precision="f32", convs=None):
+        self.p, self.precision, self.convs = p, precision, convs
 
     @classmethod
-    def from_state_dict(cls, sd, prefix, stride, device):
+    def from_state_dict(cls, sd, prefix, stride, device, precision="f32"):
         pre = (prefix + ".") if prefix and not prefix.endswith(".") else prefix
+        if precision != "f32":
+            c1 = FusedConv(sd, pre + "conv1", pre + "bn1", device, stride=stride, relu=True, precision=precision)
+            c2 = FusedConv(sd, pre + "conv2", pre + "bn2", device, relu=True, same_pad_kernel=3,
+                           precision=precision)
+            c3 = FusedConv(sd, pre + "conv3", pre + "bn3", device, relu=True, precision=precision)
+            cd = None
+            if (pre + "downsample.0.weight") in sd:
+                cd = FusedConv(sd, pre + "downsample.0", pre + "downsample.1", device, stride=stride,
+                               precision=precision)
+            return cls(None, precision, (c1, c2, c3, cd))
         w1 = pack_weight(sd[pre + "conv1.weight"], device)
         s1, t1 = fold_bn(sd, pre + "conv1", pre + "bn1", device)
         w2 = pack_weight(sd[pre + "conv2.weight"], device)
@@ -184,28 +229,34 @@ class FusedBottleneck:
         return cls((w1, s1, t1, w2, s2, t2, w3, s3, t3, wd, sdn, tdn, int(stride)))
 
     def __call__(self, x):
-        return torch.ops.maskrcnn.bottleneck_forward(x, *self.p)
+        if self.precision == "f32":
+            return torch.ops.maskrcnn.bottleneck_forward(x, *self.p)
+        c1, c2, c3, cd = self.convs
+        res = x if cd is None else cd(x)
+        return c3(c2(c1(x)), residual=res)
 
 
 class FusedBackbone:
     """ResNet-FPN trunk (model.py:133-168, 223-270): NCHW molded image → [P2..P6] NHWC."""
 
-    def __init__(self, sd, arch, device, prefix="fpn."):
+    def __init__(self, sd, arch, device, prefix="fpn.", precision="f32"):
         l = LAYERS[arch]
         self.device = device
+        self.cin_pad = 4 if precision == "f32" else 8   # 16-byte pixels (fp32 path) / 8-half chunks (fp16 path)
         self.stem = FusedConv(sd, prefix + "C1.0", prefix + "C1.1", device, stride=2, relu=True,
-                              pad=(3, 3, 3, 3), cin_pad=4)
+                              pad=(3, 3, 3, 3), cin_pad=self.cin_pad, precision=precision)
         self.stages = []
         for name, n, stride in (("C2", l[0], 1), ("C3", l[1], 2), ("C4", l[2], 2), ("C5", l[3], 2)):
             self.stages.append([FusedBottleneck.from_state_dict(sd, f"{prefix}{name}.{i}",
-                                                                stride if i == 0 else 1, device)
+                                                                stride if i == 0 else 1, device, precision)
                                 for i in range(n)])
-        self.lateral = {k: FusedConv(sd, f"{prefix}P{k}_conv1", None, device) for k in (5, 4, 3, 2)}
-        self.smooth = {k: FusedConv(sd, f"{prefix}P{k}_conv2.1", None, device, same_pad_kernel=3)
-                       for k in (5, 4, 3, 2)}
+        self.lateral = {k: FusedConv(sd, f"{prefix}P{k}_conv1", None, device, precision=precision)
+                        for k in (5, 4, 3, 2)}
+        self.smooth = {k: FusedConv(sd, f"{prefix}P{k}_conv2.1", None, device, same_pad_kernel=3,
+                                    precision=precision) for k in (5, 4, 3, 2)}
 
     def __call__(self, image_nchw):
-        x = ops.nchw_to_nhwc(image_nchw.contiguous(), 4)       # 3 → 4 channels (zero), 16-byte pixels
+        x = ops.nchw_to_nhwc(image_nchw.contiguous(), self.cin_pad)   # 3 → 4 (8) channels, zero-padded
         x = self.stem(x)                                        # conv7x7 s2 p3 + BN + ReLU
         x = ops.maxpool(x, 3, 2, ops.same_pad(x.size(1), x.size(2), 3, 2))
         cs = []
@@ -227,38 +278,39 @@ class FusedRPN:
     """RPN.forward (model.py:609-649) per level; class (6) and bbox (12) 1x1 heads fused into one
     18-channel GEMM. Returns NHWC [B,H,W,18]: channels 0-5 = (bg,fg) logits x 3 anchors, 6-17 = deltas."""
 
-    def __init__(self, sd, device, prefix="rpn."):
-        self.shared = FusedConv(sd, prefix + "conv_shared", None, device, relu=True, same_pad_kernel=3)
+    def __init__(self, sd, device, prefix="rpn.", precision="f32"):
+        self.shared = FusedConv(sd, prefix + "conv_shared", None, device, relu=True, same_pad_kernel=3,
+                                precision=precision)
         w = torch.cat([sd[prefix + "conv_class.weight"], sd[prefix + "conv_bbox.weight"]], 0)
-        self.w_head = pack_weight(w, device)
+        self.w_head = ConvWeight(pack_weight(w, device), precision)
         self.b_head = torch.cat([sd[prefix + "conv_class.bias"], sd[prefix + "conv_bbox.bias"]]).float() \
             .contiguous().to(device)
 
     def __call__(self, p):
-        return ops.conv_bn_act(self.shared(p), self.w_head, None, self.b_head)
+        return self.w_head.conv(self.shared(p), None, self.b_head)
 
 
 class FusedClassifier:
     """Classifier.forward after roi_align (model.py:782-794). Input [R,7,7,256] NHWC; the 7x7 'valid'
     conv is one GEMM with K = 7*7*256 (OHWI weight flattening == NHWC crop flattening)."""
 
-    def __init__(self, sd, device, prefix="classifier."):
+    def __init__(self, sd, device, prefix="classifier.", precision="f32"):
         w1 = pack_weight(sd[prefix + "conv1.weight"], device)  # [1024,7,7,256]
         self.pool = w1.size(1)
-        self.w1 = w1.view(w1.size(0), 1, 1, -1)
+        self.w1 = ConvWeight(w1.view(w1.size(0), 1, 1, -1), precision)
         self.s1, self.t1 = fold_bn(sd, prefix + "conv1", prefix + "bn1", device)
-        self.conv2 = FusedConv(sd, prefix + "conv2", prefix + "bn2", device, relu=True)
+        self.conv2 = FusedConv(sd, prefix + "conv2", prefix + "bn2", device, relu=True, precision=precision)
         wl = torch.cat([sd[prefix + "linear_class.weight"], sd[prefix + "linear_bbox.weight"]], 0)
-        self.w_fc = wl.float().view(wl.size(0), 1, 1, wl.size(1)).contiguous().to(device)
+        self.w_fc = ConvWeight(wl.float().view(wl.size(0), 1, 1, wl.size(1)).contiguous().to(device), precision)
         self.b_fc = torch.cat([sd[prefix + "linear_class.bias"], sd[prefix + "linear_bbox.bias"]]) \
             .float().contiguous().to(device)
         self.num_classes = sd[prefix + "linear_class.weight"].size(0)
 
     def __call__(self, pooled):
         r = pooled.size(0)
-        x = ops.conv_bn_act(pooled.view(r, 1, 1, -1), self.w1, self.s1, self.t1, relu=True)
+        x = self.w1.conv(pooled.view(r, 1, 1, -1), self.s1, self.t1, relu=True)
         x = self.conv2(x)
-        y = ops.conv_bn_act(x, self.w_fc, None, self.b_fc).view(r, -1)
+        y = self.w_fc.conv(x, None, self.b_fc).view(r, -1)
         logits = y[:, :self.num_classes]
         bbox = y[:, self.num_classes:].reshape(r, self.num_classes, 4)
         return logits, bbox
@@ -269,27 +321,29 @@ class FusedMask:
     The 2x2 stride-2 transposed conv is one GEMM to 4*256 channels + a pixel shuffle; its ReLU rides in
     the GEMM epilogue (it commutes with the shuffle)."""
 
-    def __init__(self, sd, device, prefix="mask."):
+    def __init__(self, sd, device, prefix="mask.", precision="f32"):
         self.convs = [FusedConv(sd, f"{prefix}conv{i}", f"{prefix}bn{i}", device, relu=True,
-                                same_pad_kernel=3) for i in (1, 2, 3, 4)]
+                                same_pad_kernel=3, precision=precision) for i in (1, 2, 3, 4)]
         wt = sd[prefix + "deconv.weight"].float()  # [Cin, Cout, 2, 2]
         cin, cout = wt.size(0), wt.size(1)
         # GEMM output channel = (dy*2 + dx)*Cout + co
-        self.w_de = wt.permute(2, 3, 1, 0).reshape(4 * cout, 1, 1, cin).contiguous().to(device)
+        self.w_de = ConvWeight(wt.permute(2, 3, 1, 0).reshape(4 * cout, 1, 1, cin).contiguous().to(device),
+                               precision)
         self.b_de = sd[prefix + "deconv.bias"].float().repeat(4).contiguous().to(device)
         self.cout = cout
-        self.conv5 = FusedConv(sd, prefix + "conv5", None, device)
+        self.conv5 = FusedConv(sd, prefix + "conv5", None, device, precision=precision)
 
     def __call__(self, pooled):
         x = pooled
         for c in self.convs:
             x = c(x)
         r, h, w, _ = x.shape
-        y = ops.conv_bn_act(x, self.w_de, None, self.b_de, relu=True)          # [R,h,w,4*C]
+        y = self.w_de.conv(x, None, self.b_de, relu=True)                      # [R,h,w,4*C]
         y = y.view(r, h, w, 2, 2, self.cout).permute(0, 1, 3, 2, 4, 5).reshape(r, 2 * h, 2 * w, self.cout)
         return torch.sigmoid(self.conv5(y.contiguous()))
 
 
-__all__ = ["reference_schema", "synthetic_state_dict", "fold_bn", "pack_weight", "FusedConv",
+__all__ = ["reference_schema", "synthetic_state_dict", "fold_bn", "pack_weight", "ConvWeight", "PRECISIONS",
+           "FusedConv",
            "FusedBottleneck", "FusedBackbone", "FusedRPN", "FusedClassifier", "FusedMask", "LAYERS",
            "BN_EPS"]

@@ -234,6 +234,47 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
     return out
 
 
+def split_f16(w: torch.Tensor):
+    """fp32 → (hi, lo) fp16 planes: hi = fp16(w), lo = fp16(w - fp32(hi)); hi + lo carries 22 mantissa bits."""
+    hi = w.to(torch.float16)
+    lo = (w - hi.to(torch.float32)).to(torch.float16)
+    return hi.contiguous(), lo.contiguous()
+
+
+def conv_bn_act_f16mfma(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor | None,
+                        scale: torch.Tensor | None, shift: torch.Tensor | None, stride: int = 1,
+                        pad=(0, 0, 0, 0), relu: bool = False, residual: torch.Tensor | None = None,
+                        res_div: int = 1, products: int = 3, algo_cin: int | None = None) -> torch.Tensor:
+    """conv_bn_act on fp16-operand MFMA. x/residual/y fp32 NHWC; w_hi/w_lo fp16 OHWI planes (split_f16).
+    products = 1: plain fp16 operands; products = 3: error-compensated split (fp32-grade accuracy)."""
+    _need_gpu(x, w_hi, w_lo, scale, shift, residual)
+    assert x.dtype == torch.float32 and w_hi.dtype == torch.float16 and x.is_contiguous() and w_hi.is_contiguous()
+    assert w_lo is None or (w_lo.dtype == torch.float16 and w_lo.is_contiguous() and w_lo.shape == w_hi.shape)
+    b, h, wd, cin = x.shape
+    cout, kh, kw, wcin = w_hi.shape
+    if wcin != cin:
+        raise RuntimeError(f"conv_bn_act_f16mfma: weight Cin {wcin} != input Cin {cin}")
+    pt, pl, pb, pr = [int(v) for v in pad]
+    oh = (h + pt + pb - kh) // stride + 1
+    ow = (wd + pl + pr - kw) // stride + 1
+    out = torch.empty(b, oh, ow, cout, dtype=torch.float32, device=x.device)
+    if residual is not None:
+        assert residual.is_contiguous() and tuple(residual.shape) == (b, oh // res_div, ow // res_div, cout)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mrcnn_conv_bn_act_nhwc_f16mfma(x.data_ptr(), b, h, wd, cin, w_hi.data_ptr(), _ptr(w_lo), cout,
+                                             kh, kw, int(stride), pt, pl, pb, pr, _ptr(scale), _ptr(shift),
+                                             _ptr(residual), int(res_div), int(bool(relu)), int(products),
+                                             out.data_ptr(), _stream()))
+    if prof is not None:
+        e1.record()
+        m, k = b * oh * ow, kh * kw * (algo_cin or cin)
+        prof.append((e0, e1, 2.0 * m * k * cout, (m, cout, k)))
+    return out
+
+
 def _conv_bn_act_op(x, w, scale, shift, stride, pad, relu, residual, res_div):
     return conv_bn_act(x, w, scale, shift, stride, pad, relu, residual, res_div)
 
@@ -309,4 +350,4 @@ _LIB.define("bottleneck_forward(Tensor x, Tensor w1, Tensor s1, Tensor t1, Tenso
 _LIB.impl("bottleneck_forward", bottleneck_forward, "CUDA")
 _LIB.impl("bottleneck_forward", lambda x, *a: _need_gpu(x), "CPU")
 
-__all__ += ["conv_bn_act", "same_pad", "maxpool", "nchw_to_nhwc", "nhwc_to_nchw", "bottleneck_forward"]
+__all__ += ["conv_bn_act", "conv_bn_act_f16mfma", "split_f16", "same_pad", "maxpool", "nchw_to_nhwc", "nhwc_to_nchw", "bottleneck_forward"]

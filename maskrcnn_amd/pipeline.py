@@ -54,16 +54,21 @@ class Detections:
 
 
 class MaskRCNNInference:
-    def __init__(self, state_dict: dict, cfg: InferenceConfig | None = None, device="cuda:0"):
+    def __init__(self, state_dict: dict, cfg: InferenceConfig | None = None, device="cuda:0",
+                 precision: str = "f32"):
+        """precision: contraction mode of every conv/GEMM (modules.ConvWeight): "f32" exact-fp32 MFMA (default,
+        the parity mode), "f16x3" fp16-operand MFMA with the error-compensated 3-product split (fp32-grade),
+        "f16" plain fp16 operands (BASELINE config 5). Activations are fp32 in HBM in every mode."""
         self.cfg = cfg or InferenceConfig()
+        self.precision = precision
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("MaskRCNNInference runs on the GPU only (no CPU path)")
         c = self.cfg
-        self.backbone = modules.FusedBackbone(state_dict, c.backbone, self.device)
-        self.rpn = modules.FusedRPN(state_dict, self.device)
-        self.classifier = modules.FusedClassifier(state_dict, self.device)
-        self.mask = modules.FusedMask(state_dict, self.device)
+        self.backbone = modules.FusedBackbone(state_dict, c.backbone, self.device, precision=precision)
+        self.rpn = modules.FusedRPN(state_dict, self.device, precision=precision)
+        self.classifier = modules.FusedClassifier(state_dict, self.device, precision=precision)
+        self.mask = modules.FusedMask(state_dict, self.device, precision=precision)
         self.anchors = pyramid_anchors(c).to(self.device)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.std = torch.tensor(c.rpn_bbox_std_dev, **f32)

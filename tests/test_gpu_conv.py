@@ -113,10 +113,13 @@ def test_bottleneck_golden(dev):
         cin = x.size(1)
         if cin % 4:
             continue
-        blk = modules.FusedBottleneck.from_state_dict(sd, "", int(z[f"b{i}_stride"]), dev)
-        y = blk(x.permute(0, 2, 3, 1).contiguous().to(dev)).permute(0, 3, 1, 2).cpu()
-        err = (y - torch.from_numpy(z[f"b{i}_y"])).abs().max().item()
-        assert err <= TOL, (i, err)
+        for precision in ("f32", "f16x3"):
+            if precision != "f32" and cin % 8:
+                continue
+            blk = modules.FusedBottleneck.from_state_dict(sd, "", int(z[f"b{i}_stride"]), dev, precision)
+            y = blk(x.permute(0, 2, 3, 1).contiguous().to(dev)).permute(0, 3, 1, 2).cpu()
+            err = (y - torch.from_numpy(z[f"b{i}_y"])).abs().max().item()
+            assert err <= TOL, (i, precision, err)
 
 
 def test_maxpool_and_layout(dev):
@@ -136,3 +139,50 @@ def test_maxpool_and_layout(dev):
     y = ops.nchw_to_nhwc(x3.to(dev), 4).cpu()
     assert torch.equal(y[..., :3], x3.permute(0, 2, 3, 1)) and bool((y[..., 3] == 0).all())
     assert ops.same_pad(8, 8, 3, 2) == (0, 0, 1, 1) and ops.same_pad(8, 8, 3, 1) == (1, 1, 1, 1)
+
+
+F16_CASES = [c for c in CASES if c[3] % 8 == 0] + [(2, 32, 32, 8, 64, 7, 2, (3, 3, 3, 3), True, 0, True)]
+
+
+@pytest.mark.parametrize("case", F16_CASES, ids=lambda c: "x".join(str(v) for v in c[:7]))
+def test_conv_f16mfma_vs_torch_cpu(dev, case):
+    """fp16-operand MFMA kernel. products=3 (error-compensated split) must meet the SAME 1e-4 abs bar as the
+    fp32 kernel; products=1 (plain fp16 operands, config 5) is held to its own stated tolerance:
+    2e-3 * sqrt(K) * max|w| * max|x| (fp16 has 11 significand bits)."""
+    from maskrcnn_amd import ops
+    b, h, w, cin, cout, k, stride, pad, relu, res, affine = case
+    g = torch.Generator().manual_seed((hash(case) + 17) % (2 ** 31))
+    x = torch.randn(b, cin, h, w, generator=g)
+    fan = cin * k * k
+    wt = (torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * math.sqrt(6.0 / (fan + cout * k * k))
+    scale = (torch.rand(cout, generator=g) + 0.5) if affine else None
+    shift = torch.randn(cout, generator=g) * 0.1
+    oh = (h + pad[0] + pad[2] - k) // stride + 1
+    ow = (w + pad[1] + pad[3] - k) // stride + 1
+    residual = torch.randn(b, cout, oh // res, ow // res, generator=g) if res else None
+    want = _ref_conv(x, wt, scale, shift, stride, pad, relu, residual, max(res, 1))
+    to_nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    w_hi, w_lo = ops.split_f16(to_nhwc(wt))
+    for products, tol in ((3, TOL), (1, 2e-3 * math.sqrt(fan) * wt.abs().max().item() * x.abs().max().item())):
+        got = ops.conv_bn_act_f16mfma(to_nhwc(x), w_hi, w_lo, None if scale is None else scale.to(dev),
+                                      shift.to(dev), stride, pad, relu,
+                                      None if residual is None else to_nhwc(residual), max(res, 1), products)
+        err = (got.permute(0, 3, 1, 2).cpu() - want).abs().max().item()
+        assert err <= tol, f"products={products}: max abs err {err:.3e} > {tol:.3e}"
+
+
+def test_conv_f16x3_is_fp32_grade_at_large_magnitude(dev):
+    """The split keeps 22 significand bits per operand: relative error stays ~1e-6 for |x| up to 1e4."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 12, 12, 256, generator=g) * 3000.0
+    wt = torch.randn(128, 3, 3, 256, generator=g) * 0.02
+    want = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.permute(0, 3, 1, 2).double(), padding=1)
+    w_hi, w_lo = ops.split_f16(wt.to(dev))
+    got = ops.conv_bn_act_f16mfma(x.to(dev), w_hi, w_lo, None, None, 1, (1, 1, 1, 1), False, None, 1, 3)
+    f32 = ops.conv_bn_act(x.to(dev), wt.to(dev), None, None, 1, (1, 1, 1, 1))
+    ref_scale = want.abs().max().item()
+    e3 = (got.permute(0, 3, 1, 2).cpu().double() - want).abs().max().item() / ref_scale
+    e32 = (f32.permute(0, 3, 1, 2).cpu().double() - want).abs().max().item() / ref_scale
+    assert e3 < 5e-6, e3
+    assert e3 < 20 * max(e32, 1e-8), (e3, e32)   # within a small factor of the exact-fp32 kernel's own error

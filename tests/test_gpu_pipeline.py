@@ -13,8 +13,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def setup():
+@pytest.fixture(scope="module", params=["f32", "f16x3"])
+def setup(request):
+    """Both contraction modes are held to the SAME bars: "f16x3" (fp16-operand MFMA, error-compensated
+    3-product split) claims fp32-grade accuracy, so it has to pass the fp32 path's tests unchanged."""
+    precision = request.param
     assert torch.cuda.is_available()
     from maskrcnn_amd import modules
     from maskrcnn_amd.config import InferenceConfig
@@ -37,7 +40,7 @@ def setup():
     # up. Calibrate the four head layers so scores are distinct and boxes sane; this only rescales the
     # synthetic weights, both paths then see the same state_dict.
     for _ in range(8):
-        net = MaskRCNNInference(sd, cfg, dev)
+        net = MaskRCNNInference(sd, cfg, dev, precision=precision)
         det, mid = net.predict(images.to(dev), windows.to(dev), with_masks=True, return_intermediates=True)
         sc = mid["rpn_scores"].double().clamp(1e-7, 1 - 1e-7)
         sat = torch.log(sc / (1 - sc)).std().item()  # std of the fg-bg logit difference

@@ -25,3 +25,14 @@ for (b, h, wd, cin, cout, k) in [(8, 256, 256, 256, 512, 3), (8, 64, 64, 256, 25
         w = torch.randn(cout, k, k, cin, device=dev) * 0.05 if fill is None else torch.zeros(cout, k, k, cin, device=dev)
         ms = run(x, w, pad=pad)
         print(f"M={b*h*wd} N={cout} K={cin*k*k} {name}: {ms:.3f} ms  {flops/ms/1e9:.1f} TFLOP/s", flush=True)
+        w_hi, w_lo = ops.split_f16(w)
+        for products in (3, 1):
+            fn = lambda: ops.conv_bn_act_f16mfma(x, w_hi, w_lo, None, None, 1, pad, False, None, 1, products)
+            for _ in range(3): fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20): fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            print(f"    f16mfma products={products}: {ms:.3f} ms  {flops/ms/1e9:.1f} TFLOP/s (algorithmic)", flush=True)
