@@ -54,13 +54,19 @@ const char* mrcnn_arch(void);
  *               loop in MaskRCNN.mrn_refine (model.py:1454-1475).
  *   keep_out    int64[S][n_max]: first counts_out[s] entries = kept indices ascending, rest = -1
  *   counts_out  int32[S]
- * Limits: 1 <= n_max <= mrcnn_nms_max_boxes() (on-chip path; LDS-resident).  S >= 1.
+ *   workspace   optional device scratch of >= mrcnn_nms_workspace_bytes(S, n_max) bytes, 16-byte aligned.
+ *               NULL: one LDS-resident workgroup per segment does everything (one launch, no scratch).
+ *               Given (and n_max > 128): the pair tests are spread over the whole chip (sort → 64x64 pair-mask
+ *               tiles → serial scan), 3 launches, several times faster at n_max >= 500. Same results.
+ * Limits: 1 <= n_max <= mrcnn_nms_max_boxes().  S >= 1.
  * ---------------------------------------------------------------------------------------------- */
 int64_t mrcnn_nms_max_boxes(void);
+size_t mrcnn_nms_workspace_bytes(int32_t num_segments, int64_t n_max);
 int mrcnn_nms_batched_f32(const float* dets, int32_t num_segments, int64_t n_max, int64_t seg_stride,
                           int64_t row_stride, int64_t col_stride, const int32_t* seg_counts,
                           const int32_t* class_ids, float threshold, int64_t* keep_out,
-                          int32_t* counts_out, mrcnn_stream_t stream);
+                          int32_t* counts_out, void* workspace, size_t workspace_bytes,
+                          mrcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * crop_and_resize ("RoIAlign") forward — replaces

@@ -20,8 +20,9 @@ _SIGS = {
     "mrcnn_last_error": (ctypes.c_char_p, []),
     "mrcnn_arch": (ctypes.c_char_p, []),
     "mrcnn_nms_max_boxes": (c_i64, []),
+    "mrcnn_nms_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i64]),
     "mrcnn_nms_batched_f32": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp,
-                                               c_f32, c_vp, c_vp, c_vp]),
+                                               c_f32, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "mrcnn_crop_forward_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32,
                                                 c_f32, c_i32, c_i32, c_vp, c_vp]),
     "mrcnn_crop_backward_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,

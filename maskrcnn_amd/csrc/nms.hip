@@ -253,6 +253,206 @@ __global__ __launch_bounds__(T) void nms_kernel(const float* __restrict__ dets, 
     if (tid == 0) counts_out[seg] = total;
 }
 
+
+// =====================================================================================================
+// Path 2 (needs a caller-provided workspace): the O(N^2) pair tests leave the single workgroup and spread
+// over the whole chip; only the inherently serial greedy scan stays on one wave per segment.
+//   K1 nms_sort_kernel   1 workgroup / segment : LDS bitonic sort, sorted boxes + areas + classes + input
+//                                                indices to the workspace
+//   K2 nms_mask_kernel   1 wave / 64x64 tile   : lane = column box, 64 row boxes broadcast by readlane,
+//                                                one __ballot per row → mask[row][column word] (upper triangle)
+//   K3 nms_scan_kernel   1 workgroup / segment : mask rows of the segment pulled into LDS (N <= 1024) or read
+//                                                from L2; wave 0 keeps the "removed" bitset one 64-bit word per
+//                                                lane, resolves each 64-box chunk serially over its alive boxes
+//                                                (readlane), ORs the survivors' rows into the bitset; then
+//                                                ballot/popcount compaction to ascending input indices.
+// Identical arithmetic (iou_ge) and identical visiting order → identical keep set to path 1 and the CPU path.
+// =====================================================================================================
+struct NmsWs {
+    float4* box;    // [S][Np] sorted (y1,x1,y2,x2)
+    float* area;    // [S][Np]
+    int* cls;       // [S][Np]
+    int* idx;       // [S][Np] input index, -1 for padding
+    u64* mask;      // [S][Np][NB]
+    int np, nb;
+};
+
+template <int CAP, int T>
+__global__ __launch_bounds__(T) void nms_sort_kernel(const float* __restrict__ dets, int64_t n_max,
+                                                     int64_t seg_stride, int64_t row_stride,
+                                                     int64_t col_stride,
+                                                     const int32_t* __restrict__ seg_counts,
+                                                     const int32_t* __restrict__ class_ids, NmsWs ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);  // [CAP]
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    int n = seg_counts ? seg_counts[seg] : static_cast<int>(n_max);
+    n = n < 0 ? 0 : (n > n_max ? static_cast<int>(n_max) : n);
+    const float* d = dets + static_cast<int64_t>(seg) * seg_stride;
+    const int32_t* cls = class_ids ? class_ids + static_cast<int64_t>(seg) * n_max : nullptr;
+    int np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    for (int i = tid; i < np2; i += T)
+        keys[i] = (i < n) ? make_key(d[i * row_stride + 4 * col_stride], static_cast<u32>(i)) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (np2 >> 1); t += T) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const u64 a = keys[i], b = keys[i + j];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    keys[i] = b;
+                    keys[i + j] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int64_t base = static_cast<int64_t>(seg) * ws.np;
+    for (int p = tid; p < ws.np; p += T) {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        float area = 0.f;
+        int c = 0, idx = -1;
+        if (p < n) {
+            idx = static_cast<int>(keys[p] & 0xFFFFFFFFu);
+            const float* r = d + static_cast<int64_t>(idx) * row_stride;
+            b.x = r[0]; b.y = r[col_stride]; b.z = r[2 * col_stride]; b.w = r[3 * col_stride];
+            float w = b.w - b.y;
+            w = w + 1.0f;
+            float h = b.z - b.x;
+            h = h + 1.0f;
+            area = w * h;  // nms_cpu.cpp:26
+            c = cls ? cls[idx] : 0;
+        }
+        ws.box[base + p] = b;
+        ws.area[base + p] = area;
+        ws.cls[base + p] = c;
+        ws.idx[base + p] = idx;
+    }
+}
+
+// grid = (nb*(nb+1)/2 upper-triangle tiles, S), block = 64
+__global__ __launch_bounds__(64) void nms_mask_kernel(NmsWs ws, float thr) {
+    // decode (rb <= cb) from the linear upper-triangle index
+    int t = blockIdx.x, rb = 0;
+    while (t >= ws.nb - rb) { t -= ws.nb - rb; ++rb; }
+    const int cb = rb + t;
+    const int seg = blockIdx.y, lane = threadIdx.x;
+    const int64_t base = static_cast<int64_t>(seg) * ws.np;
+    const int pj = cb * 64 + lane, pi0 = rb * 64;
+    const float4 bj4 = ws.box[base + pj];
+    const Box bj = {bj4.x, bj4.y, bj4.z, bj4.w, ws.area[base + pj]};
+    const int cj = ws.cls[base + pj];
+    const bool jvalid = ws.idx[base + pj] >= 0;
+    // row boxes: lane i holds row i; broadcast with readlane
+    const float4 bi4 = ws.box[base + pi0 + lane];
+    const float ai = ws.area[base + pi0 + lane];
+    const int ci = ws.cls[base + pi0 + lane];
+    u64 mine = 0;  // lane i ends up holding row i's word
+    for (int i = 0; i < 64; ++i) {
+        Box bi;
+        bi.y1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bi4.x), i));
+        bi.x1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bi4.y), i));
+        bi.y2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bi4.z), i));
+        bi.x2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bi4.w), i));
+        bi.area = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ai), i));
+        const int cri = __builtin_amdgcn_readlane(ci, i);
+        const bool hit = jvalid && (pj > pi0 + i) && (cri == cj) && iou_ge(bi, bj, thr);
+        const u64 m = __ballot(hit);
+        if (lane == i) mine = m;
+    }
+    ws.mask[(base + pi0 + lane) * ws.nb + cb] = mine;
+}
+
+// grid = S, block = 256. LDS: mask rows (when they fit) + keep flags.
+template <bool MASK_IN_LDS>
+__global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs ws, int64_t n_max,
+                                                       const int32_t* __restrict__ seg_counts,
+                                                       int64_t* __restrict__ keep_out,
+                                                       int32_t* __restrict__ counts_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int np = ws.np, nb = ws.nb;
+    int n = seg_counts ? seg_counts[seg] : static_cast<int>(n_max);
+    n = n < 0 ? 0 : (n > n_max ? static_cast<int>(n_max) : n);
+    const int64_t base = static_cast<int64_t>(seg) * np;
+    const u64* gmask = ws.mask + base * nb;
+    u64* lmask = reinterpret_cast<u64*>(smem);                                  // [np][nb] if MASK_IN_LDS
+    unsigned char* keepf = smem + (MASK_IN_LDS ? sizeof(u64) * np * nb : 0);    // [np] by input index
+    u64* keptw = reinterpret_cast<u64*>(keepf + np);                            // [nb] survivors per chunk
+    const int nchunks = (n + 63) >> 6;
+    if (MASK_IN_LDS) {
+        // only rows < n and only the upper triangle were written by K2; copy whole rows of live chunks
+        for (int e = tid; e < nchunks * 64 * nb; e += 256) lmask[e] = gmask[e];
+    }
+    for (int i = tid; i < np; i += 256) keepf[i] = 0;
+    __syncthreads();
+    const u64* mk = MASK_IN_LDS ? lmask : gmask;
+    if (wave == 0) {
+        u64 remv = 0;  // lane w: removed bits of boxes [64w, 64w+63]
+        for (int c = 0; c < nchunks; ++c) {
+            const int p = c * 64 + lane;
+            const u64 cm = (lane < 64) ? mk[static_cast<int64_t>(p) * nb + c] : 0;  // diagonal word of row p
+            const u32 cm_lo = static_cast<u32>(cm), cm_hi = static_cast<u32>(cm >> 32);
+            const u32 r_lo = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(remv)), c));
+            const u32 r_hi = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(remv >> 32)), c));
+            const u64 removed = (static_cast<u64>(r_hi) << 32) | r_lo;
+            const u64 validm = (n - c * 64 >= 64) ? ~0ull : ((1ull << (n - c * 64)) - 1ull);
+            u64 alive = ~removed & validm;
+            u64 kept = 0, rem = alive;
+            while (rem) {
+                const int i = __builtin_ctzll(rem);
+                kept |= 1ull << i;
+                const u32 m_hi = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(cm_hi), i));
+                const u32 m_lo = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(cm_lo), i));
+                alive &= ~((static_cast<u64>(m_hi) << 32) | m_lo);
+                rem = alive & ~((2ull << i) - 1ull);
+            }
+            if (lane == 0) keptw[c] = kept;
+            // survivors of this chunk remove later boxes: lane w ORs word w of every surviving row
+            if (lane > c && lane < nb) {
+                u64 acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+                const u64* rowp = mk + (static_cast<int64_t>(c) * 64) * nb + lane;
+#pragma unroll 4
+                for (int i = 0; i < 64; i += 4) {
+                    const u64 v0 = rowp[static_cast<int64_t>(i) * nb];
+                    const u64 v1 = rowp[static_cast<int64_t>(i + 1) * nb];
+                    const u64 v2 = rowp[static_cast<int64_t>(i + 2) * nb];
+                    const u64 v3 = rowp[static_cast<int64_t>(i + 3) * nb];
+                    acc0 |= ((kept >> i) & 1ull) ? v0 : 0ull;
+                    acc1 |= ((kept >> (i + 1)) & 1ull) ? v1 : 0ull;
+                    acc2 |= ((kept >> (i + 2)) & 1ull) ? v2 : 0ull;
+                    acc3 |= ((kept >> (i + 3)) & 1ull) ? v3 : 0ull;
+                }
+                remv |= acc0 | acc1 | acc2 | acc3;
+            }
+        }
+    }
+    __syncthreads();
+    // survivors → flags by input index
+    for (int p = tid; p < n; p += 256)
+        if ((keptw[p >> 6] >> (p & 63)) & 1ull) keepf[ws.idx[base + p]] = 1;
+    __syncthreads();
+    // ascending-index compaction by wave 0 (ballot + popcount), then -1 padding by everyone
+    int64_t* keep = keep_out + static_cast<int64_t>(seg) * n_max;
+    int* totalp = reinterpret_cast<int*>(keptw + nb);
+    if (wave == 0) {
+        int basepos = 0;
+        for (int w0 = 0; w0 < n; w0 += 64) {
+            const int i = w0 + lane;
+            const bool f = (i < n) && keepf[i];
+            const u64 m = __ballot(f);
+            if (f) keep[basepos + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+            basepos += __builtin_popcountll(m);
+        }
+        if (lane == 0) { *totalp = basepos; counts_out[seg] = basepos; }
+    }
+    __syncthreads();
+    const int total = *totalp;
+    for (int64_t i = total + tid; i < n_max; i += 256) keep[i] = -1;
+}
+
 template <int CAP>
 constexpr size_t nms_lds_bytes() {
     return sizeof(u64) * CAP + sizeof(float) * 5 * CAP + sizeof(int) * CAP + sizeof(u64) * 64 +
@@ -277,21 +477,97 @@ int launch(const float* dets, int32_t S, int64_t n_max, int64_t seg_stride, int6
     return mrcnn::check_launch("nms_kernel");
 }
 
+template <int CAP, int T>
+int launch_sort(const float* dets, int32_t S, int64_t n_max, int64_t seg_stride, int64_t row_stride,
+                int64_t col_stride, const int32_t* seg_counts, const int32_t* class_ids, NmsWs ws,
+                hipStream_t stream) {
+    hipLaunchKernelGGL((nms_sort_kernel<CAP, T>), dim3(S), dim3(T), sizeof(u64) * CAP, stream, dets, n_max,
+                       seg_stride, row_stride, col_stride, seg_counts, class_ids, ws);
+    return mrcnn::check_launch("nms_sort_kernel");
+}
+
+size_t ws_layout(int32_t S, int64_t n_max, void* base, NmsWs* ws) {
+    const int np = static_cast<int>((n_max + 63) / 64 * 64), nb = np / 64;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_box = take(sizeof(float4) * S * np), o_area = take(sizeof(float) * S * np);
+    const size_t o_cls = take(sizeof(int) * S * np), o_idx = take(sizeof(int) * S * np);
+    const size_t o_mask = take(sizeof(u64) * S * np * nb);
+    if (ws) {
+        unsigned char* b = static_cast<unsigned char*>(base);
+        ws->box = reinterpret_cast<float4*>(b + o_box);
+        ws->area = reinterpret_cast<float*>(b + o_area);
+        ws->cls = reinterpret_cast<int*>(b + o_cls);
+        ws->idx = reinterpret_cast<int*>(b + o_idx);
+        ws->mask = reinterpret_cast<u64*>(b + o_mask);
+        ws->np = np;
+        ws->nb = nb;
+    }
+    return off;
+}
+
 }  // namespace
 
 extern "C" int64_t mrcnn_nms_max_boxes(void) { return 4096; }
+
+extern "C" size_t mrcnn_nms_workspace_bytes(int32_t num_segments, int64_t n_max) {
+    if (num_segments < 1 || n_max < 1 || n_max > mrcnn_nms_max_boxes()) return 0;
+    return ws_layout(num_segments, n_max, nullptr, nullptr);
+}
 
 extern "C" int mrcnn_nms_batched_f32(const float* dets, int32_t num_segments, int64_t n_max,
                                      int64_t seg_stride, int64_t row_stride, int64_t col_stride,
                                      const int32_t* seg_counts, const int32_t* class_ids,
                                      float threshold, int64_t* keep_out, int32_t* counts_out,
-                                     mrcnn_stream_t stream) {
+                                     void* workspace, size_t workspace_bytes, mrcnn_stream_t stream) {
     MRCNN_REQUIRE(dets && keep_out && counts_out, "nms: null pointer");
     MRCNN_REQUIRE(num_segments >= 1, "nms: num_segments=%d must be >= 1", num_segments);
     MRCNN_REQUIRE(n_max >= 1 && n_max <= mrcnn_nms_max_boxes(),
                   "nms: n_max=%lld outside [1, %lld] (on-chip path)", (long long)n_max,
                   (long long)mrcnn_nms_max_boxes());
     hipStream_t s = mrcnn::as_stream(stream);
+    if (workspace && n_max > 128) {
+        // ---- path 2: sort → pair mask over the whole chip → serial scan ------------------------------
+        MRCNN_REQUIRE(workspace_bytes >= mrcnn_nms_workspace_bytes(num_segments, n_max),
+                      "nms: workspace too small (%zu < %zu bytes)", workspace_bytes,
+                      mrcnn_nms_workspace_bytes(num_segments, n_max));
+        MRCNN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "nms: workspace must be 16-byte aligned");
+        NmsWs ws;
+        ws_layout(num_segments, n_max, workspace, &ws);
+        int rc;
+        if (n_max <= 1024)
+            rc = launch_sort<1024, 1024>(dets, num_segments, n_max, seg_stride, row_stride, col_stride,
+                                         seg_counts, class_ids, ws, s);
+        else if (n_max <= 2048)
+            rc = launch_sort<2048, 1024>(dets, num_segments, n_max, seg_stride, row_stride, col_stride,
+                                         seg_counts, class_ids, ws, s);
+        else
+            rc = launch_sort<4096, 1024>(dets, num_segments, n_max, seg_stride, row_stride, col_stride,
+                                         seg_counts, class_ids, ws, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(ws.nb * (ws.nb + 1) / 2, num_segments), dim3(64), 0, s, ws,
+                           threshold);
+        if ((rc = mrcnn::check_launch("nms_mask_kernel"))) return rc;
+        const size_t tail = ws.np + sizeof(u64) * ws.nb + 16;
+        const size_t lds_full = sizeof(u64) * ws.np * ws.nb + tail;
+        if (lds_full <= 150 * 1024) {
+            auto k = nms_scan_kernel<true>;
+            if (lds_full > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   static_cast<int>(lds_full));
+                if (e != hipSuccess)
+                    return mrcnn::fail(MRCNN_ERR_LAUNCH, "nms: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            }
+            hipLaunchKernelGGL(k, dim3(num_segments), dim3(256), lds_full, s, ws, n_max, seg_counts, keep_out,
+                               counts_out);
+        } else {
+            hipLaunchKernelGGL(nms_scan_kernel<false>, dim3(num_segments), dim3(256), tail, s, ws, n_max,
+                               seg_counts, keep_out, counts_out);
+        }
+        return mrcnn::check_launch("nms_scan_kernel");
+    }
+    // ---- path 1: one LDS-resident workgroup per segment, no workspace --------------------------------
     if (n_max <= 256)
         return launch<256, 256>(dets, num_segments, n_max, seg_stride, row_stride, col_stride,
                                 seg_counts, class_ids, threshold, keep_out, counts_out, s);

@@ -41,9 +41,9 @@ def _need_gpu(*tensors):
 # NMS
 # --------------------------------------------------------------------------------------------------
 def nms_batched(dets: torch.Tensor, threshold: float, seg_counts: torch.Tensor | None = None,
-                class_ids: torch.Tensor | None = None):
+                class_ids: torch.Tensor | None = None, use_workspace: bool = True):
     """dets [S, N, 5] fp32 (any strides) → (keep int64 [S, N] ascending indices padded with -1,
-    counts int32 [S]). No host synchronisation."""
+    counts int32 [S]). No host synchronisation. use_workspace=False forces the single-launch LDS path."""
     _need_gpu(dets, seg_counts, class_ids)
     if dets.dtype != torch.float32:
         raise RuntimeError(f'"nms" GPU path implemented for Float only, got {dets.dtype}')
@@ -55,9 +55,14 @@ def nms_batched(dets: torch.Tensor, threshold: float, seg_counts: torch.Tensor |
         assert seg_counts.dtype == torch.int32 and seg_counts.is_contiguous() and seg_counts.numel() == s
     if class_ids is not None:
         assert class_ids.dtype == torch.int32 and class_ids.is_contiguous() and class_ids.numel() == s * n
+    ws, ws_bytes = None, 0
+    if use_workspace and n > 128:
+        ws_bytes = int(lib.mrcnn_nms_workspace_bytes(s, n))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dets.device)
     check(lib.mrcnn_nms_batched_f32(dets.data_ptr(), s, n, dets.stride(0), dets.stride(1),
                                     dets.stride(2), _ptr(seg_counts), _ptr(class_ids),
-                                    float(threshold), keep.data_ptr(), counts.data_ptr(), _stream()))
+                                    float(threshold), keep.data_ptr(), counts.data_ptr(), _ptr(ws), ws_bytes,
+                                    _stream()))
     return keep, counts
 
 

@@ -56,6 +56,7 @@ def test_nms_golden(dev):
 
 def test_nms_random_vs_oracle(dev, oracle):
     import maskrcnn
+    from maskrcnn_amd import ops
     g = torch.Generator().manual_seed(7)
     for n in (1, 5, 64, 65, 255, 256, 257, 777, 1000, 1024, 1025, 2048, 3000, 4096):
         for thr in (0.3, 0.7):
@@ -63,6 +64,10 @@ def test_nms_random_vs_oracle(dev, oracle):
             want = oracle.nms(d, thr)
             got = maskrcnn.nms(d.to(dev), thr).cpu()
             assert torch.equal(got, want), (n, thr)
+            # both device paths: chip-wide pair mask (workspace) and the single-launch LDS kernel
+            for ws in (True, False):
+                keep, cnt = ops.nms_batched(d.to(dev).unsqueeze(0), thr, use_workspace=ws)
+                assert torch.equal(keep[0, :int(cnt[0])].cpu(), want), (n, thr, ws)
     with pytest.raises(RuntimeError):
         maskrcnn.nms(_rand_dets(g, 5000).to(dev), 0.5)  # beyond the on-chip path: loud, not wrong
 
@@ -88,7 +93,9 @@ def test_nms_batched_class_aware(dev, oracle):
     dets = torch.stack([_rand_dets(g, N) for _ in range(S)])
     counts = torch.tensor([1000, 999, 512, 1, 0, 64, 65, 300], dtype=torch.int32)
     cls = torch.randint(1, 9, (S, N), generator=g, dtype=torch.int32)
+    keep1, cnt1 = ops.nms_batched(dets.to(dev), 0.3, counts.to(dev), cls.to(dev), use_workspace=False)
     keep, cnt = ops.nms_batched(dets.to(dev), 0.3, counts.to(dev), cls.to(dev))
+    assert torch.equal(keep, keep1) and torch.equal(cnt, cnt1)
     keep, cnt = keep.cpu(), cnt.cpu()
     for s in range(S):
         n = int(counts[s])

@@ -161,3 +161,66 @@ def test_batch_independence_and_determinism(setup):
     assert torch.equal(det.class_ids[0], s["det"].class_ids[1])
     assert torch.equal(det.boxes[0], s["det"].boxes[1])
     assert torch.equal(det.scores[0], s["det"].scores[1])
+
+
+# ------------------------------------------------------------------------------------------------------
+# non-square images, ResNet-101 (BASELINE config 5 shape class), hipGraph capture
+# ------------------------------------------------------------------------------------------------------
+def _small_net(precision, h, w, arch, seed=11):
+    from maskrcnn_amd import modules
+    from maskrcnn_amd.config import InferenceConfig
+    from maskrcnn_amd.pipeline import MaskRCNNInference
+    dev = torch.device("cuda:0")
+    cfg = InferenceConfig(image_height=h, image_width=w, backbone=arch, pre_nms_limit=200,
+                          proposal_count=100, detection_max_instances=10)
+    sd = modules.synthetic_state_dict(arch, seed=0, bn_seed=1)
+    g = torch.Generator().manual_seed(seed)
+    images = (torch.randint(0, 256, (1, h, w, 3), generator=g).float() - torch.tensor(cfg.mean_pixel))
+    images = images.permute(0, 3, 1, 2).contiguous()
+    windows = torch.tensor([[0., 0., float(h), float(w)]])
+    return cfg, sd, MaskRCNNInference(sd, cfg, dev, precision=precision), images, windows, dev
+
+
+def test_config5_shape_class_r101_nonsquare(oracle):
+    """ResNet-101-FPN on a non-square image (the 832x1344 class of BASELINE config 5, reduced to 192x320):
+    exact-fp32 and f16x3 trunks meet the fp32 bar; the plain-fp16 MFMA path ("fp16 MFMA path" of config 5)
+    is held to its own stated tolerance, 2e-2 of the activation range (11 significand bits, ~100 layers)."""
+    want = None
+    for precision, rel in (("f32", 1e-4), ("f16x3", 1e-4), ("f16", 2e-2)):
+        cfg, sd, net, images, windows, dev = _small_net(precision, 192, 320, "resnet101")
+        if want is None:
+            want = oracle.fpn_forward(images, sd, "resnet101")
+            assert [tuple(f.shape[2:]) for f in want] == [(48, 80), (24, 40), (12, 20), (6, 10), (3, 5)]
+        det, mid = net.predict(images.to(dev), windows.to(dev), return_intermediates=True)
+        for lvl, (w_, g_) in enumerate(zip(want, mid["feature_maps"])):
+            err = (g_[0].permute(2, 0, 1).cpu() - w_[0]).abs().max().item()
+            tol = rel * max(1.0, w_.abs().max().item())
+            assert err <= tol, f"{precision} P{lvl + 2}: {err:.3e} > {tol:.3e}"
+        assert tuple(mid["rpn_scores"].shape) == (1, 3 * (48 * 80 + 24 * 40 + 12 * 20 + 6 * 10 + 3 * 5))
+        assert tuple(det.boxes.shape) == (1, 10, 4) and tuple(det.masks.shape) == (1, 10, 28, 28, 81)
+        assert bool((det.boxes[..., 2] <= 192).all()) and bool((det.boxes[..., 3] <= 320).all())
+
+
+def test_step_is_hipgraph_capturable():
+    """No allocation-dependent control flow, no host sync: the whole step captures into a hipGraph and the
+    replay reproduces the eager result bit for bit."""
+    cfg, sd, net, images, windows, dev = _small_net("f32", 128, 128, "resnet50")
+    images, windows = images.to(dev), windows.to(dev)
+    eager = net.predict(images, windows)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            net.predict(images, windows)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = net.predict(images, windows)
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured.class_ids, eager.class_ids)
+    assert torch.equal(captured.boxes, eager.boxes)
+    assert torch.equal(captured.scores, eager.scores)
+    assert torch.equal(captured.masks, eager.masks)
