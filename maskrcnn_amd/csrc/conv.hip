@@ -116,52 +116,62 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
                            __uint_as_float(v.w));
     };
-    int t_c0 = 0, t_ky = 0, t_kx = 0;  // (tap, channel) of the NEXT tile to load — wave-uniform, incremental
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
+    // ---- staging in pieces ---------------------------------------------------------------------------
+    // One k tile = PA + PB pieces (one 16-byte slot each). Loads and LDS writes are issued piece by piece
+    // BETWEEN the MFMAs of the main loop (below), so their issue cycles hide in the 64-cycle shadow of the
+    // wave's own MFMAs instead of forming an MFMA-free block around the barrier.
+    int t_c0 = 0, t_ky = 0, t_kx = 0, t_k0 = 0;  // (tap, channel, k) of the NEXT k tile to load — wave-uniform
+    int cur_tap_off = 0, cur_ky = 0, cur_kx = 0, cur_k0 = 0;
+    bool cur_kvalid = true;
+    auto begin_load = [&]() {  // scalar bookkeeping for the k tile about to be loaded
+        cur_k0 = t_k0;
+        cur_kvalid = t_k0 < p.K;
         if constexpr (!GENERIC) {
-            const int ky = t_ky, kx = t_kx;
-            const int tap_off = (ky * p.W + kx) * p.Cin + t_c0 + kq * 4;
-#pragma unroll
-            for (int i = 0; i < PA; ++i) {
-                const bool ok = static_cast<unsigned>(a_iy[i] + ky) < static_cast<unsigned>(p.H) &&
-                                static_cast<unsigned>(a_ix[i] + kx) < static_cast<unsigned>(p.W);
-                ra[i] = bload(x_rsrc, ok ? static_cast<unsigned>(a_off[i] + tap_off) * 4u : OOB);
-            }
-#pragma unroll
-            for (int i = 0; i < PB; ++i)
-                rb[i] = bload(w_rsrc, b_ok[i] ? static_cast<unsigned>(b_off[i] + k0) * 4u : OOB);
+            cur_ky = t_ky;
+            cur_kx = t_kx;
+            cur_tap_off = (t_ky * p.W + t_kx) * p.Cin + t_c0 + kq * 4;
             t_c0 += BK;
             if (t_c0 >= p.Cin) {
                 t_c0 = 0;
                 if (++t_kx == p.KW) { t_kx = 0; ++t_ky; }
             }
-        } else {
-            const int kk = k0 + kq * 4;
-            const bool kin = kk < p.K;
-            const int tap = kk / p.Cin, c = kk - tap * p.Cin;
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
-            const int tap_off = (ky * p.W + kx) * p.Cin + c;
-#pragma unroll
-            for (int i = 0; i < PA; ++i) {
+        }
+        t_k0 += BK;
+    };
+    auto load_piece = [&](int pc) {  // pc < PA: activation slot pc; else weight slot pc - PA
+        if (pc < PA) {
+            const int i = pc;
+            if constexpr (!GENERIC) {
+                const bool ok = cur_kvalid &&
+                                static_cast<unsigned>(a_iy[i] + cur_ky) < static_cast<unsigned>(p.H) &&
+                                static_cast<unsigned>(a_ix[i] + cur_kx) < static_cast<unsigned>(p.W);
+                ra[i] = bload(x_rsrc, ok ? static_cast<unsigned>(a_off[i] + cur_tap_off) * 4u : OOB);
+            } else {
+                const int kk = cur_k0 + kq * 4;
+                const bool kin = kk < p.K;
+                const int tap = kk / p.Cin, c = kk - tap * p.Cin;
+                const int ky = tap / p.KW, kx = tap - ky * p.KW;
+                const int tap_off = (ky * p.W + kx) * p.Cin + c;
                 const bool ok = kin &&
                                 static_cast<unsigned>(a_iy[i] + ky) < static_cast<unsigned>(p.H) &&
                                 static_cast<unsigned>(a_ix[i] + kx) < static_cast<unsigned>(p.W);
                 ra[i] = bload(x_rsrc, ok ? static_cast<unsigned>(a_off[i] + tap_off) * 4u : OOB);
             }
-#pragma unroll
-            for (int i = 0; i < PB; ++i)
-                rb[i] = bload(w_rsrc, (b_ok[i] && kin) ? static_cast<unsigned>(b_off[i] + k0) * 4u : OOB);
+        } else {
+            const int i = pc - PA;
+            bool ok = b_ok[i] && cur_kvalid;
+            if constexpr (GENERIC) ok = ok && (cur_k0 + kq * 4 < p.K);
+            rb[i] = bload(w_rsrc, ok ? static_cast<unsigned>(b_off[i] + cur_k0) * 4u : OOB);
         }
     };
-    auto store_tile = [&](int buf) {
-        float* a = As + buf * BM * LDS_STRIDE + r0 * LDS_STRIDE + kq * 4;
-        float* b = Bs + buf * BN * LDS_STRIDE + r0 * LDS_STRIDE + kq * 4;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) *reinterpret_cast<float4*>(a + RPP * i * LDS_STRIDE) = ra[i];
-#pragma unroll
-        for (int i = 0; i < PB; ++i) *reinterpret_cast<float4*>(b + RPP * i * LDS_STRIDE) = rb[i];
+    auto store_piece = [&](int pc, int buf) {
+        if (pc < PA)
+            *reinterpret_cast<float4*>(As + buf * BM * LDS_STRIDE + (r0 + RPP * pc) * LDS_STRIDE + kq * 4) = ra[pc];
+        else
+            *reinterpret_cast<float4*>(Bs + buf * BN * LDS_STRIDE + (r0 + RPP * (pc - PA)) * LDS_STRIDE + kq * 4) =
+                rb[pc - PA];
     };
+    constexpr int NP = PA + PB;  // pieces per k tile
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -171,17 +181,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- main loop: software-pipelined over 8-deep k chunks, ONE barrier per k tile ------------------
-    // The barrier for tile t+1 sits BEFORE the last chunk of tile t: by then the fragments of that last
-    // chunk are already in registers, so its 4*TM*TN MFMAs cover the barrier skew and the LDS latency of the
-    // first fragments of tile t+1 (issued right after the barrier). Global loads for tile t+2 are issued
-    // at the same point and land in LDS one full tile later.
+    // ---- main loop ------------------------------------------------------------------------------------
+    // Per k tile and wave: NCH chunks of NM = 4*TM*TN MFMAs. The order of everything is pinned
+    // (sched_barrier after every MFMA):
+    //   chunk j < NCH-1 : prefetch the fragments of chunk j+1, then its MFMAs;
+    //   chunk NCH-2     : additionally one LDS-write piece of k tile kt+1 after every NM/NP-th MFMA;
+    //   chunk NCH-1     : barrier, prefetch chunk 0 of k tile kt+1, then its MFMAs with one global-load piece
+    //                     of k tile kt+2 after every NM/NP-th MFMA.
+    // Past the end of K the loads carry out-of-range offsets (zeros, no memory traffic) and the LDS writes
+    // fill a buffer nobody reads, so the loop body is free of conditionals.
     const int nk = (p.K + BK - 1) / BK;
     constexpr int NCH = BK / 8;
-    load_tile(0);
-    store_tile(0);
+    constexpr int NM = 4 * TM * TN;
+    static_assert(NCH >= 2, "needs at least two chunks per k tile");
+    begin_load();
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) store_piece(pc, 0);
     __syncthreads();
-    if (nk > 1) load_tile(1);
+    begin_load();
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc);
 
     const int frag = (lane & 31) * LDS_STRIDE + (lane >> 5) * 4;
     const float* Aw = As + wm * WTM * LDS_STRIDE + frag;
@@ -195,22 +216,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
         for (int i = 0; i < TN; ++i)
             fb[slot][i] = *reinterpret_cast<const float4*>(Bw + buf * BN * LDS_STRIDE + i * 32 * LDS_STRIDE + j * 8);
     };
-    auto mfma_chunk = [&](int slot) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float4 a = fa[slot][i];
-                const float av = s == 0 ? a.x : s == 1 ? a.y : s == 2 ? a.z : a.w;
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn) {
-                    const float4 b = fb[slot][jn];
-                    const float bv = s == 0 ? b.x : s == 1 ? b.y : s == 2 ? b.z : b.w;
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jn], 0, 0, 0);
-                }
-            }
-        }
-    };
     read_frags(0, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -220,15 +225,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
             if (j + 1 < NCH) {
                 read_frags(cur ^ 1, buf, j + 1);
             } else {
-                if (kt + 1 < nk) store_tile(buf ^ 1);   // registers hold tile kt+1 (loaded one tile ago)
-                __syncthreads();
-                if (kt + 1 < nk) {
-                    if (kt + 2 < nk) load_tile(kt + 2);
-                    read_frags(cur ^ 1, buf ^ 1, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);      // keep the last chunk's MFMAs AFTER the barrier
+                __syncthreads();  // every wave has written its pieces of k tile kt+1 and read k tile kt
+                read_frags(cur ^ 1, buf ^ 1, 0);
+                begin_load();     // k tile kt+2
             }
-            mfma_chunk(cur);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float4 a = fa[cur][i];
+                    const float av = s == 0 ? a.x : s == 1 ? a.y : s == 2 ? a.z : a.w;
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn) {
+                        const float4 b = fb[cur][jn];
+                        const float bv = s == 0 ? b.x : s == 1 ? b.y : s == 2 ? b.z : b.w;
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jn], 0, 0, 0);
+                        const int m = (s * TM + i) * TN + jn;  // MFMA index in the chunk, 0..NM-1
+#pragma unroll
+                        for (int pc = m * NP / NM; pc < (m + 1) * NP / NM; ++pc) {
+                            if (j == NCH - 2) store_piece(pc, buf ^ 1);
+                            if (j == NCH - 1) load_piece(pc);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
         }
     }
 
@@ -300,7 +322,8 @@ int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
     const int per_xcd = (p.tiles_m + 7) / 8;
     const long long grid = 8LL * per_xcd * p.tiles_n;
     if (grid > 0x7fffffffLL) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: grid too large");
-    constexpr size_t lds = conv_lds_bytes<BM, BN, BK>();
+    static const size_t lds_pad = getenv("MRCNN_CONV_LDS_PAD") ? atoi(getenv("MRCNN_CONV_LDS_PAD")) : 0;  // tuning aid
+    const size_t lds = conv_lds_bytes<BM, BN, BK>() + lds_pad;
     auto set_attr = [&](const void* f) -> int {
         if (lds <= 64 * 1024) return MRCNN_OK;
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -376,5 +399,6 @@ extern "C" int mrcnn_conv_bn_act_nhwc_f32(const float* x, int32_t batch, int32_t
     // a loss on mid-size ones; kept selectable for tuning only.
     const bool use_big = force == 2 && big_tiles >= 1 && !generic;
     if (use_big) return launch_conv<256, 128, 2, 2, 16>(p, generic, s);
+    if (force == 3 && !generic) return launch_conv<128, 128, 2, 2, 16>(p, generic, s);  // 41 KB LDS: 3 workgroups/CU
     return launch_conv<128, 128, 2, 2, 32>(p, generic, s);
 }
