@@ -121,77 +121,86 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParamsH p) {
 
     u32x4 ra[PA];        // 4 fp32 activations per slot (raw bits)
     u32x4 rb[NPL][PB];   // 8 fp16 weights per slot per plane
-    int t_c0 = 0, t_ky = 0, t_kx = 0;
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
+    // ---- staging in pieces (see conv.hip): PA activation pieces + NPL*PB weight pieces per k tile, issued
+    // between the MFMAs of the main loop. Past the end of K the offsets are out of range (zeros, no traffic).
+    int t_c0 = 0, t_ky = 0, t_kx = 0, t_k0 = 0;
+    int cur_tap_off = 0, cur_ky = 0, cur_kx = 0, cur_k0 = 0;
+    bool cur_kvalid = true;
+    auto begin_load = [&]() {
+        cur_k0 = t_k0;
+        cur_kvalid = t_k0 < p.K;
         if constexpr (!GENERIC) {
-            const int ky = t_ky, kx = t_kx;
-            const int tap_off = (ky * p.W + kx) * p.Cin + t_c0 + kq * 4;
-#pragma unroll
-            for (int i = 0; i < PA; ++i) {
-                const bool ok = static_cast<unsigned>(a_iy[i] + ky) < static_cast<unsigned>(p.H) &&
-                                static_cast<unsigned>(a_ix[i] + kx) < static_cast<unsigned>(p.W);
-                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(
-                    x_rsrc, static_cast<int>(ok ? static_cast<unsigned>(a_off[i] + tap_off) * 4u : OOB), 0, 0);
-            }
+            cur_ky = t_ky;
+            cur_kx = t_kx;
+            cur_tap_off = (t_ky * p.W + t_kx) * p.Cin + t_c0 + kq * 4;
             t_c0 += BK;
             if (t_c0 >= p.Cin) {
                 t_c0 = 0;
                 if (++t_kx == p.KW) { t_kx = 0; ++t_ky; }
             }
-        } else {
-            const int kk = k0 + kq * 4;
-            const bool kin = kk < p.K;
-            const int tap = kk / p.Cin, c = kk - tap * p.Cin;
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
-            const int tap_off = (ky * p.W + kx) * p.Cin + c;
-#pragma unroll
-            for (int i = 0; i < PA; ++i) {
+        }
+        t_k0 += BK;
+    };
+    constexpr int NPB = NPL * PB, NP = PA + NPB;
+    auto load_piece = [&](int pc) {
+        if (pc < PA) {
+            const int i = pc;
+            unsigned off;
+            if constexpr (!GENERIC) {
+                const bool ok = cur_kvalid &&
+                                static_cast<unsigned>(a_iy[i] + cur_ky) < static_cast<unsigned>(p.H) &&
+                                static_cast<unsigned>(a_ix[i] + cur_kx) < static_cast<unsigned>(p.W);
+                off = ok ? static_cast<unsigned>(a_off[i] + cur_tap_off) * 4u : OOB;
+            } else {
+                const int kk = cur_k0 + kq * 4;
+                const bool kin = kk < p.K;
+                const int tap = kk / p.Cin, c = kk - tap * p.Cin;
+                const int ky = tap / p.KW, kx = tap - ky * p.KW;
+                const int tap_off = (ky * p.W + kx) * p.Cin + c;
                 const bool ok = kin &&
                                 static_cast<unsigned>(a_iy[i] + ky) < static_cast<unsigned>(p.H) &&
                                 static_cast<unsigned>(a_ix[i] + kx) < static_cast<unsigned>(p.W);
-                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(
-                    x_rsrc, static_cast<int>(ok ? static_cast<unsigned>(a_off[i] + tap_off) * 4u : OOB), 0, 0);
+                off = ok ? static_cast<unsigned>(a_off[i] + tap_off) * 4u : OOB;
             }
-        }
-        const bool kin_b = (k0 + bc * 8) < p.K;  // K % 8 == 0
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const unsigned off = (b_ok[i] && kin_b) ? static_cast<unsigned>(b_off[i] + k0) * 2u : OOB;
-            rb[0][i] = __builtin_amdgcn_raw_buffer_load_b128(wh_rsrc, static_cast<int>(off), 0, 0);
-            if constexpr (PRODUCTS == 3)
-                rb[1][i] = __builtin_amdgcn_raw_buffer_load_b128(wl_rsrc, static_cast<int>(off), 0, 0);
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(off), 0, 0);
+        } else {
+            const int q = pc - PA, pl = q / PB, i = q % PB;
+            const bool ok = b_ok[i] && cur_kvalid && (cur_k0 + bc * 8 < p.K);
+            const unsigned off = ok ? static_cast<unsigned>(b_off[i] + cur_k0) * 2u : OOB;
+            rb[pl][i] = __builtin_amdgcn_raw_buffer_load_b128(pl == 0 ? wh_rsrc : wl_rsrc, static_cast<int>(off), 0, 0);
         }
     };
     // swizzled byte offset of 16-byte chunk c of row r inside a plane
     auto chunk_off = [](int r, int c) { return r * ROW_BYTES + ((c ^ ((r >> 2) & 3)) << 4); };
-    auto store_tile = [&](int buf) {
-        unsigned char* a = As + buf * A_BUF;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const int r = ar0 + 32 * i;
-            const float v0 = __uint_as_float(ra[i].x), v1 = __uint_as_float(ra[i].y);
-            const float v2 = __uint_as_float(ra[i].z), v3 = __uint_as_float(ra[i].w);
-            const _Float16 h0 = static_cast<_Float16>(v0), h1 = static_cast<_Float16>(v1);
-            const _Float16 h2 = static_cast<_Float16>(v2), h3 = static_cast<_Float16>(v3);
-            const int off = chunk_off(r, kq >> 1) + (kq & 1) * 8;
-            u32x2 hi = {pack2(h0, h1), pack2(h2, h3)};
-            *reinterpret_cast<u32x2*>(a + off) = hi;
+    auto store_piece = [&](int pc, int buf) {
+        if (pc < PA) {
+            const int i = pc, r = ar0 + 32 * i;
+            unsigned char* a = As + buf * A_BUF + chunk_off(r, kq >> 1) + (kq & 1) * 8;
             if constexpr (PRODUCTS == 3) {
-                const _Float16 l0 = static_cast<_Float16>(v0 - static_cast<float>(h0));
-                const _Float16 l1 = static_cast<_Float16>(v1 - static_cast<float>(h1));
-                const _Float16 l2 = static_cast<_Float16>(v2 - static_cast<float>(h2));
-                const _Float16 l3 = static_cast<_Float16>(v3 - static_cast<float>(h3));
-                u32x2 lo = {pack2(l0, l1), pack2(l2, l3)};
-                *reinterpret_cast<u32x2*>(a + A_PLANE + off) = lo;
+                // hi = the top 11 significand bits (a mask: exactly an fp16 value), lo = fp16(v - hi):
+                // 3 VALU per element instead of convert / convert back / subtract / convert
+                const unsigned b0 = ra[i].x & 0xFFFFE000u, b1 = ra[i].y & 0xFFFFE000u;
+                const unsigned b2 = ra[i].z & 0xFFFFE000u, b3 = ra[i].w & 0xFFFFE000u;
+                const float h0 = __uint_as_float(b0), h1 = __uint_as_float(b1);
+                const float h2 = __uint_as_float(b2), h3 = __uint_as_float(b3);
+                const float l0 = __uint_as_float(ra[i].x) - h0, l1 = __uint_as_float(ra[i].y) - h1;
+                const float l2 = __uint_as_float(ra[i].z) - h2, l3 = __uint_as_float(ra[i].w) - h3;
+                u32x2 hi = {pack2(static_cast<_Float16>(h0), static_cast<_Float16>(h1)),
+                            pack2(static_cast<_Float16>(h2), static_cast<_Float16>(h3))};
+                u32x2 lo = {pack2(static_cast<_Float16>(l0), static_cast<_Float16>(l1)),
+                            pack2(static_cast<_Float16>(l2), static_cast<_Float16>(l3))};
+                *reinterpret_cast<u32x2*>(a) = hi;
+                *reinterpret_cast<u32x2*>(a + A_PLANE) = lo;
+            } else {
+                u32x2 hi = {pack2(static_cast<_Float16>(__uint_as_float(ra[i].x)),
+                                  static_cast<_Float16>(__uint_as_float(ra[i].y))),
+                            pack2(static_cast<_Float16>(__uint_as_float(ra[i].z)),
+                                  static_cast<_Float16>(__uint_as_float(ra[i].w)))};
+                *reinterpret_cast<u32x2*>(a) = hi;
             }
-        }
-        unsigned char* b = Bs + buf * B_BUF;
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int off = chunk_off(br0 + 64 * i, bc);
-            *reinterpret_cast<u32x4*>(b + off) = rb[0][i];
-            if constexpr (PRODUCTS == 3) *reinterpret_cast<u32x4*>(b + B_PLANE + off) = rb[1][i];
+        } else {
+            const int q = pc - PA, pl = q / PB, i = q % PB;
+            *reinterpret_cast<u32x4*>(Bs + buf * B_BUF + pl * B_PLANE + chunk_off(br0 + 64 * i, bc)) = rb[pl][i];
         }
     };
 
@@ -207,48 +216,72 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParamsH p) {
     const int sw = (ln >> 2) & 3;
     const unsigned char* Aw = As + (wm * WTM + ln) * ROW_BYTES;
     const unsigned char* Bw = Bs + (wn * WTN + ln) * ROW_BYTES;
-    f16x8 fa[NPL][TM], fb[NPL][TN];
-    auto read_frags = [&](int buf, int ks) {
+    f16x8 fa[2][NPL][TM], fb[2][NPL][TN];
+    auto read_frags = [&](int slot, int buf, int ks) {
         const int co = ((ks * 2 + lh) ^ sw) << 4;
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                fa[pl][i] = *reinterpret_cast<const f16x8*>(Aw + buf * A_BUF + pl * A_PLANE +
-                                                            i * 32 * ROW_BYTES + co);
+                fa[slot][pl][i] = *reinterpret_cast<const f16x8*>(Aw + buf * A_BUF + pl * A_PLANE +
+                                                                  i * 32 * ROW_BYTES + co);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
-                fb[pl][i] = *reinterpret_cast<const f16x8*>(Bw + buf * B_BUF + pl * B_PLANE +
-                                                            i * 32 * ROW_BYTES + co);
-        }
-    };
-    auto mfma_step = [&]() {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn) {
-                if constexpr (PRODUCTS == 3) {  // small terms first
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][i], fb[0][jn], acc[i][jn], 0, 0, 0);
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[1][jn], acc[i][jn], 0, 0, 0);
-                }
-                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][i], fb[0][jn], acc[i][jn], 0, 0, 0);
-            }
+                fb[slot][pl][i] = *reinterpret_cast<const f16x8*>(Bw + buf * B_BUF + pl * B_PLANE +
+                                                                  i * 32 * ROW_BYTES + co);
         }
     };
 
+    // ---- main loop: two 16-deep steps per k tile, order pinned (see conv.hip) -------------------------
+    //   step 0: prefetch the fragments of step 1; MFMAs of step 0 with the LDS-write pieces of k tile kt+1;
+    //   step 1: barrier; prefetch step 0 of k tile kt+1; MFMAs of step 1 with the load pieces of k tile kt+2.
     const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    constexpr int NM = PRODUCTS * TM * TN;  // MFMAs per step
+    begin_load();
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) store_piece(pc, 0);
     __syncthreads();
+    begin_load();
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc);
+    read_frags(0, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        read_frags(buf, 0);
-        mfma_step();
-        read_frags(buf, 1);
-        mfma_step();
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 0) {
+                read_frags(1, buf, 1);
+            } else {
+                __syncthreads();
+                read_frags(0, buf ^ 1, 0);
+                begin_load();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            int m = 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+#pragma unroll
+                    for (int pr = 0; pr < PRODUCTS; ++pr) {
+                        // small terms first: (lo,hi), (hi,lo), then (hi,hi)
+                        const int pa = (PRODUCTS == 3 && pr == 0) ? 1 : 0;
+                        const int pb = (PRODUCTS == 3 && pr == 1) ? 1 : 0;
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][pa][i], fb[ks][pb][jn],
+                                                                            acc[i][jn], 0, 0, 0);
+#pragma unroll
+                        for (int pc = m * NP / NM; pc < (m + 1) * NP / NM; ++pc) {
+                            if (ks == 0) store_piece(pc, buf ^ 1);
+                            else load_piece(pc);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        ++m;
+                    }
+                }
+            }
+        }
     }
 
     // ---- epilogue (identical to conv.hip): affine + residual + ReLU through buffer descriptors ----------
