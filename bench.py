@@ -256,7 +256,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "alt_precision": alt,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -20,7 +20,9 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # under torchrun (RANK set) the group is created even at world size 1, so the RCCL path can be exercised
+    # on a single GPU (MRCNN_FORCE_COLLECTIVE=1 makes the helpers below issue the collectives there too)
+    if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -42,7 +44,7 @@ def shard_range(global_batch: int, rank: int, world: int) -> tuple[int, int]:
 def all_gather_detections(packed: torch.Tensor, counts: torch.Tensor):
     """packed [B_local, D, 6] fp32, counts [B_local] int32 → ([world*B_local, D, 6], [world*B_local]),
     rank-major (== global image order under shard_range with equal shards). Identity at world 1."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return packed, counts
     world = dist.get_world_size()
     packed = packed.contiguous()
@@ -54,13 +56,19 @@ def all_gather_detections(packed: torch.Tensor, counts: torch.Tensor):
     return out_p, out_c
 
 
+def _collectives_on() -> bool:
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("MRCNN_FORCE_COLLECTIVE") == "1"
+
+
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         dist.barrier()
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
