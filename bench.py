@@ -169,9 +169,17 @@ def main():
             net.predict(images, windows, with_masks=True)
         torch.cuda.synchronize()
         prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
-        flops = sum(f for _, _, f, _ in prof)
+        ms = sum(r[0].elapsed_time(r[1]) for r in prof)
+        flops = sum(r[2] for r in prof)
+        algo_bytes = sum(r[4] for r in prof) / args.roofline_steps
         achieved = flops / (ms * 1e-3) / 1e12
+        # HBM traffic of the conv launches of one step from the committed rocprofv3 PMC passes (separate runs of
+        # this same command, FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied by profiles/summarize_pmc.py)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic.json")
+        if args.precision == "f32" and args.batch == 8 and args.size == 1024 and os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_step")
         if args.dump_conv:
             per = len(prof) // args.roofline_steps
             rows = []
@@ -187,7 +195,10 @@ def main():
         roofline = {"bound": "mfma", "kernel": ("conv_igemm_f32" if args.precision == "f32" else "conv_igemm_f16")
                     + " (all conv/GEMM launches of one step)",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "traffic_note": "HBM bytes of all conv launches of one step (rocprofv3 --pmc, committed under "
+                                    "profiles/); algorithmic bytes (each tensor once) alongside",
+                    "algorithmic_bytes_per_step": int(algo_bytes),
                     "launches_per_step": len(prof) // args.roofline_steps,
                     "conv_gflop_per_image": round(flops / args.roofline_steps / args.batch / 1e9, 1),
                     "conv_ms_per_step": round(ms / args.roofline_steps, 3)}
@@ -221,8 +232,8 @@ def main():
                 net_alt.predict(images, windows, with_masks=True)
             torch.cuda.synchronize()
             prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in prof)
-            fl = sum(f for _, _, f, _ in prof)
+            ms = sum(r[0].elapsed_time(r[1]) for r in prof)
+            fl = sum(r[2] for r in prof)
             alt["conv_algorithmic_tflops"] = round(fl / (ms * 1e-3) / 1e12, 1)
             alt["conv_ms_per_step"] = round(ms / args.roofline_steps, 3)
         del net_alt

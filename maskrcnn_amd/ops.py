@@ -190,7 +190,8 @@ __all__ = ["nms_batched", "crop", "roi_align_pyramid", "MaskrcnnHipError"]
 # --------------------------------------------------------------------------------------------------
 # conv + BN + ReLU (+ residual), channels-last
 # --------------------------------------------------------------------------------------------------
-# When set to a list, every conv launch appends (start_event, end_event, algorithmic_flops, (M, N, K)) —
+# When set to a list, every conv launch appends (start_event, end_event, algorithmic_flops, (M, N, K),
+# algorithmic_bytes = each operand/result tensor once) —
 # HIP events recorded on the launch stream; used by bench.py's roofline pass, never in the timed region.
 CONV_PROFILE: list | None = None
 
@@ -235,7 +236,8 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
     if prof is not None:
         e1.record()
         m, k = b * oh * ow, kh * kw * (algo_cin or cin)  # algorithmic: 2*MACs of the un-padded conv
-        prof.append((e0, e1, 2.0 * m * k * cout, (m, cout, k)))
+        nbytes = 4 * (x.numel() + w.numel() + out.numel() + (residual.numel() if residual is not None else 0))
+        prof.append((e0, e1, 2.0 * m * k * cout, (m, cout, k), nbytes))
     return out
 
 
@@ -276,7 +278,9 @@ def conv_bn_act_f16mfma(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor 
     if prof is not None:
         e1.record()
         m, k = b * oh * ow, kh * kw * (algo_cin or cin)
-        prof.append((e0, e1, 2.0 * m * k * cout, (m, cout, k)))
+        nbytes = 4 * (x.numel() + out.numel() + (residual.numel() if residual is not None else 0)) + \
+            2 * w_hi.numel() * (2 if products == 3 else 1)
+        prof.append((e0, e1, 2.0 * m * k * cout, (m, cout, k), nbytes))
     return out
 
 

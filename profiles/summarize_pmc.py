@@ -10,8 +10,8 @@ import sys
 def step_sum(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     conv = [r for r in rows if "conv_igemm_f32" in r["Kernel_Name"]]
-    # a batch-8 step starts at the stem launch: the GENERIC (...true>) instantiation with the largest grid
-    stems = [i for i, r in enumerate(conv) if "true>" in r["Kernel_Name"]]
+    # a batch-8 step starts at the stem launch: the GENERIC (<..., true, RES>) instantiation with the largest grid
+    stems = [i for i, r in enumerate(conv) if ", true," in r["Kernel_Name"]]
     big = max(int(conv[i]["Grid_Size"]) for i in stems)
     starts = [i for i in stems if int(conv[i]["Grid_Size"]) == big]
     i0 = starts[-1]
