@@ -166,6 +166,23 @@ int mrcnn_maxpool_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_
                            int32_t kernel, int32_t stride, int32_t pad_top, int32_t pad_left,
                            int32_t pad_bottom, int32_t pad_right, float* y, mrcnn_stream_t stream);
 
+/* RPN glue, two launches.
+ * mrcnn_rpn_scores_deltas_f32 — replaces the per-level permute/view/softmax/cat of RPN.forward + rpn_detect
+ *   (model.py:627-641,1294-1304): heads[l] = fused head output of level l, NHWC [batch][H_l][W_l][18]
+ *   (channels 0-5: (bg,fg) logits of the 3 anchor ratios, 6-17: their 4 deltas); level_hw[l] = H_l*W_l.
+ *   scores [batch][A] = softmax(bg,fg)[1], deltas [batch][A][4], A = 3*sum(level_hw), anchor index
+ *   = first(l) + (y*W_l + x)*3 + ratio — the reference's order (utils.py:154-160).
+ * mrcnn_proposal_decode_f32 — replaces the gather + boxes_refine + boxes_clamp_ of rpn_refine
+ *   (model.py:1341-1358, data.py:124-148,86-92): for the top-k anchor indices `order` [batch][k] (int64) and
+ *   their scores, dets [batch][k][5] = (clip(refine(anchor, delta*std_dev), [0,H]x[0,W]), score), in the
+ *   reference's fp32 op order. */
+int mrcnn_rpn_scores_deltas_f32(const float* const heads[5], const int32_t level_hw[5], int32_t batch,
+                                float* scores, float* deltas, mrcnn_stream_t stream);
+int mrcnn_proposal_decode_f32(const float* anchors, const float* deltas, const int64_t* order,
+                              const float* top_scores, int32_t batch, int32_t num_anchors, int32_t k,
+                              const float std_dev[4], float image_height, float image_width, float* dets,
+                              mrcnn_stream_t stream);
+
 /* Layout conversions at the boundary (reference tensors are NCHW, model.py:1109). */
 int mrcnn_nchw_to_nhwc_f32(const float* x, int32_t batch, int32_t channels, int32_t height,
                            int32_t width, int32_t channels_padded, float* y, mrcnn_stream_t stream);

@@ -39,6 +39,10 @@ _SIGS = {
                                                         c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mrcnn_maxpool_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                                 c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mrcnn_rpn_scores_deltas_f32": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), c_i32, c_vp,
+                                                     c_vp, c_vp]),
+    "mrcnn_proposal_decode_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                                   ctypes.POINTER(c_f32), c_f32, c_f32, c_vp, c_vp]),
     "mrcnn_nchw_to_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mrcnn_nhwc_to_nchw_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
 }

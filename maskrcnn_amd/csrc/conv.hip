@@ -123,9 +123,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
     int t_c0 = 0, t_ky = 0, t_kx = 0, t_k0 = 0;  // (tap, channel, k) of the NEXT k tile to load — wave-uniform
     int cur_tap_off = 0, cur_ky = 0, cur_kx = 0, cur_k0 = 0;
     bool cur_kvalid = true;
+    // GENERIC only: per-thread (channel, ky, kx) of the slot k = k0 + 4*kq, no division in the loop
+    int n_c = 0, n_ky = 0, n_kx = 0;      // state of the NEXT k tile
+    int g_ky = 0, g_kx = 0, g_tap_off = 0;  // state of the k tile being loaded
+    bool g_kin = true;
+    if constexpr (GENERIC) {
+        const int tap = (kq * 4) / p.Cin;
+        n_c = kq * 4 - tap * p.Cin;
+        n_ky = tap / p.KW;
+        n_kx = tap - n_ky * p.KW;
+    }
     auto begin_load = [&]() {  // scalar bookkeeping for the k tile about to be loaded
         cur_k0 = t_k0;
         cur_kvalid = t_k0 < p.K;
+        if constexpr (GENERIC) {
+            g_ky = n_ky;
+            g_kx = n_kx;
+            g_tap_off = (n_ky * p.W + n_kx) * p.Cin + n_c;
+            g_kin = (t_k0 + kq * 4) < p.K;
+            n_c += BK;
+            while (n_c >= p.Cin) {  // at most BK / Cin + 1 rounds
+                n_c -= p.Cin;
+                if (++n_kx == p.KW) { n_kx = 0; ++n_ky; }
+            }
+        }
         if constexpr (!GENERIC) {
             cur_ky = t_ky;
             cur_kx = t_kx;
@@ -146,16 +167,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
                                 static_cast<unsigned>(a_iy[i] + cur_ky) < static_cast<unsigned>(p.H) &&
                                 static_cast<unsigned>(a_ix[i] + cur_kx) < static_cast<unsigned>(p.W);
                 ra[i] = bload(x_rsrc, ok ? static_cast<unsigned>(a_off[i] + cur_tap_off) * 4u : OOB);
-            } else {
-                const int kk = cur_k0 + kq * 4;
-                const bool kin = kk < p.K;
-                const int tap = kk / p.Cin, c = kk - tap * p.Cin;
-                const int ky = tap / p.KW, kx = tap - ky * p.KW;
-                const int tap_off = (ky * p.W + kx) * p.Cin + c;
-                const bool ok = kin &&
-                                static_cast<unsigned>(a_iy[i] + ky) < static_cast<unsigned>(p.H) &&
-                                static_cast<unsigned>(a_ix[i] + kx) < static_cast<unsigned>(p.W);
-                ra[i] = bload(x_rsrc, ok ? static_cast<unsigned>(a_off[i] + tap_off) * 4u : OOB);
+            } else {  // this thread's slot has its own (tap, channel), advanced incrementally in begin_load
+                const bool ok = g_kin &&
+                                static_cast<unsigned>(a_iy[i] + g_ky) < static_cast<unsigned>(p.H) &&
+                                static_cast<unsigned>(a_ix[i] + g_kx) < static_cast<unsigned>(p.W);
+                ra[i] = bload(x_rsrc, ok ? static_cast<unsigned>(a_off[i] + g_tap_off) * 4u : OOB);
             }
         } else {
             const int i = pc - PA;
@@ -322,19 +338,20 @@ int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
     const int per_xcd = (p.tiles_m + 7) / 8;
     const long long grid = 8LL * per_xcd * p.tiles_n;
     if (grid > 0x7fffffffLL) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: grid too large");
-    static const size_t lds_pad = getenv("MRCNN_CONV_LDS_PAD") ? atoi(getenv("MRCNN_CONV_LDS_PAD")) : 0;  // tuning aid
-    const size_t lds = conv_lds_bytes<BM, BN, BK>() + lds_pad;
-    auto set_attr = [&](const void* f) -> int {
-        if (lds <= 64 * 1024) return MRCNN_OK;
+    constexpr size_t lds = conv_lds_bytes<BM, BN, BK>();
+    auto set_attr = [&](const void* f, bool& done) -> int {  // once per kernel instantiation
+        if (done || lds <= 64 * 1024) return MRCNN_OK;
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            static_cast<int>(lds));
         if (e != hipSuccess)
             return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        done = true;
         return MRCNN_OK;
     };
     const int res = p.residual ? p.res_div : 0;
+    static bool attr_done[2][3] = {};
     auto go = [&](auto kern) -> int {
-        if (int rc = set_attr(reinterpret_cast<const void*>(kern))) return rc;
+        if (int rc = set_attr(reinterpret_cast<const void*>(kern), attr_done[generic ? 1 : 0][res])) return rc;
         hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
         return MRCNN_OK;
     };

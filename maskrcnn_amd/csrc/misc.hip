@@ -127,3 +127,109 @@ extern "C" int mrcnn_nhwc_to_nchw_f32(const float* x, int32_t batch, int32_t cha
     hipLaunchKernelGGL(nhwc_to_nchw, grid, dim3(256), 0, mrcnn::as_stream(stream), x, channels, HW, y);
     return mrcnn::check_launch("nhwc_to_nchw");
 }
+
+// ------------------------------------------------------------------------------------------------------
+// RPN glue: the per-level permute/view/softmax/cat of rpn_detect (model.py:627-641,
+// 1294-1304) and the gather / delta decode / clip of rpn_refine (model.py:1336-1358, data.py:124-148,86-92)
+// as two launches instead of ~30 elementwise ones.
+// ------------------------------------------------------------------------------------------------------
+namespace {
+
+struct RpnLevels {
+    const float* y[5];   // fused head output per level, NHWC [B][H][W][18]: 0-5 (bg,fg) logits x 3, 6-17 deltas
+    int hw[5];           // H*W per level
+    int first[5];        // first anchor index of the level
+};
+
+// one thread per (image, anchor): fg = softmax(bg, fg)[1] as exp(x - max) / sum (the formula torch uses)
+__global__ __launch_bounds__(256) void rpn_scores_deltas(RpnLevels lv, int B, int A,
+                                                         float* __restrict__ scores,
+                                                         float* __restrict__ deltas) {
+    const int64_t total = static_cast<int64_t>(B) * A;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int b = static_cast<int>(e / A), a = static_cast<int>(e - static_cast<int64_t>(b) * A);
+        int l = 0;
+#pragma unroll
+        for (int i = 1; i < 5; ++i) l += (a >= lv.first[i]) ? 1 : 0;
+        const int local = a - lv.first[l];
+        const int pix = local / 3, r = local - pix * 3;
+        const float* p = lv.y[l] + (static_cast<int64_t>(b) * lv.hw[l] + pix) * 18;
+        const float l0 = p[2 * r], l1 = p[2 * r + 1];
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        scores[e] = e1 / (e0 + e1);
+        float4 d = make_float4(p[6 + 4 * r], p[7 + 4 * r], p[8 + 4 * r], p[9 + 4 * r]);
+        *reinterpret_cast<float4*>(deltas + e * 4) = d;
+    }
+}
+
+// one thread per (image, top-k slot): boxes_refine(anchor, delta*std) then clamp, data.py op order
+__global__ __launch_bounds__(256) void proposal_decode(const float* __restrict__ anchors,
+                                                       const float* __restrict__ deltas,
+                                                       const int64_t* __restrict__ order,
+                                                       const float* __restrict__ top_scores, int B, int A,
+                                                       int K, float s0, float s1, float s2, float s3,
+                                                       float img_h, float img_w, float* __restrict__ dets) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * K) return;
+    const int b = e / K;
+    const int64_t idx = order[e];
+    const float4 an = *reinterpret_cast<const float4*>(anchors + idx * 4);
+    const float4 dl = *reinterpret_cast<const float4*>(deltas + (static_cast<int64_t>(b) * A + idx) * 4);
+    const float dy = dl.x * s0, dx = dl.y * s1, dh = dl.z * s2, dw = dl.w * s3;  // boxes_scale (:1341)
+    float height = an.z - an.x;
+    float width = an.w - an.y;
+    float cy = an.x + 0.5f * height;
+    float cx = an.y + 0.5f * width;
+    cy = cy + dy * height;
+    cx = cx + dx * width;
+    height = height * expf(dh);
+    width = width * expf(dw);
+    float y1 = cy - 0.5f * height;
+    float x1 = cx - 0.5f * width;
+    float y2 = y1 + height;
+    float x2 = x1 + width;
+    y1 = fminf(fmaxf(y1, 0.f), img_h);
+    x1 = fminf(fmaxf(x1, 0.f), img_w);
+    y2 = fminf(fmaxf(y2, 0.f), img_h);
+    x2 = fminf(fmaxf(x2, 0.f), img_w);
+    float* o = dets + static_cast<int64_t>(e) * 5;
+    o[0] = y1; o[1] = x1; o[2] = y2; o[3] = x2; o[4] = top_scores[e];
+}
+
+}  // namespace
+
+extern "C" int mrcnn_rpn_scores_deltas_f32(const float* const heads[5], const int32_t level_hw[5],
+                                           int32_t batch, float* scores, float* deltas,
+                                           mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(heads && level_hw && scores && deltas && batch >= 1, "rpn_scores_deltas: bad arguments");
+    RpnLevels lv;
+    int a = 0;
+    for (int l = 0; l < 5; ++l) {
+        MRCNN_REQUIRE(heads[l] && level_hw[l] >= 1, "rpn_scores_deltas: bad level %d", l);
+        lv.y[l] = heads[l];
+        lv.hw[l] = level_hw[l];
+        lv.first[l] = a;
+        a += level_hw[l] * 3;
+    }
+    const int64_t total = static_cast<int64_t>(batch) * a;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(rpn_scores_deltas, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                       mrcnn::as_stream(stream), lv, batch, a, scores, deltas);
+    return mrcnn::check_launch("rpn_scores_deltas");
+}
+
+extern "C" int mrcnn_proposal_decode_f32(const float* anchors, const float* deltas, const int64_t* order,
+                                         const float* top_scores, int32_t batch, int32_t num_anchors,
+                                         int32_t k, const float std_dev[4], float image_height,
+                                         float image_width, float* dets, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(anchors && deltas && order && top_scores && std_dev && dets, "proposal_decode: null pointer");
+    MRCNN_REQUIRE(batch >= 1 && num_anchors >= 1 && k >= 1, "proposal_decode: bad sizes");
+    const int total = batch * k;
+    hipLaunchKernelGGL(proposal_decode, dim3((total + 255) / 256), dim3(256), 0, mrcnn::as_stream(stream),
+                       anchors, deltas, order, top_scores, batch, num_anchors, k, std_dev[0], std_dev[1],
+                       std_dev[2], std_dev[3], image_height, image_width, dets);
+    return mrcnn::check_launch("proposal_decode");
+}

@@ -360,3 +360,40 @@ _LIB.impl("bottleneck_forward", bottleneck_forward, "CUDA")
 _LIB.impl("bottleneck_forward", lambda x, *a: _need_gpu(x), "CPU")
 
 __all__ += ["conv_bn_act", "conv_bn_act_f16mfma", "split_f16", "same_pad", "maxpool", "nchw_to_nhwc", "nhwc_to_nchw", "bottleneck_forward"]
+
+
+def rpn_scores_deltas(heads):
+    """heads: 5 contiguous fp32 NHWC tensors [B,H_l,W_l,18] (fused RPN head outputs, P2..P6) →
+    (fg scores [B,A], deltas [B,A,4]) in the reference's anchor order. One launch."""
+    assert len(heads) == 5
+    _need_gpu(*heads)
+    b = heads[0].size(0)
+    for h in heads:
+        assert h.is_contiguous() and h.dtype == torch.float32 and h.size(0) == b and h.size(3) == 18
+    hw = [h.size(1) * h.size(2) for h in heads]
+    a = 3 * sum(hw)
+    scores = torch.empty(b, a, dtype=torch.float32, device=heads[0].device)
+    deltas = torch.empty(b, a, 4, dtype=torch.float32, device=heads[0].device)
+    ptrs = (c_vp * 5)(*[h.data_ptr() for h in heads])
+    check(lib.mrcnn_rpn_scores_deltas_f32(ptrs, (c_i32 * 5)(*hw), b, scores.data_ptr(), deltas.data_ptr(),
+                                          _stream()))
+    return scores, deltas
+
+
+def proposal_decode(anchors, deltas, order, top_scores, std_dev, image_height, image_width):
+    """anchors [A,4], deltas [B,A,4], order int64 [B,K], top_scores [B,K] → dets [B,K,5]: refined (data.py:124),
+    clipped (data.py:86) boxes + score. One launch."""
+    _need_gpu(anchors, deltas, order, top_scores)
+    assert anchors.is_contiguous() and deltas.is_contiguous() and order.is_contiguous() and top_scores.is_contiguous()
+    assert order.dtype == torch.int64 and deltas.dtype == torch.float32
+    b, k = order.shape
+    dets = torch.empty(b, k, 5, dtype=torch.float32, device=deltas.device)
+    from ._lib import c_f32
+    check(lib.mrcnn_proposal_decode_f32(anchors.data_ptr(), deltas.data_ptr(), order.data_ptr(),
+                                        top_scores.data_ptr(), b, anchors.size(0), k,
+                                        (c_f32 * 4)(*[float(v) for v in std_dev]), float(image_height),
+                                        float(image_width), dets.data_ptr(), _stream()))
+    return dets
+
+
+__all__ += ["rpn_scores_deltas", "proposal_decode"]

@@ -79,14 +79,7 @@ class MaskRCNNInference:
     # ---------------------------------------------------------------- stage 1: proposals
     def rpn_heads(self, fms):
         """rpn_detect (model.py:1294-1304) → fg scores [B,A], deltas [B,A,4], A = 261888 at 1024^2."""
-        b = fms[0].size(0)
-        logits, deltas = [], []
-        for p in fms:
-            y = self.rpn(p)                                   # [B,H,W,18]
-            logits.append(y[..., :6].reshape(b, -1, 2))       # NHWC == permute(0,2,3,1) of model.py:627
-            deltas.append(y[..., 6:].reshape(b, -1, 4))
-        logits, deltas = torch.cat(logits, 1), torch.cat(deltas, 1)
-        return torch.softmax(logits, dim=2)[..., 1], deltas
+        return ops.rpn_scores_deltas([self.rpn(p) for p in fms])   # [B,H,W,18] per level → one launch
 
     def proposals(self, scores, deltas):
         """rpn_refine (model.py:1307-1382), batched. → rois [B,P,4] normalised (zero beyond count),
@@ -94,11 +87,10 @@ class MaskRCNNInference:
         c = self.cfg
         k = min(c.pre_nms_limit, self.anchors.size(0))
         top, order = scores.topk(k, dim=1, sorted=True)                  # model.py:1345-1348
-        d = deltas.gather(1, order.unsqueeze(-1).expand(-1, -1, 4)) * self.std   # :1341,1349
-        boxes = boxes_refine(self.anchors[order], d)                     # :1350-1354
-        hi = self.norm.view(1, 1, 4)
-        boxes = torch.minimum(torch.maximum(boxes, torch.zeros_like(boxes)), hi.expand_as(boxes))  # :1358
-        dets = torch.cat([boxes, top.unsqueeze(-1)], dim=2).contiguous()
+        # gather + boxes_scale + boxes_refine + boxes_clamp_ (:1341-1358) in one launch
+        dets = ops.proposal_decode(self.anchors, deltas, order, top, c.rpn_bbox_std_dev, c.image_height,
+                                   c.image_width)
+        boxes = dets[..., :4]
         keep, counts = ops.nms_batched(dets, c.rpn_nms_threshold)        # :1364, score order == index order
         p = min(c.proposal_count, k)
         counts = counts.clamp(max=p)                                     # keep[:proposal_count] :1366

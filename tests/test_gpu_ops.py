@@ -240,3 +240,30 @@ def test_roi_align_pyramid_batched_vs_oracle(dev, oracle):
         assert torch.equal(levels[b * R:(b + 1) * R].cpu()[ok], want_lv[ok])
         want = oracle.roi_align(r[ok], [f[b:b + 1] for f in fms], 7, shape)
         assert torch.equal(got[b * R:(b + 1) * R][ok], want)
+
+
+# ------------------------------------------------------------------------------------ RPN glue kernels
+def test_rpn_scores_deltas_and_proposal_decode(dev, oracle):
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(31)
+    B = 2
+    sizes = [(16, 12), (8, 6), (4, 3), (2, 2), (1, 1)]
+    heads = [torch.randn(B, h, w, 18, generator=g) * 2 for h, w in sizes]
+    scores, deltas = ops.rpn_scores_deltas([t.to(dev) for t in heads])
+    # reference formulation: permute/view/softmax/cat of model.py:627-641,1294-1304 (heads are already NHWC)
+    logits = torch.cat([t[..., :6].reshape(B, -1, 2) for t in heads], 1)
+    want_scores = torch.softmax(logits, dim=2)[..., 1]
+    want_deltas = torch.cat([t[..., 6:].reshape(B, -1, 4) for t in heads], 1)
+    assert torch.equal(deltas.cpu(), want_deltas)
+    assert (scores.cpu() - want_scores).abs().max().item() <= 2e-7
+    A = want_scores.size(1)
+    anchors = torch.rand(A, 4, generator=g) * 200
+    anchors[:, 2:] += anchors[:, :2] + 4
+    top, order = want_scores.topk(50, dim=1)
+    std = [0.1, 0.1, 0.2, 0.2]
+    dets = ops.proposal_decode(anchors.to(dev), deltas, order.to(dev), top.to(dev), std, 256, 320).cpu()
+    for b in range(B):
+        d = oracle.boxes_scale(want_deltas[b][order[b]], std)
+        want = oracle.boxes_clamp(oracle.boxes_refine(anchors[order[b]], d), [0, 0, 256, 320])
+        assert torch.allclose(dets[b, :, :4], want, rtol=1e-6, atol=1e-4)   # expf ulp differences only
+        assert torch.equal(dets[b, :, 4], top[b])
