@@ -94,7 +94,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (configs[2]: 8)")
     ap.add_argument("--arch", default="resnet50")
-    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--size", type=int, default=1024, help="square image side (BASELINE metric: 1024)")
+    ap.add_argument("--height", type=int, default=None, help="non-square images (config 5: 832 x 1344)")
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--proposals", type=int, default=1000)
     ap.add_argument("--cpu-images", type=int, default=2, help="CPU baseline sample size (0 = skip)")
     ap.add_argument("--roofline-steps", type=int, default=2)
@@ -119,14 +121,15 @@ def main():
     from maskrcnn_amd.config import InferenceConfig
     from maskrcnn_amd.pipeline import MaskRCNNInference
 
-    cfg = InferenceConfig(image_height=args.size, image_width=args.size, backbone=args.arch,
+    H, W = args.height or args.size, args.width or args.size
+    cfg = InferenceConfig(image_height=H, image_width=W, backbone=args.arch,
                           pre_nms_limit=args.proposals, proposal_count=args.proposals)
     sd = modules.synthetic_state_dict(args.arch, seed=0, bn_seed=1)
     g = torch.Generator().manual_seed(1000 + rank)  # each rank owns its own shard of the global batch
     mean = torch.tensor(cfg.mean_pixel)
-    images = (torch.randint(0, 256, (args.batch, args.size, args.size, 3), generator=g).float() - mean)
+    images = (torch.randint(0, 256, (args.batch, H, W, 3), generator=g).float() - mean)
     images = images.permute(0, 3, 1, 2).contiguous().to(dev)
-    windows = torch.tensor([[0.0, 0.0, args.size, args.size]] * args.batch, device=dev)
+    windows = torch.tensor([[0.0, 0.0, float(H), float(W)]] * args.batch, device=dev)
 
     make_net = lambda s, prec=args.precision: MaskRCNNInference(s, cfg, dev, precision=prec)
     net = calibrate_heads_(sd, make_net, images[:1], windows[:1])
@@ -177,7 +180,8 @@ def main():
         # this same command, FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied by profiles/summarize_pmc.py)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic.json")
-        if args.precision == "f32" and args.batch == 8 and args.size == 1024 and os.path.exists(tpath):
+        if (args.precision == "f32" and args.batch == 8 and (H, W) == (1024, 1024) and args.arch == "resnet50"
+                and os.path.exists(tpath)):
             with open(tpath) as fh:
                 traffic = json.load(fh).get("hbm_bytes_per_step")
         if args.dump_conv:
@@ -247,7 +251,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "images/sec at 1024x1024, 1000 proposals/img (Mask R-CNN inference hot path)",
+            "metric": f"images/sec at {H}x{W}, {args.proposals} proposals/img (Mask R-CNN inference hot path)",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -256,7 +260,7 @@ def main():
             "data": "synthetic (seeded uint8-range images minus MEAN_PIXEL; reference-init random weights, "
                     "randomised BN stats, head layers rescaled so proposals are non-degenerate)",
             "config": {"workload": f"configs[2] per GPU: full {args.arch}-FPN + RoIAlign + NMS inference, "
-                                   f"batch={args.batch} synthetic {args.size}x{args.size}, "
+                                   f"batch={args.batch} synthetic {H}x{W}, "
                                    f"{args.proposals} proposals/img, {cfg.detection_max_instances} mask slots/img",
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}: image shards, replicated weights, one RCCL all-gather of "
