@@ -30,9 +30,62 @@ def timeit(fn, iters=50, warm=5):
     return e0.elapsed_time(e1) / iters * 1e3  # µs
 
 
+def cpu_reference(g):
+    """BASELINE config 2 'vs c++ext CPU': the reference's own compiled CPU extension (oracle/_ref, test
+    infrastructure) on this host, same inputs. Skipped when oracle/_ref is absent."""
+    import contextlib
+    import time
+    try:
+        from oracle import build_ref
+        ref = build_ref.load()
+    except Exception:
+        ref = None
+    if ref is None:
+        return
+
+    @contextlib.contextmanager
+    def mute():  # crop_cpu.cpp:163 printf()s on every call
+        import ctypes
+        sys.stdout.flush()
+        saved, devnull = os.dup(1), os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 1)
+        try:
+            yield
+        finally:
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(saved, 1)
+            os.close(devnull)
+            os.close(saved)
+
+    fm = torch.randn(1, 256, 256, 256, generator=g)
+    c = torch.rand(256, 2, generator=g)
+    hw = torch.rand(256, 2, generator=g) * 0.10 + 0.02
+    boxes = torch.cat([c - hw / 2, c + hw / 2], 1).clamp(0, 1)
+    ind = torch.zeros(256, dtype=torch.int32)
+    crops = torch.zeros(256, 256, 14, 14)
+    with mute():
+        ref.crop_forward(fm, boxes, ind, 0.0, 14, 14, crops)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ref.crop_forward(fm, boxes, ind, 0.0, 14, 14, crops)
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+    print(json.dumps({"op": "crop_forward_cpu_reference (oracle/_ref, 1 thread)", "level_hw": 256, "rois": 256,
+                      "ms": round(ms, 1)}), flush=True)
+    for n in (500, 1000):
+        cc = torch.rand(n, 2, generator=g) * 1000
+        d = torch.cat([cc, cc + torch.rand(n, 2, generator=g) * 80 + 4, torch.rand(n, 1, generator=g)], 1)
+        ref.nms(d, 0.7)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ref.nms(d, 0.7)
+        print(json.dumps({"op": "nms_cpu_reference (oracle/_ref, 1 thread)", "n": n,
+                          "ms": round((time.perf_counter() - t0) / 5 * 1e3, 2)}), flush=True)
+
+
 def main():
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(1234)
+    cpu_reference(torch.Generator().manual_seed(1234))
     for hl in (256, 128, 64, 32):
         fm = torch.randn(1, 256, hl, hl, generator=g).to(dev)
         c = torch.rand(256, 2, generator=g)
