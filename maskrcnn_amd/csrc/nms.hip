@@ -273,7 +273,8 @@ struct NmsWs {
     float* area;    // [S][Np]
     int* cls;       // [S][Np]
     int* idx;       // [S][Np] input index, -1 for padding
-    u64* mask;      // [S][Np][NB]
+    u64* mask;      // [S][Np][NB]   row-oriented: word cb of row p = later boxes of chunk cb suppressed by p
+    u64* diagcol;   // [S][Np]       column-oriented, diagonal tiles only: earlier boxes of p's own chunk that suppress p
     int np, nb;
 };
 
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsWs ws, float thr) {
     const float ai = ws.area[base + pi0 + lane];
     const int ci = ws.cls[base + pi0 + lane];
     u64 mine = 0;  // lane i ends up holding row i's word
+    u64 col = 0;   // lane j: rows of this tile that suppress column box j
     for (int i = 0; i < 64; ++i) {
         Box bi;
         bi.y1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(bi4.x), i));
@@ -361,8 +363,10 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsWs ws, float thr) {
         const bool hit = jvalid && (pj > pi0 + i) && (cri == cj) && iou_ge(bi, bj, thr);
         const u64 m = __ballot(hit);
         if (lane == i) mine = m;
+        col |= hit ? (1ull << i) : 0ull;
     }
     ws.mask[(base + pi0 + lane) * ws.nb + cb] = mine;
+    if (rb == cb) ws.diagcol[base + pj] = col;
 }
 
 // grid = S, block = 256. LDS: mask rows (when they fit) + keep flags.
@@ -381,33 +385,38 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs ws, int64_t n_max,
     u64* lmask = reinterpret_cast<u64*>(smem);                                  // [np][nb] if MASK_IN_LDS
     unsigned char* keepf = smem + (MASK_IN_LDS ? sizeof(u64) * np * nb : 0);    // [np] by input index
     u64* keptw = reinterpret_cast<u64*>(keepf + np);                            // [nb] survivors per chunk
+    u64* dcol = keptw + nb + 2;                                                 // [np] diagonal column masks
     const int nchunks = (n + 63) >> 6;
     if (MASK_IN_LDS) {
         // only rows < n and only the upper triangle were written by K2; copy whole rows of live chunks
         for (int e = tid; e < nchunks * 64 * nb; e += 256) lmask[e] = gmask[e];
     }
-    for (int i = tid; i < np; i += 256) keepf[i] = 0;
+    for (int i = tid; i < np; i += 256) {
+        keepf[i] = 0;
+        dcol[i] = ws.diagcol[base + i];
+    }
     __syncthreads();
     const u64* mk = MASK_IN_LDS ? lmask : gmask;
     if (wave == 0) {
         u64 remv = 0;  // lane w: removed bits of boxes [64w, 64w+63]
         for (int c = 0; c < nchunks; ++c) {
             const int p = c * 64 + lane;
-            const u64 cm = (lane < 64) ? mk[static_cast<int64_t>(p) * nb + c] : 0;  // diagonal word of row p
-            const u32 cm_lo = static_cast<u32>(cm), cm_hi = static_cast<u32>(cm >> 32);
+            const u64 dc = dcol[p];  // earlier boxes of this chunk that would suppress box p
             const u32 r_lo = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(remv)), c));
             const u32 r_hi = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(remv >> 32)), c));
             const u64 removed = (static_cast<u64>(r_hi) << 32) | r_lo;
             const u64 validm = (n - c * 64 >= 64) ? ~0ull : ((1ull << (n - c * 64)) - 1ull);
-            u64 alive = ~removed & validm;
-            u64 kept = 0, rem = alive;
-            while (rem) {
-                const int i = __builtin_ctzll(rem);
-                kept |= 1ull << i;
-                const u32 m_hi = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(cm_hi), i));
-                const u32 m_lo = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(cm_lo), i));
-                alive &= ~((static_cast<u64>(m_hi) << 32) | m_lo);
-                rem = alive & ~((2ull << i) - 1ull);
+            const u64 alive = ~removed & validm;
+            // Greedy resolution of the chunk as a fixpoint: K[j] = alive[j] && no kept EARLIER box suppresses j.
+            // Starting from K = alive, iteration t fixes (at least) the first t+1 positions, and a fixpoint
+            // satisfies the greedy recurrence, whose solution is unique — typically 2-4 rounds of one AND +
+            // one ballot instead of a 64-step serial walk.
+            const bool me_alive = (alive >> lane) & 1ull;
+            u64 kept = alive;
+            for (int round = 0; round < 65; ++round) {
+                const u64 next = __ballot(me_alive && (dc & kept) == 0ull);
+                if (next == kept) break;
+                kept = next;
             }
             if (lane == 0) keptw[c] = kept;
             // survivors of this chunk remove later boxes: lane w ORs word w of every surviving row
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs ws, int64_t n_max,
     __syncthreads();
     // ascending-index compaction by wave 0 (ballot + popcount), then -1 padding by everyone
     int64_t* keep = keep_out + static_cast<int64_t>(seg) * n_max;
-    int* totalp = reinterpret_cast<int*>(keptw + nb);
+    int* totalp = reinterpret_cast<int*>(keptw + nb);  // one of the two spare words after keptw
     if (wave == 0) {
         int basepos = 0;
         for (int w0 = 0; w0 < n; w0 += 64) {
@@ -493,6 +502,7 @@ size_t ws_layout(int32_t S, int64_t n_max, void* base, NmsWs* ws) {
     const size_t o_box = take(sizeof(float4) * S * np), o_area = take(sizeof(float) * S * np);
     const size_t o_cls = take(sizeof(int) * S * np), o_idx = take(sizeof(int) * S * np);
     const size_t o_mask = take(sizeof(u64) * S * np * nb);
+    const size_t o_dcol = take(sizeof(u64) * S * np);
     if (ws) {
         unsigned char* b = static_cast<unsigned char*>(base);
         ws->box = reinterpret_cast<float4*>(b + o_box);
@@ -500,6 +510,7 @@ size_t ws_layout(int32_t S, int64_t n_max, void* base, NmsWs* ws) {
         ws->cls = reinterpret_cast<int*>(b + o_cls);
         ws->idx = reinterpret_cast<int*>(b + o_idx);
         ws->mask = reinterpret_cast<u64*>(b + o_mask);
+        ws->diagcol = reinterpret_cast<u64*>(b + o_dcol);
         ws->np = np;
         ws->nb = nb;
     }
@@ -548,7 +559,7 @@ extern "C" int mrcnn_nms_batched_f32(const float* dets, int32_t num_segments, in
         hipLaunchKernelGGL(nms_mask_kernel, dim3(ws.nb * (ws.nb + 1) / 2, num_segments), dim3(64), 0, s, ws,
                            threshold);
         if ((rc = mrcnn::check_launch("nms_mask_kernel"))) return rc;
-        const size_t tail = ws.np + sizeof(u64) * ws.nb + 16;
+        const size_t tail = ws.np + sizeof(u64) * (ws.nb + 2) + sizeof(u64) * ws.np;
         const size_t lds_full = sizeof(u64) * ws.np * ws.nb + tail;
         if (lds_full <= 150 * 1024) {
             auto k = nms_scan_kernel<true>;
