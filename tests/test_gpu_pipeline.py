@@ -7,6 +7,8 @@ synthetic weights). Stage by stage, each stage fed with the HIP path's own upstr
   detections         : identical class ids / boxes / scores (scores 1e-6)
   masks              : <= 1e-4 abs
 """
+import math
+
 import pytest
 import torch
 
@@ -224,3 +226,29 @@ def test_step_is_hipgraph_capturable():
     assert torch.equal(captured.boxes, eager.boxes)
     assert torch.equal(captured.scores, eager.scores)
     assert torch.equal(captured.masks, eager.masks)
+
+
+def test_full_size_trunk_and_roialign_one_image(oracle):
+    """BASELINE full size (1024x1024, ResNet-50-FPN, 1000 RoIs), one image: the CPU oracle needs a few seconds.
+    Trunk activations within 1e-4 of the activation range; pyramid RoIAlign of 1000 seeded RoIs on the HIP
+    path's own feature maps bit-exact with the oracle's roi_align on the same maps."""
+    from maskrcnn_amd import ops
+    cfg, sd, net, images, windows, dev = _small_net("f32", 1024, 1024, "resnet50", seed=0)
+    fms = net.backbone(images.to(dev))
+    torch.cuda.synchronize()
+    want = oracle.fpn_forward(images, sd, "resnet50")
+    assert [tuple(f.shape) for f in want] == [(1, 256, 256, 256), (1, 256, 128, 128), (1, 256, 64, 64),
+                                              (1, 256, 32, 32), (1, 256, 16, 16)]   # model.py:165-166
+    for lvl, (w_, g_) in enumerate(zip(want, fms)):
+        err = (g_[0].permute(2, 0, 1).cpu() - w_[0]).abs().max().item()
+        tol = 1e-4 * max(1.0, w_.abs().max().item())
+        assert err <= tol, f"P{lvl + 2}: {err:.3e} > {tol:.3e}"
+    g = torch.Generator().manual_seed(1234)  # SURVEY §8d proposal injection recipe
+    c = torch.rand(1000, 2, generator=g)
+    hw = torch.exp(torch.rand(1000, 2, generator=g) * (math.log(0.6) - math.log(0.02)) + math.log(0.02))
+    rois = torch.cat([c - hw / 2, c + hw / 2], 1).clamp(0, 1)
+    got = ops.roi_align_pyramid(fms[:4], rois.to(dev), 7, 1024.0 * 1024.0, rois_per_image=1000)
+    maps_cpu = [f.permute(0, 3, 1, 2).cpu().contiguous() for f in fms[:4]]
+    ok = (rois[:, 2] > rois[:, 0]) & (rois[:, 3] > rois[:, 1])
+    want_p = oracle.roi_align(rois[ok], maps_cpu, 7, (1024, 1024, 3))
+    assert torch.equal(got.permute(0, 3, 1, 2).cpu()[ok], want_p)
