@@ -183,6 +183,21 @@ int mrcnn_proposal_decode_f32(const float* anchors, const float* deltas, const i
                               const float std_dev[4], float image_height, float image_width, float* dets,
                               mrcnn_stream_t stream);
 
+/* Detection decode — the first half of MaskRCNN.mrn_refine (model.py:1405-1443) for a whole batch in one launch:
+ * softmax + arg-max over classes, class-specific delta gather, boxes_refine(rois, delta*std_dev) (data.py:124-148),
+ * scale to pixels, clip to each image's window, round (half to even), validity = class > 0 and slot <
+ * roi_counts[image] (and score >= min_confidence when min_confidence > 0; config.py:204 sets 0 = no filter).
+ *   logits [batch*P][num_classes] (row stride logit_stride elements), bbox [batch*P][num_classes][4] (row stride
+ *   bbox_stride), rois [batch*P][4] normalised, windows [batch][4] pixels.
+ *   dets [batch*P][5] = (y1,x1,y2,x2,score), class_ids int64 [batch*P] = arg-max class,
+ *   nms_class_ids int32 [batch*P] = class for valid slots, a unique negative value otherwise (so that excluded
+ *   slots neither suppress nor are suppressed in the class-aware NMS that follows). */
+int mrcnn_detection_decode_f32(const float* logits, int64_t logit_stride, const float* bbox, int64_t bbox_stride,
+                               const float* rois, const int32_t* roi_counts, const float* windows, int32_t batch,
+                               int32_t rois_per_image, int32_t num_classes, const float std_dev[4],
+                               float image_height, float image_width, float min_confidence, float* dets,
+                               int32_t* nms_class_ids, int64_t* class_ids, mrcnn_stream_t stream);
+
 /* Layout conversions at the boundary (reference tensors are NCHW, model.py:1109). */
 int mrcnn_nchw_to_nhwc_f32(const float* x, int32_t batch, int32_t channels, int32_t height,
                            int32_t width, int32_t channels_padded, float* y, mrcnn_stream_t stream);

@@ -43,6 +43,9 @@ _SIGS = {
                                                      c_vp, c_vp]),
     "mrcnn_proposal_decode_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
                                                    ctypes.POINTER(c_f32), c_f32, c_f32, c_vp, c_vp]),
+    "mrcnn_detection_decode_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                                    ctypes.POINTER(c_f32), c_f32, c_f32, c_f32, c_vp, c_vp, c_vp,
+                                                    c_vp]),
     "mrcnn_nchw_to_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mrcnn_nhwc_to_nchw_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
 }

@@ -233,3 +233,90 @@ extern "C" int mrcnn_proposal_decode_f32(const float* anchors, const float* delt
                        std_dev[2], std_dev[3], image_height, image_width, dets);
     return mrcnn::check_launch("proposal_decode");
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Detection decode: the first half of MaskRCNN.mrn_refine (model.py:1405-1443) for a whole batch in one
+// launch — softmax + argmax over classes, class-specific delta gather, boxes_refine(rois, delta*std)
+// (data.py:124-148), scale to pixels, clip to the image window, round, and the validity rule
+// (class > 0, inside the image's live RoI slots, optional score threshold).
+// One wavefront per RoI: lanes stride over the classes, wave reductions for max / sum / argmax.
+// ------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void detection_decode(
+    const float* __restrict__ logits, int64_t logit_stride, const float* __restrict__ bbox,
+    int64_t bbox_stride, const float* __restrict__ rois, const int* __restrict__ roi_counts,
+    const float* __restrict__ windows, int B, int P, int C, float s0, float s1, float s2, float s3,
+    float img_h, float img_w, float min_conf, float* __restrict__ dets, int* __restrict__ nms_cls,
+    int64_t* __restrict__ class_ids) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);  // RoI index in [0, B*P)
+    if (r >= B * P) return;
+    const int b = r / P, slot = r - b * P;
+    const float* lg = logits + static_cast<int64_t>(r) * logit_stride;
+    // max and first argmax over classes
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = lg[c];
+        if (v > best) { best = v; besti = c; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(besti, off, 64);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += expf(lg[c] - best);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane != 0) return;
+    const float score = 1.0f / sum;  // exp(0) / sum: the probability of the arg-max class
+    const float* dl = bbox + static_cast<int64_t>(r) * bbox_stride + besti * 4;
+    const float dy = dl[0] * s0, dx = dl[1] * s1, dh = dl[2] * s2, dw = dl[3] * s3;
+    const float* ro = rois + static_cast<int64_t>(r) * 4;
+    float height = ro[2] - ro[0];
+    float width = ro[3] - ro[1];
+    float cy = ro[0] + 0.5f * height;
+    float cx = ro[1] + 0.5f * width;
+    cy = cy + dy * height;
+    cx = cx + dx * width;
+    height = height * expf(dh);
+    width = width * expf(dw);
+    float y1 = cy - 0.5f * height;
+    float x1 = cx - 0.5f * width;
+    float y2 = y1 + height;
+    float x2 = x1 + width;
+    y1 = y1 * img_h; x1 = x1 * img_w; y2 = y2 * img_h; x2 = x2 * img_w;  // boxes_scale (:1426)
+    const float* w = windows + b * 4;
+    y1 = rintf(fminf(fmaxf(y1, w[0]), w[2]));
+    x1 = rintf(fminf(fmaxf(x1, w[1]), w[3]));
+    y2 = rintf(fminf(fmaxf(y2, w[0]), w[2]));
+    x2 = rintf(fminf(fmaxf(x2, w[1]), w[3]));
+    float* o = dets + static_cast<int64_t>(r) * 5;
+    o[0] = y1; o[1] = x1; o[2] = y2; o[3] = x2; o[4] = score;
+    bool valid = besti > 0 && slot < roi_counts[b];
+    if (min_conf > 0.f) valid = valid && score >= min_conf;
+    class_ids[r] = besti;
+    nms_cls[r] = valid ? besti : -(slot + 1);  // excluded slots: unique negative class, never interact in NMS
+}
+
+}  // namespace
+
+extern "C" int mrcnn_detection_decode_f32(const float* logits, int64_t logit_stride, const float* bbox,
+                                          int64_t bbox_stride, const float* rois, const int32_t* roi_counts,
+                                          const float* windows, int32_t batch, int32_t rois_per_image,
+                                          int32_t num_classes, const float std_dev[4], float image_height,
+                                          float image_width, float min_confidence, float* dets,
+                                          int32_t* nms_class_ids, int64_t* class_ids, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(logits && bbox && rois && roi_counts && windows && std_dev && dets && nms_class_ids && class_ids,
+                  "detection_decode: null pointer");
+    MRCNN_REQUIRE(batch >= 1 && rois_per_image >= 1 && num_classes >= 1, "detection_decode: bad sizes");
+    const int total = batch * rois_per_image;
+    hipLaunchKernelGGL(detection_decode, dim3((total + 3) / 4), dim3(256), 0, mrcnn::as_stream(stream), logits,
+                       logit_stride, bbox, bbox_stride, rois, roi_counts, windows, batch, rois_per_image,
+                       num_classes, std_dev[0], std_dev[1], std_dev[2], std_dev[3], image_height, image_width,
+                       min_confidence, dets, nms_class_ids, class_ids);
+    return mrcnn::check_launch("detection_decode");
+}

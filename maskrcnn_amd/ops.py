@@ -397,3 +397,28 @@ def proposal_decode(anchors, deltas, order, top_scores, std_dev, image_height, i
 
 
 __all__ += ["rpn_scores_deltas", "proposal_decode"]
+
+
+def detection_decode(logits, bbox, rois, roi_counts, windows, std_dev, image_height, image_width,
+                     min_confidence: float = 0.0):
+    """First half of mrn_refine (model.py:1405-1443), one launch. logits [B*P,C] (row-strided view allowed),
+    bbox [B*P,C,4] (row-strided view allowed), rois [B,P,4], roi_counts int32 [B], windows [B,4] →
+    (dets [B,P,5], nms_class_ids int32 [B,P], class_ids int64 [B,P])."""
+    _need_gpu(logits, bbox, rois, roi_counts, windows)
+    b, p, _ = rois.shape
+    c = logits.size(1)
+    assert logits.stride(1) == 1 and bbox.stride(2) == 1 and bbox.stride(1) == 4 and rois.is_contiguous()
+    assert roi_counts.dtype == torch.int32 and windows.dtype == torch.float32 and windows.is_contiguous()
+    dets = torch.empty(b, p, 5, dtype=torch.float32, device=rois.device)
+    nms_cls = torch.empty(b, p, dtype=torch.int32, device=rois.device)
+    cls = torch.empty(b, p, dtype=torch.int64, device=rois.device)
+    from ._lib import c_f32
+    check(lib.mrcnn_detection_decode_f32(logits.data_ptr(), logits.stride(0), bbox.data_ptr(), bbox.stride(0),
+                                         rois.data_ptr(), roi_counts.data_ptr(), windows.data_ptr(), b, p, c,
+                                         (c_f32 * 4)(*[float(v) for v in std_dev]), float(image_height),
+                                         float(image_width), float(min_confidence), dets.data_ptr(),
+                                         nms_cls.data_ptr(), cls.data_ptr(), _stream()))
+    return dets, nms_cls, cls
+
+
+__all__ += ["detection_decode"]

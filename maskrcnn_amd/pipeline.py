@@ -106,25 +106,15 @@ class MaskRCNNInference:
         rois [B,P,4]; logits [B*P,C]; bbox [B*P,C,4]; windows [B,4] pixel (y1,x1,y2,x2)."""
         c = self.cfg
         b, p, _ = rois.shape
-        probs = torch.softmax(logits, dim=1)                              # model.py:791
-        class_scores, class_ids = probs.max(dim=1)                        # :1407,1414
-        deltas = bbox.gather(1, class_ids.view(-1, 1, 1).expand(-1, 1, 4)).squeeze(1)   # :1415
-        refined = boxes_refine(rois.reshape(-1, 4), deltas * self.std)    # :1418-1422
-        boxes = (refined * self.norm).view(b, p, 4)                       # :1426
-        w = windows.to(boxes.dtype).view(b, 1, 4)
-        lo = torch.stack([w[..., 0], w[..., 1], w[..., 0], w[..., 1]], -1)
-        hi = torch.stack([w[..., 2], w[..., 3], w[..., 2], w[..., 3]], -1)
-        boxes = torch.round(torch.minimum(torch.maximum(boxes, lo), hi))  # :1429-1432
-        class_ids = class_ids.view(b, p)
-        class_scores = class_scores.view(b, p)
-        slot = torch.arange(p, device=rois.device).view(1, p)
-        valid = (class_ids > 0) & (slot < roi_counts.view(b, 1))          # :1437 (+ padded slots)
-        if c.detection_min_confidence:
-            valid = valid & (class_scores >= c.detection_min_confidence)  # :1441-1442
-        # per-class NMS (:1454-1475) as ONE class-aware pass per image; excluded slots get a unique
-        # negative class so they neither suppress nor are suppressed
-        cls = torch.where(valid, class_ids, -(slot + 1).expand(b, p)).to(torch.int32).contiguous()
-        dets = torch.cat([boxes, class_scores.unsqueeze(-1)], dim=2).contiguous()
+        # softmax/argmax (:791,1407-1415), delta gather, boxes_refine, scale, window clip, round (:1418-1432) and
+        # the validity rule (:1437-1443) in one launch; excluded slots get a unique negative NMS class so they
+        # neither suppress nor are suppressed in the class-aware pass that replaces the per-class loop (:1454-1475)
+        dets, cls, class_ids = ops.detection_decode(logits, bbox, rois.contiguous(), roi_counts,
+                                                    windows.to(torch.float32).contiguous(), c.rpn_bbox_std_dev,
+                                                    c.image_height, c.image_width,
+                                                    float(c.detection_min_confidence or 0.0))
+        boxes, class_scores = dets[..., :4], dets[..., 4]
+        valid = cls > 0
         keep, _ = ops.nms_batched(dets, c.detection_nms_threshold, class_ids=cls)
         kept = torch.zeros(b, p + 1, dtype=torch.bool, device=rois.device)
         kept.scatter_(1, keep + 1, True)                                   # -1 padding lands in column 0

@@ -267,3 +267,39 @@ def test_rpn_scores_deltas_and_proposal_decode(dev, oracle):
         want = oracle.boxes_clamp(oracle.boxes_refine(anchors[order[b]], d), [0, 0, 256, 320])
         assert torch.allclose(dets[b, :, :4], want, rtol=1e-6, atol=1e-4)   # expf ulp differences only
         assert torch.equal(dets[b, :, 4], top[b])
+
+
+def test_detection_decode_vs_oracle_math(dev, oracle):
+    """softmax/argmax + class-specific refine + window clip + round + validity, vs the oracle's box math."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(41)
+    B, P, C = 2, 300, 81
+    logits = torch.randn(B * P, C, generator=g) * 2
+    bbox = torch.randn(B * P, C, 4, generator=g) * 0.3
+    c = torch.rand(B, P, 2, generator=g)
+    hw = torch.rand(B, P, 2, generator=g) * 0.3 + 0.02
+    rois = torch.cat([c - hw / 2, c + hw / 2], -1).clamp(0, 1)
+    counts = torch.tensor([300, 123], dtype=torch.int32)
+    windows = torch.tensor([[0., 0., 512., 640.], [64., 0., 448., 640.]])
+    std = [0.1, 0.1, 0.2, 0.2]
+    for min_conf in (0.0, 0.3):
+        dets, nms_cls, cls = ops.detection_decode(logits.to(dev), bbox.to(dev), rois.to(dev), counts.to(dev),
+                                                  windows.to(dev), std, 512, 640, min_conf)
+        dets, nms_cls, cls = dets.cpu(), nms_cls.cpu(), cls.cpu()
+        probs = torch.softmax(logits, dim=1)
+        score, ids = probs.max(dim=1)
+        assert torch.equal(cls.view(-1), ids)
+        assert torch.allclose(dets[..., 4].reshape(-1), score, rtol=0, atol=1e-6)
+        d = bbox[torch.arange(B * P), ids] * torch.tensor(std)
+        refined = oracle.boxes_refine(rois.view(-1, 4), d) * torch.tensor([512., 640., 512., 640.])
+        for b in range(B):
+            want = torch.round(oracle.boxes_clamp(refined[b * P:(b + 1) * P], windows[b].tolist()))
+            diff = (dets[b, :, :4] - want).abs()
+            assert float(diff.max()) <= 1.0 and float((diff > 0).float().mean()) < 0.01  # expf ulp at .5 only
+            slot = torch.arange(P)
+            valid = (ids[b * P:(b + 1) * P] > 0) & (slot < counts[b])
+            if min_conf:
+                valid &= dets[b, :, 4] >= min_conf
+            assert torch.equal(nms_cls[b] > 0, valid)
+            assert torch.equal(nms_cls[b][valid].long(), ids[b * P:(b + 1) * P][valid])
+            assert nms_cls[b][~valid].unique().numel() == int((~valid).sum())   # unique negatives
