@@ -236,6 +236,38 @@ class FusedBottleneck:
         return c3(c2(c1(x)), residual=res)
 
 
+class Bottleneck(nn.Module):
+    """Drop-in for the reference's `Bottleneck` nn.Module (model.py:174-211): same constructor, same
+    parameter/buffer names (conv{1,2,3}, bn{1,2,3}, downsample.{0,1}) so reference state dicts load unchanged,
+    NCHW in / NCHW out. forward() runs the fused HIP path (inference, BN in eval mode); the folded (scale, shift)
+    pairs and repacked weights are rebuilt whenever a parameter changes."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=stride)
+        self.bn1 = nn.BatchNorm2d(planes, eps=BN_EPS, momentum=0.01)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3)
+        self.bn2 = nn.BatchNorm2d(planes, eps=BN_EPS, momentum=0.01)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1)
+        self.bn3 = nn.BatchNorm2d(planes * 4, eps=BN_EPS, momentum=0.01)
+        self.downsample = downsample
+        self.stride = stride
+        self._fused, self._fused_key = None, None
+
+    def _key(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("maskrcnn_amd.Bottleneck is inference-only (call .eval(); BN statistics are frozen)")
+        key = self._key()
+        if self._fused is None or key != self._fused_key:
+            self._fused = FusedBottleneck.from_state_dict(self.state_dict(), "", self.stride, x.device)
+            self._fused_key = key
+        return ops.nhwc_to_nchw(self._fused(ops.nchw_to_nhwc(x.contiguous())))
+
+
 class FusedBackbone:
     """ResNet-FPN trunk (model.py:133-168, 223-270): NCHW molded image → [P2..P6] NHWC."""
 
@@ -344,6 +376,7 @@ class FusedMask:
 
 
 __all__ = ["reference_schema", "synthetic_state_dict", "fold_bn", "pack_weight", "ConvWeight", "PRECISIONS",
+           "Bottleneck",
            "FusedConv",
            "FusedBottleneck", "FusedBackbone", "FusedRPN", "FusedClassifier", "FusedMask", "LAYERS",
            "BN_EPS"]

@@ -17,7 +17,7 @@ import ctypes
 
 import torch
 
-from ._lib import MaskrcnnHipError, c_i32, c_vp, check, lib
+from ._lib import MaskrcnnHipError, c_f32, c_i32, c_vp, check, lib
 
 _LIB = torch.library.Library("maskrcnn", "DEF")
 
@@ -388,7 +388,6 @@ def proposal_decode(anchors, deltas, order, top_scores, std_dev, image_height, i
     assert order.dtype == torch.int64 and deltas.dtype == torch.float32
     b, k = order.shape
     dets = torch.empty(b, k, 5, dtype=torch.float32, device=deltas.device)
-    from ._lib import c_f32
     check(lib.mrcnn_proposal_decode_f32(anchors.data_ptr(), deltas.data_ptr(), order.data_ptr(),
                                         top_scores.data_ptr(), b, anchors.size(0), k,
                                         (c_f32 * 4)(*[float(v) for v in std_dev]), float(image_height),
@@ -412,7 +411,6 @@ def detection_decode(logits, bbox, rois, roi_counts, windows, std_dev, image_hei
     dets = torch.empty(b, p, 5, dtype=torch.float32, device=rois.device)
     nms_cls = torch.empty(b, p, dtype=torch.int32, device=rois.device)
     cls = torch.empty(b, p, dtype=torch.int64, device=rois.device)
-    from ._lib import c_f32
     check(lib.mrcnn_detection_decode_f32(logits.data_ptr(), logits.stride(0), bbox.data_ptr(), bbox.stride(0),
                                          rois.data_ptr(), roi_counts.data_ptr(), windows.data_ptr(), b, p, c,
                                          (c_f32 * 4)(*[float(v) for v in std_dev]), float(image_height),

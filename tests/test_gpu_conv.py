@@ -186,3 +186,28 @@ def test_conv_f16x3_is_fp32_grade_at_large_magnitude(dev):
     e32 = (f32.permute(0, 3, 1, 2).cpu().double() - want).abs().max().item() / ref_scale
     assert e3 < 5e-6, e3
     assert e3 < 20 * max(e32, 1e-8), (e3, e32)   # within a small factor of the exact-fp32 kernel's own error
+
+
+def test_bottleneck_module_dropin(dev):
+    """`Bottleneck(inplanes, planes, stride, downsample)` nn.Module: reference constructor and state-dict keys,
+    NCHW in/out, reloads its folded parameters when the weights change."""
+    from maskrcnn_amd import modules
+    z = load_golden("graph_small")
+    i = 2  # (32 -> 16 planes, stride 2, with downsample)
+    sd = {k[len(f"b{i}_sd_"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"b{i}_sd_")}
+    down = torch.nn.Sequential(torch.nn.Conv2d(32, 64, kernel_size=1, stride=2),
+                               torch.nn.BatchNorm2d(64, eps=0.001, momentum=0.01))
+    blk = modules.Bottleneck(32, 16, 2, down)
+    assert sorted(blk.state_dict().keys()) == sorted(sd.keys())
+    blk.load_state_dict(sd)
+    blk = blk.to(dev).eval()
+    x = torch.from_numpy(z[f"b{i}_x"]).to(dev)
+    with torch.no_grad():
+        y = blk(x)
+        assert (y.cpu() - torch.from_numpy(z[f"b{i}_y"])).abs().max().item() <= TOL
+        blk.conv3.bias.add_(1.0)          # parameter change must invalidate the folded copy
+        y2 = blk(x)
+    assert (y2 - y).abs().max().item() > 1e-3
+    blk.train()
+    with pytest.raises(RuntimeError):
+        blk(x)
