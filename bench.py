@@ -125,14 +125,17 @@ def main():
     cfg = InferenceConfig(image_height=H, image_width=W, backbone=args.arch,
                           pre_nms_limit=args.proposals, proposal_count=args.proposals)
     sd = modules.synthetic_state_dict(args.arch, seed=0, bn_seed=1)
-    g = torch.Generator().manual_seed(1000 + rank)  # each rank owns its own shard of the global batch
+    g = torch.Generator().manual_seed(rank)  # seed 0 on rank 0; each rank owns its own shard of the batch
     mean = torch.tensor(cfg.mean_pixel)
     images = (torch.randint(0, 256, (args.batch, H, W, 3), generator=g).float() - mean)
     images = images.permute(0, 3, 1, 2).contiguous().to(dev)
     windows = torch.tensor([[0.0, 0.0, float(H), float(W)]] * args.batch, device=dev)
 
     make_net = lambda s, prec=args.precision: MaskRCNNInference(s, cfg, dev, precision=prec)
-    net = calibrate_heads_(sd, make_net, images[:1], windows[:1])
+    # the head calibration uses ONE fixed image on every rank, so all ranks end up with identical (replicated) weights
+    gc = torch.Generator().manual_seed(999)
+    cal = (torch.randint(0, 256, (1, H, W, 3), generator=gc).float() - mean).permute(0, 3, 1, 2).contiguous().to(dev)
+    net = calibrate_heads_(sd, make_net, cal, windows[:1])
 
     def step():
         det = net.predict(images, windows, with_masks=True)
