@@ -131,7 +131,7 @@ int mrcnn_roi_align_pyramid_nhwc_f32(const float* const fm[4], const int32_t fm_
  *   residual fp32 [batch][OH/res_div][OW/res_div][cout] or NULL, added before the activation;
  *            res_div = 1 (Bottleneck `out += residual`) or 2 (FPN top-down: nearest 2x upsample,
  *            model.py:150-152)
- *   relu     0/1
+ *   activation 0 none, 1 ReLU, 2 sigmoid (1/(1+exp(-v)), Mask.forward's last op, model.py:914)
  *   y        fp32 [batch][OH][OW][cout],  OH = (H + pad_top + pad_bottom - kh)/stride + 1, same for OW
  * Zero padding is applied on the fly (SamePad2d, model.py:64-87, never materialised).
  * ---------------------------------------------------------------------------------------------- */
@@ -139,7 +139,7 @@ int mrcnn_conv_bn_act_nhwc_f32(const float* x, int32_t batch, int32_t height, in
                                int32_t cin, const float* w, int32_t cout, int32_t kh, int32_t kw,
                                int32_t stride, int32_t pad_top, int32_t pad_left, int32_t pad_bottom,
                                int32_t pad_right, const float* scale, const float* shift,
-                               const float* residual, int32_t res_div, int32_t relu, float* y,
+                               const float* residual, int32_t res_div, int32_t activation, float* y,
                                mrcnn_stream_t stream);
 
 /* Same contract as mrcnn_conv_bn_act_nhwc_f32, but the contraction runs on fp16-operand MFMA
@@ -155,8 +155,23 @@ int mrcnn_conv_bn_act_nhwc_f16mfma(const float* x, int32_t batch, int32_t height
                                    const void* w_hi, const void* w_lo, int32_t cout, int32_t kh, int32_t kw,
                                    int32_t stride, int32_t pad_top, int32_t pad_left, int32_t pad_bottom,
                                    int32_t pad_right, const float* scale, const float* shift,
-                                   const float* residual, int32_t res_div, int32_t relu, int32_t products,
+                                   const float* residual, int32_t res_div, int32_t activation, int32_t products,
                                    float* y, mrcnn_stream_t stream);
+
+/* 2x2 stride-2 transposed convolution + bias + activation, NHWC — Mask.forward's `deconv` + ReLU
+ * (nn.ConvTranspose2d(256, 256, kernel_size=2, stride=2), model.py:864,906-912) as ONE GEMM whose epilogue scatters
+ * straight into the up-sampled tensor (no pixel-shuffle copy):
+ *     y[b, 2i+dy, 2j+dx, co] = act( sum_ci x[b,i,j,ci] * w[(dy*2+dx)*cout + co][ci] + bias4[(dy*2+dx)*cout + co] )
+ *   x [batch][H][W][cin];  w fp32 [4*cout][1][1][cin] (the caller repacks the [cin][cout][2][2] weight once);
+ *   bias4 fp32 [4*cout] (the bias repeated for the four taps);  y [batch][2H][2W][cout].
+ * The _f16mfma form takes the split fp16 weight planes and `products` like mrcnn_conv_bn_act_nhwc_f16mfma. */
+int mrcnn_deconv2x2_bias_act_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                      const float* w, int32_t cout, const float* bias4, int32_t activation,
+                                      float* y, mrcnn_stream_t stream);
+int mrcnn_deconv2x2_bias_act_nhwc_f16mfma(const float* x, int32_t batch, int32_t height, int32_t width,
+                                          int32_t cin, const void* w_hi, const void* w_lo, int32_t cout,
+                                          const float* bias4, int32_t activation, int32_t products, float* y,
+                                          mrcnn_stream_t stream);
 
 /* Zero-padded max-pool, NHWC fp32: [batch][H][W][C] -> [batch][OH][OW][C], OH = (H+pad_top+pad_bottom-k)/s+1.
  * Covers the stem's SamePad2d(3,2) + MaxPool2d(3,2) (model.py:227-228; pads (0,1,0,1) on even sizes — the

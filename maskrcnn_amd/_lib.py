@@ -37,6 +37,10 @@ _SIGS = {
     "mrcnn_conv_bn_act_nhwc_f16mfma": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32,
                                                         c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp,
                                                         c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mrcnn_deconv2x2_bias_act_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32,
+                                                           c_vp, c_vp]),
+    "mrcnn_deconv2x2_bias_act_nhwc_f16mfma": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32,
+                                                               c_vp, c_i32, c_i32, c_vp, c_vp]),
     "mrcnn_maxpool_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                                 c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mrcnn_rpn_scores_deltas_f32": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), c_i32, c_vp,

@@ -37,7 +37,8 @@ struct ConvParams {
     float* y;
     int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
     int M, K;  // GEMM sizes
-    int res_div, relu;
+    int res_div, act;  // act: 0 none, 1 ReLU, 2 sigmoid
+    int out_mode;      // 0: y[m][n]; 1: 2x2 stride-2 transposed-conv scatter, n = (dy*2+dx)*Cout/4 + co
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;  // buffer-descriptor ranges (< 4 GiB each)
 };
@@ -286,7 +287,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
         const bool n_ok = n < p.Cout;
         sc[jn] = (n_ok && p.scale) ? p.scale[n] : 1.0f;
         sh[jn] = (n_ok && p.shift) ? p.shift[n] : 0.0f;
-        ncol[jn] = n_ok ? static_cast<unsigned>(n) * 4u : OOB;
+        if constexpr (RES != 4) {
+            ncol[jn] = n_ok ? static_cast<unsigned>(n) * 4u : OOB;
+        } else {  // n = (dy*2 + dx)*cq + co  →  pixel (2i+dy, 2j+dx), channel co of the [B][2*OH][2*OW][cq] output
+            const int cq = p.Cout >> 2, q = n / cq, co = n - q * cq;
+            ncol[jn] = n_ok ? static_cast<unsigned>(((q >> 1) * 2 * p.OW + (q & 1)) * cq + co) * 4u : OOB;
+        }
     }
     const int rh = p.OH >> 1, rw = p.OW >> 1;
     const unsigned row_bytes = static_cast<unsigned>(p.Cout) * 4u;
@@ -298,7 +304,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
         for (int r = 0; r < 16; ++r) {
             const int m = mb + (r & 3) + 8 * (r >> 2);
             const bool ok = m < p.M;
-            yrow[r] = ok ? static_cast<unsigned>(m) * row_bytes : OOB;
+            if constexpr (RES != 4) {
+                yrow[r] = ok ? static_cast<unsigned>(m) * row_bytes : OOB;
+            } else {
+                const int mm = ok ? m : 0;
+                const int b = mm / ohw, rem = mm - b * ohw;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                yrow[r] = ok ? static_cast<unsigned>((b * 2 * p.OH + 2 * oy) * (2 * p.OW) + 2 * ox) *
+                                   (row_bytes >> 2)
+                             : OOB;
+            }
             if constexpr (RES == 1) {
                 rrow[r] = yrow[r];
             } else if constexpr (RES == 2) {
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
             float rv[16];
-            if constexpr (RES != 0) {
+            if constexpr (RES == 1 || RES == 2) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     // OOB in either term must stay OOB: saturating add via max
@@ -322,8 +337,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][jn][r] * sc[jn] + sh[jn];
-                if constexpr (RES != 0) v += rv[r];
-                if (p.relu) v = v > 0.f ? v : 0.f;
+                if constexpr (RES == 1 || RES == 2) v += rv[r];
+                if constexpr (RES == 3) v = 1.0f / (1.0f + expf(-v));
+                else if (p.act) v = v > 0.f ? v : 0.f;
                 const unsigned off = (yrow[r] | ncol[jn]) >= OOB ? OOB : yrow[r] + ncol[jn];
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(off), 0, 0);
             }
@@ -348,8 +364,9 @@ int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
         done = true;
         return MRCNN_OK;
     };
-    const int res = p.residual ? p.res_div : 0;
-    static bool attr_done[2][3] = {};
+    // epilogue variant: 0 plain, 1 / 2 residual (same size / half size), 3 sigmoid, 4 deconv-2x2 scatter
+    const int res = p.out_mode == 1 ? 4 : (p.act == 2 ? 3 : (p.residual ? p.res_div : 0));
+    static bool attr_done[2][5] = {};
     auto go = [&](auto kern) -> int {
         if (int rc = set_attr(reinterpret_cast<const void*>(kern), attr_done[generic ? 1 : 0][res])) return rc;
         hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
@@ -359,24 +376,31 @@ int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
     if (generic)
         rc = res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 0>)
            : res == 1 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 1>)
-                      : go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 2>);
+           : res == 2 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 2>)
+           : res == 3 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 3>)
+                      : go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 4>);
     else
         rc = res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 0>)
            : res == 1 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 1>)
-                      : go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 2>);
+           : res == 2 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 2>)
+           : res == 3 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 3>)
+                      : go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 4>);
     if (rc) return rc;
     return mrcnn::check_launch("conv_igemm_f32");
 }
 
 }  // namespace
 
-extern "C" int mrcnn_conv_bn_act_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
-                                          int32_t cin, const float* w, int32_t cout, int32_t kh,
-                                          int32_t kw, int32_t stride, int32_t pad_top, int32_t pad_left,
-                                          int32_t pad_bottom, int32_t pad_right, const float* scale,
-                                          const float* shift, const float* residual, int32_t res_div,
-                                          int32_t relu, float* y, mrcnn_stream_t stream) {
+static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                        const float* w, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad_top,
+                        int32_t pad_left, int32_t pad_bottom, int32_t pad_right, const float* scale,
+                        const float* shift, const float* residual, int32_t res_div, int32_t relu,
+                        int32_t out_mode, float* y, mrcnn_stream_t stream) {
     MRCNN_REQUIRE(x && w && y, "conv: null pointer");
+    MRCNN_REQUIRE(relu >= 0 && relu <= 2, "conv: activation must be 0 (none), 1 (ReLU) or 2 (sigmoid)");
+    MRCNN_REQUIRE(residual == nullptr || (relu != 2 && out_mode == 0),
+                  "conv: a residual cannot be combined with sigmoid or the deconv scatter");
+    MRCNN_REQUIRE(out_mode == 0 || relu != 2, "conv: deconv scatter supports activation 0 or 1");
     MRCNN_REQUIRE(batch >= 1 && height >= 1 && width >= 1 && cin >= 4 && cin % 4 == 0 && cout >= 1,
                   "conv: bad shape B=%d H=%d W=%d Cin=%d (Cin %% 4 == 0 required) Cout=%d", batch, height,
                   width, cin, cout);
@@ -404,7 +428,8 @@ extern "C" int mrcnn_conv_bn_act_nhwc_f32(const float* x, int32_t batch, int32_t
     p.w_bytes = static_cast<unsigned>(4LL * K * cout);
     p.y_bytes = static_cast<unsigned>(4LL * M * cout);
     p.r_bytes = residual ? static_cast<unsigned>(4LL * M * cout / (p.res_div * p.res_div)) : 0u;
-    p.relu = relu;
+    p.act = relu;  // 0 none, 1 ReLU, 2 sigmoid
+    p.out_mode = out_mode;
     const bool generic = (cin % 32) != 0;
     hipStream_t s = mrcnn::as_stream(stream);
     static const int force = getenv("MRCNN_CONV_TILE") ? atoi(getenv("MRCNN_CONV_TILE")) : 0;  // tuning aid
@@ -421,4 +446,22 @@ extern "C" int mrcnn_conv_bn_act_nhwc_f32(const float* x, int32_t batch, int32_t
     if (use_big) return launch_conv<256, 128, 2, 2, 16>(p, generic, s);
     if (force == 3 && !generic) return launch_conv<128, 128, 2, 2, 16>(p, generic, s);  // 41 KB LDS: 3 workgroups/CU
     return launch_conv<128, 128, 2, 2, 32>(p, generic, s);
+}
+
+extern "C" int mrcnn_conv_bn_act_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
+                                          int32_t cin, const float* w, int32_t cout, int32_t kh,
+                                          int32_t kw, int32_t stride, int32_t pad_top, int32_t pad_left,
+                                          int32_t pad_bottom, int32_t pad_right, const float* scale,
+                                          const float* shift, const float* residual, int32_t res_div,
+                                          int32_t activation, float* y, mrcnn_stream_t stream) {
+    return run_conv_f32(x, batch, height, width, cin, w, cout, kh, kw, stride, pad_top, pad_left, pad_bottom,
+                        pad_right, scale, shift, residual, res_div, activation, 0, y, stream);
+}
+
+extern "C" int mrcnn_deconv2x2_bias_act_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
+                                                 int32_t cin, const float* w, int32_t cout, const float* bias4,
+                                                 int32_t activation, float* y, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(cout >= 1, "deconv2x2: cout=%d", cout);
+    return run_conv_f32(x, batch, height, width, cin, w, 4 * cout, 1, 1, 1, 0, 0, 0, 0, nullptr, bias4, nullptr, 1,
+                        activation, 1, y, stream);
 }

@@ -36,7 +36,8 @@ struct ConvParamsH {
     float* y;
     int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
     int M, K;
-    int res_div, relu;
+    int res_div, act;  // act: 0 none, 1 ReLU, 2 sigmoid
+    int out_mode;      // 0: y[m][n]; 1: 2x2 stride-2 transposed-conv scatter, n = (dy*2+dx)*Cout/4 + co
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;
 };
@@ -296,7 +297,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParamsH p) {
         const bool n_ok = n < p.Cout;
         sc[jn] = (n_ok && p.scale) ? p.scale[n] : 1.0f;
         sh[jn] = (n_ok && p.shift) ? p.shift[n] : 0.0f;
-        ncol[jn] = n_ok ? static_cast<unsigned>(n) * 4u : OOB;
+        if constexpr (RES != 4) {
+            ncol[jn] = n_ok ? static_cast<unsigned>(n) * 4u : OOB;
+        } else {  // n = (dy*2 + dx)*cq + co  →  pixel (2i+dy, 2j+dx), channel co of the [B][2*OH][2*OW][cq] output
+            const int cq = p.Cout >> 2, q = n / cq, co = n - q * cq;
+            ncol[jn] = n_ok ? static_cast<unsigned>(((q >> 1) * 2 * p.OW + (q & 1)) * cq + co) * 4u : OOB;
+        }
     }
     const int rh = p.OH >> 1, rw = p.OW >> 1;
     const unsigned row_bytes = static_cast<unsigned>(p.Cout) * 4u;
@@ -308,7 +314,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParamsH p) {
         for (int r = 0; r < 16; ++r) {
             const int m = mb + (r & 3) + 8 * (r >> 2);
             const bool ok = m < p.M;
-            yrow[r] = ok ? static_cast<unsigned>(m) * row_bytes : OOB;
+            if constexpr (RES != 4) {
+                yrow[r] = ok ? static_cast<unsigned>(m) * row_bytes : OOB;
+            } else {
+                const int mm = ok ? m : 0;
+                const int b = mm / ohw, rem = mm - b * ohw;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                yrow[r] = ok ? static_cast<unsigned>((b * 2 * p.OH + 2 * oy) * (2 * p.OW) + 2 * ox) *
+                                   (row_bytes >> 2)
+                             : OOB;
+            }
             if constexpr (RES == 1) {
                 rrow[r] = yrow[r];
             } else if constexpr (RES == 2) {
@@ -321,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParamsH p) {
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
             float rv[16];
-            if constexpr (RES != 0) {
+            if constexpr (RES == 1 || RES == 2) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned off = (rrow[r] | ncol[jn]) >= OOB ? OOB : rrow[r] + ncol[jn];
@@ -331,8 +346,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParamsH p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][jn][r] * sc[jn] + sh[jn];
-                if constexpr (RES != 0) v += rv[r];
-                if (p.relu) v = v > 0.f ? v : 0.f;
+                if constexpr (RES == 1 || RES == 2) v += rv[r];
+                if constexpr (RES == 3) v = 1.0f / (1.0f + expf(-v));
+                else if (p.act) v = v > 0.f ? v : 0.f;
                 const unsigned off = (yrow[r] | ncol[jn]) >= OOB ? OOB : yrow[r] + ncol[jn];
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(off), 0, 0);
             }
@@ -347,7 +363,8 @@ int launch(ConvParamsH p, bool generic, hipStream_t stream) {
     const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
     if (grid > 0x7fffffffLL) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv_f16: grid too large");
     constexpr size_t lds = lds_bytes<BM, BN, PRODUCTS>();
-    const int res = p.residual ? p.res_div : 0;
+    // epilogue variant: 0 plain, 1 / 2 residual (same size / half size), 3 sigmoid, 4 deconv-2x2 scatter
+    const int res = p.out_mode == 1 ? 4 : (p.act == 2 ? 3 : (p.residual ? p.res_div : 0));
     auto go = [&](auto kern) -> int {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -363,11 +380,15 @@ int launch(ConvParamsH p, bool generic, hipStream_t stream) {
     if (generic)
         rc = res == 0 ? go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, true, 0>)
            : res == 1 ? go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, true, 1>)
-                      : go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, true, 2>);
+           : res == 2 ? go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, true, 2>)
+           : res == 3 ? go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, true, 3>)
+                      : go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, true, 4>);
     else
         rc = res == 0 ? go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, false, 0>)
            : res == 1 ? go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, false, 1>)
-                      : go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, false, 2>);
+           : res == 2 ? go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, false, 2>)
+           : res == 3 ? go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, false, 3>)
+                      : go(conv_igemm_f16<BM, BN, WM, WN, PRODUCTS, false, 4>);
     if (rc) return rc;
     return mrcnn::check_launch("conv_igemm_f16");
 }
@@ -380,13 +401,15 @@ int dispatch(const ConvParamsH& p, bool generic, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int mrcnn_conv_bn_act_nhwc_f16mfma(const float* x, int32_t batch, int32_t height, int32_t width,
-                                              int32_t cin, const void* w_hi, const void* w_lo, int32_t cout,
-                                              int32_t kh, int32_t kw, int32_t stride, int32_t pad_top,
-                                              int32_t pad_left, int32_t pad_bottom, int32_t pad_right,
-                                              const float* scale, const float* shift, const float* residual,
-                                              int32_t res_div, int32_t relu, int32_t products, float* y,
-                                              mrcnn_stream_t stream) {
+static int run_conv_f16(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                        const void* w_hi, const void* w_lo, int32_t cout, int32_t kh, int32_t kw, int32_t stride,
+                        int32_t pad_top, int32_t pad_left, int32_t pad_bottom, int32_t pad_right,
+                        const float* scale, const float* shift, const float* residual, int32_t res_div,
+                        int32_t relu, int32_t products, int32_t out_mode, float* y, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(relu >= 0 && relu <= 2, "conv_f16: activation must be 0 (none), 1 (ReLU) or 2 (sigmoid)");
+    MRCNN_REQUIRE(residual == nullptr || (relu != 2 && out_mode == 0),
+                  "conv_f16: a residual cannot be combined with sigmoid or the deconv scatter");
+    MRCNN_REQUIRE(out_mode == 0 || relu != 2, "conv_f16: deconv scatter supports activation 0 or 1");
     MRCNN_REQUIRE(x && w_hi && y, "conv_f16: null pointer");
     MRCNN_REQUIRE(products == 1 || (products == 3 && w_lo), "conv_f16: products must be 1, or 3 with w_lo");
     MRCNN_REQUIRE(batch >= 1 && height >= 1 && width >= 1 && cin >= 8 && cin % 8 == 0 && cout >= 1,
@@ -413,7 +436,8 @@ extern "C" int mrcnn_conv_bn_act_nhwc_f16mfma(const float* x, int32_t batch, int
     p.M = static_cast<int>(M);
     p.K = static_cast<int>(K);
     p.res_div = residual ? res_div : 1;
-    p.relu = relu;
+    p.act = relu;  // 0 none, 1 ReLU, 2 sigmoid
+    p.out_mode = out_mode;
     p.x_bytes = static_cast<unsigned>(4LL * batch * height * width * cin);
     p.w_bytes = static_cast<unsigned>(2LL * K * cout);
     p.y_bytes = static_cast<unsigned>(4LL * M * cout);
@@ -421,4 +445,24 @@ extern "C" int mrcnn_conv_bn_act_nhwc_f16mfma(const float* x, int32_t batch, int
     const bool generic = (cin % BK) != 0;
     hipStream_t s = mrcnn::as_stream(stream);
     return products == 3 ? dispatch<3>(p, generic, s) : dispatch<1>(p, generic, s);
+}
+
+extern "C" int mrcnn_conv_bn_act_nhwc_f16mfma(const float* x, int32_t batch, int32_t height, int32_t width,
+                                              int32_t cin, const void* w_hi, const void* w_lo, int32_t cout,
+                                              int32_t kh, int32_t kw, int32_t stride, int32_t pad_top,
+                                              int32_t pad_left, int32_t pad_bottom, int32_t pad_right,
+                                              const float* scale, const float* shift, const float* residual,
+                                              int32_t res_div, int32_t activation, int32_t products, float* y,
+                                              mrcnn_stream_t stream) {
+    return run_conv_f16(x, batch, height, width, cin, w_hi, w_lo, cout, kh, kw, stride, pad_top, pad_left,
+                        pad_bottom, pad_right, scale, shift, residual, res_div, activation, products, 0, y, stream);
+}
+
+extern "C" int mrcnn_deconv2x2_bias_act_nhwc_f16mfma(const float* x, int32_t batch, int32_t height, int32_t width,
+                                                     int32_t cin, const void* w_hi, const void* w_lo,
+                                                     int32_t cout, const float* bias4, int32_t activation,
+                                                     int32_t products, float* y, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(cout >= 1, "deconv2x2: cout=%d", cout);
+    return run_conv_f16(x, batch, height, width, cin, w_hi, w_lo, 4 * cout, 1, 1, 1, 0, 0, 0, 0, nullptr, bias4,
+                        nullptr, 1, activation, products, 1, y, stream);
 }

@@ -170,6 +170,12 @@ class ConvWeight:
                 self.w_lo = None
         self.cin = (self.w if precision == "f32" else self.w_hi).size(3)
 
+    def deconv2x2(self, x, bias4, activation=0):
+        """self holds the [4*Cout,1,1,Cin] repack of a 2x2 stride-2 transposed-conv weight."""
+        if self.precision == "f32":
+            return ops.deconv2x2(x, self.w, bias4, activation, 0)
+        return ops.deconv2x2(x, (self.w_hi, self.w_lo), bias4, activation, 3 if self.precision == "f16x3" else 1)
+
     def conv(self, x, scale, shift, stride=1, pad=(0, 0, 0, 0), relu=False, residual=None, res_div=1,
              algo_cin=None):
         if self.precision == "f32":
@@ -350,8 +356,8 @@ class FusedClassifier:
 
 class FusedMask:
     """Mask.forward after roi_align (model.py:894-914). Input [R,14,14,256] NHWC → [R,28,28,81] NHWC.
-    The 2x2 stride-2 transposed conv is one GEMM to 4*256 channels + a pixel shuffle; its ReLU rides in
-    the GEMM epilogue (it commutes with the shuffle)."""
+    The 2x2 stride-2 transposed conv is one GEMM to 4*256 channels whose epilogue scatters (dy,dx,co) straight into
+    the up-sampled tensor and applies bias + ReLU; the final sigmoid is the 1x1 conv's epilogue activation."""
 
     def __init__(self, sd, device, prefix="mask.", precision="f32"):
         self.convs = [FusedConv(sd, f"{prefix}conv{i}", f"{prefix}bn{i}", device, relu=True,
@@ -363,16 +369,14 @@ class FusedMask:
                                precision)
         self.b_de = sd[prefix + "deconv.bias"].float().repeat(4).contiguous().to(device)
         self.cout = cout
-        self.conv5 = FusedConv(sd, prefix + "conv5", None, device, precision=precision)
+        self.conv5 = FusedConv(sd, prefix + "conv5", None, device, relu=2, precision=precision)  # 2 = sigmoid
 
     def __call__(self, pooled):
         x = pooled
         for c in self.convs:
             x = c(x)
-        r, h, w, _ = x.shape
-        y = self.w_de.conv(x, None, self.b_de, relu=True)                      # [R,h,w,4*C]
-        y = y.view(r, h, w, 2, 2, self.cout).permute(0, 1, 3, 2, 4, 5).reshape(r, 2 * h, 2 * w, self.cout)
-        return torch.sigmoid(self.conv5(y.contiguous()))
+        y = self.w_de.deconv2x2(x, self.b_de, activation=1)   # [R,2h,2w,C]: deconv + bias + ReLU, scattered in place
+        return self.conv5(y)                                  # 1x1 conv + bias + sigmoid (model.py:913-914)
 
 
 __all__ = ["reference_schema", "synthetic_state_dict", "fold_bn", "pack_weight", "ConvWeight", "PRECISIONS",

@@ -202,6 +202,7 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
                 out: torch.Tensor | None = None, algo_cin: int | None = None) -> torch.Tensor:
     """y = act(scale * conv(x, w) + shift + residual).
 
+    relu: False/0 none, True/1 ReLU, 2 sigmoid.
     x [B,H,W,Cin] NHWC fp32 contiguous; w [Cout,KH,KW,Cin] (OHWI) contiguous; scale/shift [Cout] or
     None; pad = (top, left, bottom, right) zero padding applied on the fly; residual [B,OH/res_div,
     OW/res_div,Cout]. Returns y [B,OH,OW,Cout] NHWC."""
@@ -231,7 +232,7 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
         e0.record()
     check(lib.mrcnn_conv_bn_act_nhwc_f32(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout, kh, kw,
                                          int(stride), pt, pl, pb, pr, _ptr(scale), _ptr(shift),
-                                         _ptr(residual), int(res_div), int(bool(relu)),
+                                         _ptr(residual), int(res_div), int(relu),
                                          out.data_ptr(), _stream()))
     if prof is not None:
         e1.record()
@@ -273,7 +274,7 @@ def conv_bn_act_f16mfma(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor 
         e0.record()
     check(lib.mrcnn_conv_bn_act_nhwc_f16mfma(x.data_ptr(), b, h, wd, cin, w_hi.data_ptr(), _ptr(w_lo), cout,
                                              kh, kw, int(stride), pt, pl, pb, pr, _ptr(scale), _ptr(shift),
-                                             _ptr(residual), int(res_div), int(bool(relu)), int(products),
+                                             _ptr(residual), int(res_div), int(relu), int(products),
                                              out.data_ptr(), _stream()))
     if prof is not None:
         e1.record()
@@ -420,3 +421,38 @@ def detection_decode(logits, bbox, rois, roi_counts, windows, std_dev, image_hei
 
 
 __all__ += ["detection_decode"]
+
+
+def deconv2x2(x: torch.Tensor, w, bias4: torch.Tensor, activation: int = 0, products: int = 0) -> torch.Tensor:
+    """2x2 stride-2 transposed conv + bias + activation (Mask.forward's deconv, model.py:864,906-912) as one GEMM
+    scattering into [B,2H,2W,Cout]. w: fp32 [4*Cout,1,1,Cin] (products = 0) or the (w_hi, w_lo) fp16 planes of it
+    (products = 1 or 3); bias4 [4*Cout]."""
+    _need_gpu(x, bias4)
+    assert x.is_contiguous() and x.dtype == torch.float32 and bias4.is_contiguous()
+    b, h, wd, cin = x.shape
+    w0 = w if products == 0 else w[0]
+    cout = w0.size(0) // 4
+    assert w0.size(3) == cin and bias4.numel() == 4 * cout
+    y = torch.empty(b, 2 * h, 2 * wd, cout, dtype=torch.float32, device=x.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if products == 0:
+        assert w.dtype == torch.float32 and w.is_contiguous()
+        check(lib.mrcnn_deconv2x2_bias_act_nhwc_f32(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout,
+                                                    bias4.data_ptr(), int(activation), y.data_ptr(), _stream()))
+    else:
+        w_hi, w_lo = w
+        check(lib.mrcnn_deconv2x2_bias_act_nhwc_f16mfma(x.data_ptr(), b, h, wd, cin, w_hi.data_ptr(), _ptr(w_lo),
+                                                        cout, bias4.data_ptr(), int(activation), int(products),
+                                                        y.data_ptr(), _stream()))
+    if prof is not None:
+        e1.record()
+        m = b * h * wd
+        prof.append((e0, e1, 2.0 * m * cin * 4 * cout, (m, 4 * cout, cin),
+                     4 * (x.numel() + y.numel()) + (4 if products == 0 else 2 * (2 if products == 3 else 1)) * w0.numel()))
+    return y
+
+
+__all__ += ["deconv2x2"]
