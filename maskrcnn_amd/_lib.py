@@ -43,6 +43,9 @@ _SIGS = {
                                                                c_vp, c_i32, c_i32, c_vp, c_vp]),
     "mrcnn_maxpool_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                                 c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mrcnn_rpn_level_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "mrcnn_rpn_level_fused_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp,
+                                                   c_i32, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "mrcnn_rpn_scores_deltas_f32": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), c_i32, c_vp,
                                                      c_vp, c_vp]),
     "mrcnn_proposal_decode_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,

@@ -41,6 +41,9 @@ struct ConvParams {
     int out_mode;      // 0: y[m][n]; 1: 2x2 stride-2 transposed-conv scatter, n = (dy*2+dx)*Cout/4 + co
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;  // buffer-descriptor ranges (< 4 GiB each)
+    // RES == 5 (fused 1x1 heads): y is the per-N-tile partial [tiles_n][M][head_n]; w_head is [32][Cout]
+    const float* w_head;
+    int head_n;
 };
 
 template <int BM, int BN, int BK>
@@ -271,6 +274,56 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
         }
     }
 
+    if constexpr (RES == 5) {
+        // ---- fused 1x1 heads (RPN conv_class + conv_bbox, model.py:605-607,624-641): the ReLU'd tile of the
+        // shared 3x3 conv never goes to HBM. It is transposed through LDS (accumulators hold one channel per
+        // lane; the next MFMA needs one pixel per lane) and multiplied by the [32][Cout] head weights; each
+        // N tile writes its partial [BM][head_n] sums, a small kernel adds the tiles_n partials in fixed order.
+        static_assert(BM == 128 && BN == 128 && WM == 2 && WN == 2, "heads epilogue is written for the 128x128 tile");
+        constexpr int TS = BN + 4;  // row pitch of the transposed tile, floats (conflict-free b128 reads)
+        const int ln = lane & 31, lh = lane >> 5;
+        __syncthreads();  // nobody still reads the main loop's LDS tiles
+        float* T = smem;  // [BM][TS] = 67.6 KB <= the 73.7 KB the main loop used
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int n = n0 + wn * WTN + jn * 32 + ln;
+            const float sc = p.scale ? p.scale[n] : 1.0f, sh = p.shift ? p.shift[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][jn][r] * sc + sh;
+                    v = v > 0.f ? v : 0.f;
+                    T[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TS + wn * WTN + jn * 32 + ln] = v;
+                }
+        }
+        __syncthreads();
+        f32x16 hacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+        const float* Trow = T + (wave * 32 + ln) * TS + lh * 4;                       // A: pixel rows of this wave
+        const float* Wrow = p.w_head + static_cast<int64_t>(ln) * p.Cout + n0 + lh * 4;  // B: head channel ln
+#pragma unroll 4
+        for (int j = 0; j < BN / 8; ++j) {
+            const float4 a = *reinterpret_cast<const float4*>(Trow + j * 8);
+            const float4 b = *reinterpret_cast<const float4*>(Wrow + j * 8);
+            hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, hacc, 0, 0, 0);
+            hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, hacc, 0, 0, 0);
+            hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, hacc, 0, 0, 0);
+            hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, hacc, 0, 0, 0);
+        }
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+        const unsigned tile_base = static_cast<unsigned>(nt) * static_cast<unsigned>(p.M) * p.head_n * 4u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const bool ok = m < p.M && ln < p.head_n;
+            const unsigned off = ok ? tile_base + (static_cast<unsigned>(m) * p.head_n + ln) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hacc[r]), o_rsrc, static_cast<int>(off), 0, 0);
+        }
+        return;
+    }
+
     // ---- epilogue: affine + residual + ReLU, 128-byte channel runs per half-wave ------------------------
     // Branch-free: stores and residual loads go through buffer descriptors, out-of-tile rows/channels get
     // an out-of-range offset (loads return 0, stores are dropped). Per 32x32 accumulator tile the 16
@@ -365,14 +418,22 @@ int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
         return MRCNN_OK;
     };
     // epilogue variant: 0 plain, 1 / 2 residual (same size / half size), 3 sigmoid, 4 deconv-2x2 scatter
-    const int res = p.out_mode == 1 ? 4 : (p.act == 2 ? 3 : (p.residual ? p.res_div : 0));
-    static bool attr_done[2][5] = {};
+    const int res = p.w_head ? 5 : p.out_mode == 1 ? 4 : (p.act == 2 ? 3 : (p.residual ? p.res_div : 0));
+    static bool attr_done[2][6] = {};
     auto go = [&](auto kern) -> int {
         if (int rc = set_attr(reinterpret_cast<const void*>(kern), attr_done[generic ? 1 : 0][res])) return rc;
         hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
         return MRCNN_OK;
     };
     int rc;
+    if constexpr (BM == 128 && BN == 128 && WM == 2 && WN == 2 && BK == 32) {
+        if (res == 5) {
+            if (generic) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: fused heads need Cin %% 32 == 0");
+            if ((rc = go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 5>))) return rc;
+            return mrcnn::check_launch("conv_igemm_f32<heads>");
+        }
+    }
+    if (res == 5) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: fused heads need the 128x128 tile");
     if (generic)
         rc = res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 0>)
            : res == 1 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 1>)
@@ -430,6 +491,8 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
     p.r_bytes = residual ? static_cast<unsigned>(4LL * M * cout / (p.res_div * p.res_div)) : 0u;
     p.act = relu;  // 0 none, 1 ReLU, 2 sigmoid
     p.out_mode = out_mode;
+    p.w_head = nullptr;
+    p.head_n = 0;
     const bool generic = (cin % 32) != 0;
     hipStream_t s = mrcnn::as_stream(stream);
     static const int force = getenv("MRCNN_CONV_TILE") ? atoi(getenv("MRCNN_CONV_TILE")) : 0;  // tuning aid
@@ -464,4 +527,62 @@ extern "C" int mrcnn_deconv2x2_bias_act_nhwc_f32(const float* x, int32_t batch, 
     MRCNN_REQUIRE(cout >= 1, "deconv2x2: cout=%d", cout);
     return run_conv_f32(x, batch, height, width, cin, w, 4 * cout, 1, 1, 1, 0, 0, 0, 0, nullptr, bias4, nullptr, 1,
                         activation, 1, y, stream);
+}
+
+namespace {
+// y[m][c] = bias[c] + sum over N tiles (fixed order: deterministic) of partial[t][m][c]
+__global__ __launch_bounds__(256) void heads_reduce(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                    int64_t MC, int head_n, int tiles, float* __restrict__ y) {
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < MC;
+         e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        float v = bias ? bias[e % head_n] : 0.f;
+        for (int t = 0; t < tiles; ++t) v += partial[t * MC + e];
+        y[e] = v;
+    }
+}
+}  // namespace
+
+extern "C" size_t mrcnn_rpn_level_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t cout,
+                                                  int32_t head_n) {
+    if (batch < 1 || height < 1 || width < 1 || cout < 1 || head_n < 1) return 0;
+    return sizeof(float) * static_cast<size_t>((cout + 127) / 128) * batch * height * width * head_n;
+}
+
+extern "C" int mrcnn_rpn_level_fused_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                         const float* w_shared, int32_t cout, const float* b_shared,
+                                         const float* w_head32, const float* b_head, int32_t head_n,
+                                         void* workspace, size_t workspace_bytes, float* y, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x && w_shared && w_head32 && workspace && y, "rpn_level: null pointer");
+    MRCNN_REQUIRE(batch >= 1 && height >= 1 && width >= 1 && cin % 32 == 0 && cin >= 32,
+                  "rpn_level: bad shape (Cin %% 32 == 0 required)");
+    MRCNN_REQUIRE(cout % 128 == 0 && cout >= 128, "rpn_level: Cout=%d must be a multiple of 128", cout);
+    MRCNN_REQUIRE(head_n >= 1 && head_n <= 32, "rpn_level: head_n=%d must be in [1,32]", head_n);
+    MRCNN_REQUIRE(workspace_bytes >= mrcnn_rpn_level_workspace_bytes(batch, height, width, cout, head_n),
+                  "rpn_level: workspace too small");
+    const long long M = 1LL * batch * height * width;
+    const int tiles_n = cout / 128;
+    MRCNN_REQUIRE(M * cin < (1LL << 30) && 9LL * cin * cout < (1LL << 30) && M * head_n * tiles_n < (1LL << 30),
+                  "rpn_level: tensor too large for 32-bit buffer offsets");
+    ConvParams p;
+    p.x = x; p.w = w_shared; p.scale = nullptr; p.shift = b_shared; p.residual = nullptr;
+    p.y = static_cast<float*>(workspace);
+    p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout; p.KH = 3; p.KW = 3;
+    p.stride = 1; p.pad_t = 1; p.pad_l = 1; p.OH = height; p.OW = width;
+    p.M = static_cast<int>(M);
+    p.K = 9 * cin;
+    p.res_div = 1; p.act = 1; p.out_mode = 0;
+    p.x_bytes = static_cast<unsigned>(4LL * M * cin);
+    p.w_bytes = static_cast<unsigned>(4LL * p.K * cout);
+    p.y_bytes = static_cast<unsigned>(4LL * tiles_n * M * head_n);
+    p.r_bytes = 0;
+    p.w_head = w_head32;
+    p.head_n = head_n;
+    hipStream_t s = mrcnn::as_stream(stream);
+    if (int rc = launch_conv<128, 128, 2, 2, 32>(p, false, s)) return rc;
+    const int64_t MC = M * head_n;
+    int64_t blocks = (MC + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(heads_reduce, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s,
+                       static_cast<const float*>(workspace), b_head, MC, head_n, tiles_n, y);
+    return mrcnn::check_launch("heads_reduce");
 }

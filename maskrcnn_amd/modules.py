@@ -317,14 +317,26 @@ class FusedRPN:
     18-channel GEMM. Returns NHWC [B,H,W,18]: channels 0-5 = (bg,fg) logits x 3 anchors, 6-17 = deltas."""
 
     def __init__(self, sd, device, prefix="rpn.", precision="f32"):
-        self.shared = FusedConv(sd, prefix + "conv_shared", None, device, relu=True, same_pad_kernel=3,
-                                precision=precision)
+        self.precision = precision
         w = torch.cat([sd[prefix + "conv_class.weight"], sd[prefix + "conv_bbox.weight"]], 0)
-        self.w_head = ConvWeight(pack_weight(w, device), precision)
         self.b_head = torch.cat([sd[prefix + "conv_class.bias"], sd[prefix + "conv_bbox.bias"]]).float() \
             .contiguous().to(device)
+        if precision == "f32":
+            # fused level kernel: the 512-channel shared activation never leaves the chip (ops.rpn_level_fused)
+            self.w_shared = pack_weight(sd[prefix + "conv_shared.weight"], device)
+            self.b_shared = sd[prefix + "conv_shared.bias"].float().contiguous().to(device)
+            w32 = torch.zeros(32, w.size(1), dtype=torch.float32)
+            w32[:w.size(0)] = w.float().view(w.size(0), -1)
+            self.w_head32 = w32.contiguous().to(device)
+            self.head_n = w.size(0)
+        else:
+            self.shared = FusedConv(sd, prefix + "conv_shared", None, device, relu=True, same_pad_kernel=3,
+                                    precision=precision)
+            self.w_head = ConvWeight(pack_weight(w, device), precision)
 
     def __call__(self, p):
+        if self.precision == "f32":
+            return ops.rpn_level_fused(p, self.w_shared, self.b_shared, self.w_head32, self.b_head, self.head_n)
         return self.w_head.conv(self.shared(p), None, self.b_head)
 
 

@@ -456,3 +456,33 @@ def deconv2x2(x: torch.Tensor, w, bias4: torch.Tensor, activation: int = 0, prod
 
 
 __all__ += ["deconv2x2"]
+
+
+def rpn_level_fused(x, w_shared, b_shared, w_head32, b_head, head_n: int = 18) -> torch.Tensor:
+    """RPN.forward on one level (model.py:609-649) with the shared 512-channel activation kept on chip:
+    x [B,H,W,Cin] NHWC → [B,H,W,head_n] (class logits then box deltas). fp32 MFMA path."""
+    _need_gpu(x, w_shared, b_shared, w_head32, b_head)
+    assert x.is_contiguous() and w_shared.is_contiguous() and w_head32.is_contiguous()
+    b, h, wd, cin = x.shape
+    cout = w_shared.size(0)
+    assert tuple(w_shared.shape[1:]) == (3, 3, cin) and tuple(w_head32.shape) == (32, cout)
+    ws_bytes = int(lib.mrcnn_rpn_level_workspace_bytes(b, h, wd, cout, head_n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    y = torch.empty(b, h, wd, head_n, dtype=torch.float32, device=x.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mrcnn_rpn_level_fused_f32(x.data_ptr(), b, h, wd, cin, w_shared.data_ptr(), cout, _ptr(b_shared),
+                                        w_head32.data_ptr(), _ptr(b_head), int(head_n), ws.data_ptr(), ws_bytes,
+                                        y.data_ptr(), _stream()))
+    if prof is not None:
+        e1.record()
+        m = b * h * wd
+        flops = 2.0 * m * (9 * cin * cout + cout * head_n)  # shared 3x3 conv + both 1x1 heads
+        prof.append((e0, e1, flops, (m, cout, 9 * cin),
+                     4 * (x.numel() + w_shared.numel() + cout * head_n + y.numel())))
+    return y
+
+
+__all__ += ["rpn_level_fused"]

@@ -211,3 +211,23 @@ def test_bottleneck_module_dropin(dev):
     blk.train()
     with pytest.raises(RuntimeError):
         blk(x)
+
+
+def test_rpn_level_fused_vs_torch_cpu(dev):
+    """3x3 shared conv + ReLU + both 1x1 heads in one pass (shared activation kept on chip) vs torch CPU."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(12)
+    for (b, h, w) in [(2, 16, 12), (1, 5, 7), (1, 32, 32)]:
+        x = torch.randn(b, 256, h, w, generator=g)
+        ws = (torch.rand(512, 256, 3, 3, generator=g) * 2 - 1) * math.sqrt(6.0 / (256 * 9 + 512 * 9))
+        bs = torch.randn(512, generator=g) * 0.1
+        wh = torch.randn(18, 512, generator=g) * 0.05
+        bh = torch.randn(18, generator=g) * 0.1
+        t = F.relu(F.conv2d(F.pad(x, (1, 1, 1, 1)), ws, bs))
+        want = F.conv2d(t, wh.view(18, 512, 1, 1), bh).permute(0, 2, 3, 1)
+        w32 = torch.zeros(32, 512)
+        w32[:18] = wh
+        got = ops.rpn_level_fused(x.permute(0, 2, 3, 1).contiguous().to(dev),
+                                  ws.permute(0, 2, 3, 1).contiguous().to(dev), bs.to(dev), w32.to(dev), bh.to(dev))
+        err = (got.cpu() - want).abs().max().item()
+        assert err <= TOL, (b, h, w, err)
