@@ -19,28 +19,16 @@
 //               an activation tile is fetched into exactly one XCD's L2 and reused for every N tile/tap.
 //   epilogue    y = relu(acc*scale[c] + shift[c] + residual), residual optionally read at (oy/2, ox/2)
 //               (FPN nearest-neighbour upsample + add, model.py:150-152).
-#include "common.hpp"
+#include "conv_common.hpp"
 
 #include <cstdlib>
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+using namespace mrcnn_conv;
 
-struct ConvParams {
-    const float* x;
-    const float* w;
-    const float* scale;
-    const float* shift;
-    const float* residual;
-    float* y;
-    int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
-    int M, K;  // GEMM sizes
-    int res_div, act;  // act: 0 none, 1 ReLU, 2 sigmoid
-    int out_mode;      // 0: y[m][n]; 1: 2x2 stride-2 transposed-conv scatter, n = (dy*2+dx)*Cout/4 + co
-    int tiles_m, tiles_n;
-    unsigned x_bytes, w_bytes, y_bytes, r_bytes;  // buffer-descriptor ranges (< 4 GiB each)
+struct ConvParams : ConvCommon {
+    const float* w;  // [Cout][KH][KW][Cin]
     // RES == 5 (fused 1x1 heads): y is the per-N-tile partial [tiles_n][M][head_n]; w_head is [32][Cout]
     const float* w_head;
     int head_n;
@@ -65,14 +53,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
     float* As = smem;
     float* Bs = smem + 2 * BM * LDS_STRIDE;
 
-    // ---- tile mapping: XCD x owns M tiles [x*tiles_m/8, (x+1)*tiles_m/8), N fastest -----------------
-    const int t = blockIdx.x;
-    const int xcd = t & 7, seq = t >> 3;
-    const int mt_lo = (xcd * p.tiles_m) >> 3, mt_hi = ((xcd + 1) * p.tiles_m) >> 3;
-    const int mt = mt_lo + seq / p.tiles_n;
-    const int nt = seq % p.tiles_n;
-    if (mt >= mt_hi) return;
-    const int m0 = mt * BM, n0 = nt * BN;
+    int m0, n0, nt;
+    if (!tile_origin(p, BM, BN, m0, n0, nt)) return;  // XCD-aware tile order
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -80,22 +62,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
 
     // ---- per-thread row bookkeeping for the im2col gather ---------------------------------------------
     int a_off[PA], a_iy[PA], a_ix[PA];
-    const int ohw = p.OH * p.OW;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int m = m0 + r0 + RPP * i;
-        if (m < p.M) {
-            const int b = m / ohw, rem = m - b * ohw;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            a_iy[i] = oy * p.stride - p.pad_t;
-            a_ix[i] = ox * p.stride - p.pad_l;
-            a_off[i] = ((b * p.H + a_iy[i]) * p.W + a_ix[i]) * p.Cin;
-        } else {
-            a_iy[i] = -(1 << 24);  // never in range
-            a_ix[i] = 0;
-            a_off[i] = 0;
-        }
-    }
+    row_setup<PA, RPP>(p, m0, r0, a_off, a_iy, a_ix);
     int b_off[PB];
     bool b_ok[PB];
 #pragma unroll
@@ -114,7 +81,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
         const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
-    constexpr unsigned OOB = 0xFFFFFFF0u;
     auto bload = [](const __amdgpu_buffer_rsrc_t& r, unsigned byte_off) -> float4 {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(byte_off), 0, 0);
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
@@ -324,88 +290,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
         return;
     }
 
-    // ---- epilogue: affine + residual + ReLU, 128-byte channel runs per half-wave ------------------------
-    // Branch-free: stores and residual loads go through buffer descriptors, out-of-tile rows/channels get
-    // an out-of-range offset (loads return 0, stores are dropped). Per 32x32 accumulator tile the 16
-    // residual loads are issued together, then the 16 stores. RES: 0 none, 1 same size, 2 half size (FPN).
-    const int ln = lane & 31, lh = lane >> 5;
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.residual), 0, p.r_bytes, 0x00020000);
-    float sc[TN], sh[TN];
-    unsigned ncol[TN];  // byte offset of the lane's channel, or OOB
-#pragma unroll
-    for (int jn = 0; jn < TN; ++jn) {
-        const int n = n0 + wn * WTN + jn * 32 + ln;
-        const bool n_ok = n < p.Cout;
-        sc[jn] = (n_ok && p.scale) ? p.scale[n] : 1.0f;
-        sh[jn] = (n_ok && p.shift) ? p.shift[n] : 0.0f;
-        if constexpr (RES != 4) {
-            ncol[jn] = n_ok ? static_cast<unsigned>(n) * 4u : OOB;
-        } else {  // n = (dy*2 + dx)*cq + co  →  pixel (2i+dy, 2j+dx), channel co of the [B][2*OH][2*OW][cq] output
-            const int cq = p.Cout >> 2, q = n / cq, co = n - q * cq;
-            ncol[jn] = n_ok ? static_cast<unsigned>(((q >> 1) * 2 * p.OW + (q & 1)) * cq + co) * 4u : OOB;
-        }
-    }
-    const int rh = p.OH >> 1, rw = p.OW >> 1;
-    const unsigned row_bytes = static_cast<unsigned>(p.Cout) * 4u;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int mb = m0 + wm * WTM + i * 32 + 4 * lh;  // rows mb + (r&3) + 8*(r>>2)
-        unsigned yrow[16], rrow[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mb + (r & 3) + 8 * (r >> 2);
-            const bool ok = m < p.M;
-            if constexpr (RES != 4) {
-                yrow[r] = ok ? static_cast<unsigned>(m) * row_bytes : OOB;
-            } else {
-                const int mm = ok ? m : 0;
-                const int b = mm / ohw, rem = mm - b * ohw;
-                const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                yrow[r] = ok ? static_cast<unsigned>((b * 2 * p.OH + 2 * oy) * (2 * p.OW) + 2 * ox) *
-                                   (row_bytes >> 2)
-                             : OOB;
-            }
-            if constexpr (RES == 1) {
-                rrow[r] = yrow[r];
-            } else if constexpr (RES == 2) {
-                const int mm = ok ? m : 0;
-                const int b = mm / ohw, rem = mm - b * ohw;
-                const int oy = rem / p.OW, ox = rem - oy * p.OW;
-                rrow[r] = ok ? static_cast<unsigned>((b * rh + (oy >> 1)) * rw + (ox >> 1)) * row_bytes : OOB;
-            }
-        }
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
-            float rv[16];
-            if constexpr (RES == 1 || RES == 2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    // OOB in either term must stay OOB: saturating add via max
-                    const unsigned off = (rrow[r] | ncol[jn]) >= OOB ? OOB : rrow[r] + ncol[jn];
-                    rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, static_cast<int>(off), 0, 0));
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[i][jn][r] * sc[jn] + sh[jn];
-                if constexpr (RES == 1 || RES == 2) v += rv[r];
-                if constexpr (RES == 3) v = 1.0f / (1.0f + expf(-v));
-                else if (p.act) v = v > 0.f ? v : 0.f;
-                const unsigned off = (yrow[r] | ncol[jn]) >= OOB ? OOB : yrow[r] + ncol[jn];
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(off), 0, 0);
-            }
-        }
-    }
+    // ---- epilogue: affine + residual + activation (conv_common.hpp) -------------------------------------
+    if constexpr (RES != 5) epilogue<TM, TN, WTM, WTN, RES>(p, acc, m0, n0, wm, wn, lane);
 }
 
 template <int BM, int BN, int WM, int WN, int BK>
 int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
-    const int per_xcd = (p.tiles_m + 7) / 8;
-    const long long grid = 8LL * per_xcd * p.tiles_n;
+    const long long grid = tile_grid(p);
     if (grid > 0x7fffffffLL) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: grid too large");
     constexpr size_t lds = conv_lds_bytes<BM, BN, BK>();
     auto set_attr = [&](const void* f, bool& done) -> int {  // once per kernel instantiation
@@ -417,8 +310,7 @@ int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
         done = true;
         return MRCNN_OK;
     };
-    // epilogue variant: 0 plain, 1 / 2 residual (same size / half size), 3 sigmoid, 4 deconv-2x2 scatter
-    const int res = p.w_head ? 5 : p.out_mode == 1 ? 4 : (p.act == 2 ? 3 : (p.residual ? p.res_div : 0));
+    const int res = epilogue_variant(p, p.w_head != nullptr);
     static bool attr_done[2][6] = {};
     auto go = [&](auto kern) -> int {
         if (int rc = set_attr(reinterpret_cast<const void*>(kern), attr_done[generic ? 1 : 0][res])) return rc;
@@ -458,41 +350,14 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
                         const float* shift, const float* residual, int32_t res_div, int32_t relu,
                         int32_t out_mode, float* y, mrcnn_stream_t stream) {
     MRCNN_REQUIRE(x && w && y, "conv: null pointer");
-    MRCNN_REQUIRE(relu >= 0 && relu <= 2, "conv: activation must be 0 (none), 1 (ReLU) or 2 (sigmoid)");
-    MRCNN_REQUIRE(residual == nullptr || (relu != 2 && out_mode == 0),
-                  "conv: a residual cannot be combined with sigmoid or the deconv scatter");
-    MRCNN_REQUIRE(out_mode == 0 || relu != 2, "conv: deconv scatter supports activation 0 or 1");
-    MRCNN_REQUIRE(batch >= 1 && height >= 1 && width >= 1 && cin >= 4 && cin % 4 == 0 && cout >= 1,
-                  "conv: bad shape B=%d H=%d W=%d Cin=%d (Cin %% 4 == 0 required) Cout=%d", batch, height,
-                  width, cin, cout);
-    MRCNN_REQUIRE(kh >= 1 && kw >= 1 && stride >= 1 && pad_top >= 0 && pad_left >= 0 && pad_bottom >= 0 &&
-                      pad_right >= 0, "conv: bad kernel/stride/pad");
-    MRCNN_REQUIRE(residual == nullptr || res_div == 1 || res_div == 2, "conv: res_div must be 1 or 2");
     ConvParams p;
-    p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
-    p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw;
-    p.stride = stride; p.pad_t = pad_top; p.pad_l = pad_left;
-    p.OH = (height + pad_top + pad_bottom - kh) / stride + 1;
-    p.OW = (width + pad_left + pad_right - kw) / stride + 1;
-    MRCNN_REQUIRE(p.OH >= 1 && p.OW >= 1, "conv: empty output");
-    MRCNN_REQUIRE(residual == nullptr || res_div == 1 || (p.OH % 2 == 0 && p.OW % 2 == 0),
-                  "conv: res_div=2 needs even output size");
-    const long long M = 1LL * batch * p.OH * p.OW;
-    const long long K = 1LL * kh * kw * cin;
-    MRCNN_REQUIRE(1LL * batch * height * width * cin < (1LL << 30) && M * cout < (1LL << 30) &&
-                      K * cout < (1LL << 30) && M < (1LL << 31),
-                  "conv: tensor too large (each tensor < 2^30 elements: 32-bit buffer byte offsets)");
-    p.M = static_cast<int>(M);
-    p.K = static_cast<int>(K);
-    p.res_div = residual ? res_div : 1;
-    p.x_bytes = static_cast<unsigned>(4LL * batch * height * width * cin);
-    p.w_bytes = static_cast<unsigned>(4LL * K * cout);
-    p.y_bytes = static_cast<unsigned>(4LL * M * cout);
-    p.r_bytes = residual ? static_cast<unsigned>(4LL * M * cout / (p.res_div * p.res_div)) : 0u;
-    p.act = relu;  // 0 none, 1 ReLU, 2 sigmoid
-    p.out_mode = out_mode;
+    if (int rc = fill_common(p, "conv", x, batch, height, width, cin, 4, cout, kh, kw, stride, pad_top, pad_left,
+                             pad_bottom, pad_right, scale, shift, residual, res_div, relu, out_mode, y, 4))
+        return rc;
+    p.w = w;
     p.w_head = nullptr;
     p.head_n = 0;
+    const long long M = p.M;
     const bool generic = (cin % 32) != 0;
     hipStream_t s = mrcnn::as_stream(stream);
     static const int force = getenv("MRCNN_CONV_TILE") ? atoi(getenv("MRCNN_CONV_TILE")) : 0;  // tuning aid

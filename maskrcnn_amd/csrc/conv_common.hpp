@@ -1,0 +1,197 @@
+// Pieces shared by the two implicit-GEMM convolution kernels (conv.hip: exact-fp32 MFMA, conv_f16.hip:
+// fp16-operand MFMA): the problem description, tile order, im2col row bookkeeping and the epilogue.
+#pragma once
+#include "common.hpp"
+
+namespace mrcnn_conv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond every buffer descriptor's num_records
+
+// Everything about the convolution that does not depend on how the weights are stored.
+struct ConvCommon {
+    const float* x;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    float* y;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
+    int M, K;          // GEMM sizes: M = B*OH*OW, K = KH*KW*Cin
+    int res_div, act;  // act: 0 none, 1 ReLU (2 = sigmoid is the compile-time epilogue variant 3)
+    int out_mode;      // 0: y[m][n]; 1: 2x2 stride-2 transposed-conv scatter, n = (dy*2+dx)*Cout/4 + co
+    int tiles_m, tiles_n;
+    unsigned x_bytes, w_bytes, y_bytes, r_bytes;  // buffer-descriptor ranges (< 4 GiB each)
+};
+
+// Epilogue variants (template parameter RES of the kernels):
+//   0 plain, 1 residual of the output's size, 2 residual at half size (FPN nearest-upsample-add),
+//   3 sigmoid (no residual), 4 2x2 stride-2 transposed-conv scatter (no residual), 5 fused 1x1 heads (conv.hip)
+inline int epilogue_variant(const ConvCommon& p, bool fused_heads) {
+    return fused_heads ? 5 : p.out_mode == 1 ? 4 : (p.act == 2 ? 3 : (p.residual ? p.res_div : 0));
+}
+
+// XCD-aware tile order: XCD x (= blockIdx % 8) owns the M tiles [x*tiles_m/8, (x+1)*tiles_m/8) and walks N
+// fastest, so an activation tile is fetched into exactly one XCD's L2 and reused for every N tile / tap.
+__device__ __forceinline__ bool tile_origin(const ConvCommon& p, int BM, int BN, int& m0, int& n0, int& nt) {
+    const int t = blockIdx.x;
+    const int xcd = t & 7, seq = t >> 3;
+    const int mt_lo = (xcd * p.tiles_m) >> 3, mt_hi = ((xcd + 1) * p.tiles_m) >> 3;
+    const int mt = mt_lo + seq / p.tiles_n;
+    nt = seq % p.tiles_n;
+    if (mt >= mt_hi) return false;
+    m0 = mt * BM;
+    n0 = nt * BN;
+    return true;
+}
+inline long long tile_grid(const ConvCommon& p) { return 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n; }
+
+// im2col bookkeeping of the PA tile rows a thread stages: element offset of pixel (b, iy0, ix0) and the
+// (iy0, ix0) themselves for the zero-padding predicate; rows beyond M can never be in range.
+template <int PA, int RPP>
+__device__ __forceinline__ void row_setup(const ConvCommon& p, int m0, int r0, int (&a_off)[PA], int (&a_iy)[PA],
+                                          int (&a_ix)[PA]) {
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int m = m0 + r0 + RPP * i;
+        if (m < p.M) {
+            const int b = m / ohw, rem = m - b * ohw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            a_iy[i] = oy * p.stride - p.pad_t;
+            a_ix[i] = ox * p.stride - p.pad_l;
+            a_off[i] = ((b * p.H + a_iy[i]) * p.W + a_ix[i]) * p.Cin;
+        } else {
+            a_iy[i] = -(1 << 24);
+            a_ix[i] = 0;
+            a_off[i] = 0;
+        }
+    }
+}
+
+// Epilogue: act(acc*scale[c] + shift[c] (+ residual)) → y, 128-byte channel runs per half-wave. Branch-free:
+// stores and residual loads go through buffer descriptors; out-of-tile rows/channels get an out-of-range
+// offset (loads return 0, stores are dropped). Per 32x32 accumulator tile the 16 residual loads are issued
+// together, then the 16 stores.
+template <int TM, int TN, int WTM, int WTN, int RES>
+__device__ __forceinline__ void epilogue(const ConvCommon& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm,
+                                         int wn, int lane) {
+    static_assert(RES >= 0 && RES <= 4, "variant 5 (fused heads) lives in conv.hip");
+    const int ln = lane & 31, lh = lane >> 5;
+    const int ohw = p.OH * p.OW;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual), 0, p.r_bytes, 0x00020000);
+    float sc[TN], sh[TN];
+    unsigned ncol[TN];  // byte offset of the lane's channel, or OOB
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn * WTN + jn * 32 + ln;
+        const bool n_ok = n < p.Cout;
+        sc[jn] = (n_ok && p.scale) ? p.scale[n] : 1.0f;
+        sh[jn] = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+        if constexpr (RES != 4) {
+            ncol[jn] = n_ok ? static_cast<unsigned>(n) * 4u : OOB;
+        } else {  // n = (dy*2 + dx)*cq + co  →  pixel (2i+dy, 2j+dx), channel co of the [B][2*OH][2*OW][cq] output
+            const int cq = p.Cout >> 2, q = n / cq, co = n - q * cq;
+            ncol[jn] = n_ok ? static_cast<unsigned>(((q >> 1) * 2 * p.OW + (q & 1)) * cq + co) * 4u : OOB;
+        }
+    }
+    const int rh = p.OH >> 1, rw = p.OW >> 1;
+    const unsigned row_bytes = static_cast<unsigned>(p.Cout) * 4u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * WTM + i * 32 + 4 * lh;  // rows mb + (r&3) + 8*(r>>2)
+        unsigned yrow[16], rrow[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            const bool ok = m < p.M;
+            if constexpr (RES != 4) {
+                yrow[r] = ok ? static_cast<unsigned>(m) * row_bytes : OOB;
+            } else {
+                const int mm = ok ? m : 0;
+                const int b = mm / ohw, rem = mm - b * ohw;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                yrow[r] = ok ? static_cast<unsigned>((b * 2 * p.OH + 2 * oy) * (2 * p.OW) + 2 * ox) * (row_bytes >> 2)
+                             : OOB;
+            }
+            if constexpr (RES == 1) {
+                rrow[r] = yrow[r];
+            } else if constexpr (RES == 2) {
+                const int mm = ok ? m : 0;
+                const int b = mm / ohw, rem = mm - b * ohw;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                rrow[r] = ok ? static_cast<unsigned>((b * rh + (oy >> 1)) * rw + (ox >> 1)) * row_bytes : OOB;
+            }
+        }
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            float rv[16];
+            if constexpr (RES == 1 || RES == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // OOB in either term must stay OOB
+                    const unsigned off = (rrow[r] | ncol[jn]) >= OOB ? OOB : rrow[r] + ncol[jn];
+                    rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, static_cast<int>(off), 0, 0));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][jn][r] * sc[jn] + sh[jn];
+                if constexpr (RES == 1 || RES == 2) v += rv[r];
+                if constexpr (RES == 3) v = 1.0f / (1.0f + expf(-v));
+                else if (p.act) v = v > 0.f ? v : 0.f;
+                const unsigned off = (yrow[r] | ncol[jn]) >= OOB ? OOB : yrow[r] + ncol[jn];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(off), 0, 0);
+            }
+        }
+    }
+}
+
+// Host-side validation + fill of the common part; returns MRCNN_OK or sets the error message.
+inline int fill_common(ConvCommon& p, const char* who, const float* x, int batch, int height, int width, int cin,
+                       int cin_multiple, int cout, int kh, int kw, int stride, int pad_top, int pad_left,
+                       int pad_bottom, int pad_right, const float* scale, const float* shift, const float* residual,
+                       int res_div, int activation, int out_mode, float* y, int weight_elem_bytes) {
+    if (!(activation >= 0 && activation <= 2))
+        return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: activation must be 0 (none), 1 (ReLU) or 2 (sigmoid)", who);
+    if (residual && (activation == 2 || out_mode != 0))
+        return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: a residual cannot be combined with sigmoid or the deconv scatter", who);
+    if (out_mode != 0 && activation == 2)
+        return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: deconv scatter supports activation 0 or 1", who);
+    if (!(batch >= 1 && height >= 1 && width >= 1 && cin >= cin_multiple && cin % cin_multiple == 0 && cout >= 1))
+        return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: bad shape B=%d H=%d W=%d Cin=%d (Cin %% %d == 0 required) Cout=%d",
+                           who, batch, height, width, cin, cin_multiple, cout);
+    if (!(kh >= 1 && kw >= 1 && stride >= 1 && pad_top >= 0 && pad_left >= 0 && pad_bottom >= 0 && pad_right >= 0))
+        return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: bad kernel/stride/pad", who);
+    if (!(residual == nullptr || res_div == 1 || res_div == 2))
+        return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: res_div must be 1 or 2", who);
+    p.x = x; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw;
+    p.stride = stride; p.pad_t = pad_top; p.pad_l = pad_left;
+    p.OH = (height + pad_top + pad_bottom - kh) / stride + 1;
+    p.OW = (width + pad_left + pad_right - kw) / stride + 1;
+    if (!(p.OH >= 1 && p.OW >= 1)) return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: empty output", who);
+    if (!(residual == nullptr || res_div == 1 || (p.OH % 2 == 0 && p.OW % 2 == 0)))
+        return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: res_div=2 needs even output size", who);
+    const long long M = 1LL * batch * p.OH * p.OW;
+    const long long K = 1LL * kh * kw * cin;
+    if (!(1LL * batch * height * width * cin < (1LL << 30) && M * cout < (1LL << 30) && K * cout < (1LL << 30) &&
+          M < (1LL << 31)))
+        return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT,
+                           "%s: tensor too large (each tensor < 2^30 elements: 32-bit buffer byte offsets)", who);
+    p.M = static_cast<int>(M);
+    p.K = static_cast<int>(K);
+    p.res_div = residual ? res_div : 1;
+    p.act = activation;
+    p.out_mode = out_mode;
+    p.x_bytes = static_cast<unsigned>(4LL * batch * height * width * cin);
+    p.w_bytes = static_cast<unsigned>(1LL * weight_elem_bytes * K * cout);
+    p.y_bytes = static_cast<unsigned>(4LL * M * cout);
+    p.r_bytes = residual ? static_cast<unsigned>(4LL * M * cout / (p.res_div * p.res_div)) : 0u;
+    return MRCNN_OK;
+}
+
+}  // namespace mrcnn_conv
