@@ -235,6 +235,44 @@ int mrcnn_nchw_to_nhwc_f32(const float* x, int32_t batch, int32_t channels, int3
 int mrcnn_nhwc_to_nchw_f32(const float* x, int32_t batch, int32_t channels, int32_t height,
                            int32_t width, float* y, mrcnn_stream_t stream);
 
+/* ---- image pre-/post-processing around the hot path --------------------------------------
+ * The reference resizes 8-bit images through Pillow (scipy.misc.imresize, utils.py:73; torchvision Resize on a PIL
+ * image, data.py:277,295): BILINEAR with the support stretched by the scale factor when shrinking, 22-bit fixed-point
+ * coefficients, horizontal then vertical pass with an 8-bit intermediate. These entry points reproduce that
+ * arithmetic bit for bit.
+ *
+ * mrcnn_resize_bilinear_u8: n images of one size, src[i] [in_h][in_w][channels] interleaved uint8 at
+ *   src + i*src_image_stride with src_row_stride bytes between rows (so a crop of a larger image — transform.CenterCrop
+ *   before Resize in decode_masks, data.py:272-277 — needs no copy) -> dst n x [out_h][out_w][channels] contiguous,
+ *   each == numpy.array(Image.fromarray(src[i]).resize((out_w, out_h), Image.BILINEAR)). channels 1..4, sizes <= 16384. */
+size_t mrcnn_resize_u8_workspace_bytes(int32_t n, int32_t in_h, int32_t in_w, int32_t channels, int32_t out_h,
+                                       int32_t out_w);
+int mrcnn_resize_bilinear_u8(const uint8_t* src, int32_t n, int32_t in_h, int32_t in_w, int32_t channels,
+                             int64_t src_image_stride, int64_t src_row_stride, uint8_t* dst, int32_t out_h,
+                             int32_t out_w, void* workspace, size_t workspace_bytes, mrcnn_stream_t stream);
+/* Replaces utils.resize_image's resize + pad (utils.py:72-88), mold_image (model.py:1750-1754) and the HWC -> CHW
+ * float conversion of detect() (model.py:1108-1110) for one RGB image: src uint8 [in_h][in_w][3] is resized to
+ * new_h x new_w (no resample when that equals the input size), placed at (top, left) of a zero canvas out_h x out_w,
+ * and dst[c][y][x] = float(double(pixel) - mean_pixel[c]) (the reference subtracts a float64 MEAN_PIXEL array).
+ * The caller computes scale / new size / pads exactly as utils.py:56-85 does (host integers).
+ * workspace: mrcnn_resize_u8_workspace_bytes(1, in_h, in_w, 3, new_h, new_w) bytes; may be NULL when no resize. */
+int mrcnn_mold_image_u8(const uint8_t* src, int32_t in_h, int32_t in_w, int32_t new_h, int32_t new_w, int32_t top,
+                        int32_t left, int32_t out_h, int32_t out_w, const double mean_pixel[3], float* dst,
+                        void* workspace, size_t workspace_bytes, mrcnn_stream_t stream);
+/* Replaces datalib.full_masks (data.py:287-314). For detection i: the class_ids[i] channel of its mask_h x mask_w
+ * sigmoid mask (element (i,y,x,c) at masks[i*stride_n + y*stride_y + x*stride_x + c*stride_c], so both the
+ * reference's [N,C,h,w] and this library's [N,h,w,C] layouts are accepted) is multiplied by 255, converted to 8 bits
+ * (clamp, truncate: Image.fromarray(F).convert('L')), resized to the box's int(y2-y1) x int(x2-x1) and pasted at
+ * (int(y1), int(x1)) of a zero height x width canvas; out[i][y][x] = on_value where the 8-bit value > 127, else 0
+ * (on_value 1: the boolean mask of data.py:308; 255: the same mask as the 'L' image decode_masks starts from).
+ * Boxes the reference cannot paste (empty, or not inside the canvas: PIL raises) give an all-zero mask, as do
+ * class ids outside [0, num_classes) — so padded detection slots (class 0, zero box) cost nothing and stay empty.
+ * mask_h, mask_w <= 64; width % 4 == 0. */
+int mrcnn_paste_masks_u8(const float* masks, int64_t stride_n, int64_t stride_y, int64_t stride_x, int64_t stride_c,
+                         int32_t n, int32_t mask_h, int32_t mask_w, int32_t num_classes, const int64_t* class_ids,
+                         const float* boxes, int32_t height, int32_t width, int32_t on_value, uint8_t* out,
+                         mrcnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,13 @@ _SIGS = {
                                                     c_vp]),
     "mrcnn_nchw_to_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mrcnn_nhwc_to_nchw_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mrcnn_resize_u8_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "mrcnn_resize_bilinear_u8": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_vp, c_i32, c_i32,
+                                                  c_vp, ctypes.c_size_t, c_vp]),
+    "mrcnn_mold_image_u8": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                             ctypes.POINTER(ctypes.c_double), c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "mrcnn_paste_masks_u8": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp,
+                                              c_i32, c_i32, c_i32, c_vp, c_vp]),
 }
 
 

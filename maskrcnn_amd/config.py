@@ -28,6 +28,8 @@ class InferenceConfig:
     detection_nms_threshold: float = 0.3
     num_classes: int = 81
     mean_pixel: tuple = (123.7, 116.8, 103.9)
+    image_min_dim: int = 800            # config.py:145-149: resize so the short side is >= 800 (never shrink for it),
+    image_max_dim: int = 1024           #   the long side <= 1024, then zero-pad to the canvas (IMAGE_PADDING = True)
     backbone_shapes: list = field(init=False)
 
     def __post_init__(self):

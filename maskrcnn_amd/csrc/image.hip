@@ -1,0 +1,393 @@
+// Image pre-/post-processing either side of the hot path, on the GPU:
+//   resize_image + mold_image  (utils.py:42-90, model.py:1750-1754, :1102-1110)  uint8 HWC -> resized, centre-padded,
+//                              mean-subtracted fp32 CHW
+//   full_masks                 (data.py:287-314)  28x28 sigmoid masks -> full-size binary masks pasted at their boxes
+// Both reduce to Pillow's 8-bit BILINEAR resample (scipy.misc.imresize / torchvision Resize are thin wrappers over
+// Image.resize): double-precision triangle-filter coefficients with the support stretched by the scale factor when
+// shrinking, normalised, rounded to 22-bit fixed point; a horizontal pass into an 8-bit intermediate, then a vertical
+// pass, each (2^21 + sum in*k) >> 22 clamped to [0,255]. The coefficient arithmetic below follows that definition
+// operation by operation in fp64 (this file is compiled with -ffp-contract=off), so results are bit-identical to
+// Pillow's, which is what the tests check. All of it is byte/integer work bound by HBM traffic (and tiny).
+#include "common.hpp"
+
+namespace {
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;
+
+struct Axis {  // one resample direction
+    int in_size, out_size, ksize;
+    double scale, support, ss;  // ss = 1 / filterscale
+};
+
+Axis make_axis(int in_size, int out_size) {
+    Axis a;
+    a.in_size = in_size;
+    a.out_size = out_size;
+    double filterscale = a.scale = static_cast<double>(static_cast<float>(in_size)) / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    a.support = 1.0 * filterscale;  // BILINEAR support = 1.0
+    a.ksize = static_cast<int>(ceil(a.support)) * 2 + 1;
+    a.ss = 1.0 / filterscale;
+    return a;
+}
+
+__device__ __forceinline__ double tri(double x) {
+    if (x < 0.0) x = -x;
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+
+// Coefficients of output sample xx: first input tap, tap count, and k[0..ksize) (stride kstride ints).
+__device__ __forceinline__ void axis_coeffs(const Axis& a, int xx, int& xmin, int& cnt, int* k, int kstride) {
+    const double center = (xx + 0.5) * a.scale;
+    xmin = static_cast<int>(center - a.support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = static_cast<int>(center + a.support + 0.5);
+    if (xmax > a.in_size) xmax = a.in_size;
+    cnt = xmax - xmin;
+    double ww = 0.0;
+    for (int x = 0; x < cnt; ++x) ww += tri((x + xmin - center + 0.5) * a.ss);
+    for (int x = 0; x < cnt; ++x) {
+        double w = tri((x + xmin - center + 0.5) * a.ss);
+        if (ww != 0.0) w /= ww;
+        k[x * kstride] = static_cast<int>(0.5 + w * static_cast<double>(1 << PRECISION_BITS));
+    }
+    for (int x = cnt; x < a.ksize; ++x) k[x * kstride] = 0;
+}
+
+__device__ __forceinline__ unsigned clip8(int v) {
+    v >>= PRECISION_BITS;
+    return static_cast<unsigned>(v < 0 ? 0 : v > 255 ? 255 : v);
+}
+
+__global__ __launch_bounds__(256) void coeffs_kernel(const Axis a, int* __restrict__ bounds, int* __restrict__ kk) {
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (xx >= a.out_size) return;
+    int xmin, cnt;
+    axis_coeffs(a, xx, xmin, cnt, kk + static_cast<int64_t>(xx) * a.ksize, 1);
+    bounds[2 * xx] = xmin;
+    bounds[2 * xx + 1] = cnt;
+}
+
+// src n x [in_h][in_w][c] (image / row strides in bytes) -> tmp [n*in_h][out_w][c]
+__global__ __launch_bounds__(256) void resample_h_u8(const uint8_t* __restrict__ src, int n, int in_h, int c,
+                                                     int64_t image_stride, int64_t row_stride, int out_w,
+                                                     const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                     int ksize, uint8_t* __restrict__ tmp) {
+    const int64_t row = static_cast<int64_t>(out_w) * c, total = row * in_h * n;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int yg = static_cast<int>(e / row), r = static_cast<int>(e - yg * row);
+        const int img = yg / in_h, y = yg - img * in_h;
+        const int xx = r / c, ch = r - xx * c;
+        const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+        const int* k = kk + static_cast<int64_t>(xx) * ksize;
+        const uint8_t* s = src + img * image_stride + y * row_stride + static_cast<int64_t>(xmin) * c + ch;
+        int ss = 1 << (PRECISION_BITS - 1);
+        for (int x = 0; x < cnt; ++x) ss += s[static_cast<int64_t>(x) * c] * k[x];
+        tmp[e] = static_cast<uint8_t>(clip8(ss));
+    }
+}
+
+__device__ __forceinline__ unsigned resample_v_at(const uint8_t* __restrict__ tmp, int64_t row, int xe, int ymin,
+                                                  int cnt, const int* __restrict__ k) {
+    const uint8_t* s = tmp + ymin * row + xe;
+    int ss = 1 << (PRECISION_BITS - 1);
+    for (int y = 0; y < cnt; ++y) ss += s[y * row] * k[y];
+    return clip8(ss);
+}
+
+// tmp n x [in_h][row] -> dst n x [out_h][row], row = out_w*c
+__global__ __launch_bounds__(256) void resample_v_u8(const uint8_t* __restrict__ tmp, int64_t row, int n, int in_h,
+                                                     int out_h, const int* __restrict__ bounds,
+                                                     const int* __restrict__ kk, int ksize,
+                                                     uint8_t* __restrict__ dst) {
+    const int64_t total = row * out_h * n;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int yg = static_cast<int>(e / row), xe = static_cast<int>(e - yg * row);
+        const int img = yg / out_h, yy = yg - img * out_h;
+        dst[e] = static_cast<uint8_t>(resample_v_at(tmp + img * row * in_h, row, xe, bounds[2 * yy],
+                                                    bounds[2 * yy + 1], kk + static_cast<int64_t>(yy) * ksize));
+    }
+}
+
+// Vertical pass (or a plain read when RESIZE is false) fused with centre padding, mean subtraction and HWC -> CHW:
+// dst[ch][oy][ox] = float(double(pixel) - mean[ch]); pad pixels are 0 before the subtraction (utils.py:86,
+// model.py:1754: MEAN_PIXEL is a float64 array, so the reference subtracts in double and narrows afterwards).
+template <bool RESIZE>
+__global__ __launch_bounds__(256) void mold_kernel(const uint8_t* __restrict__ img, int new_h, int new_w, int top,
+                                                   int left, int out_h, int out_w, const int* __restrict__ bounds,
+                                                   const int* __restrict__ kk, int ksize, double m0, double m1,
+                                                   double m2, float* __restrict__ dst) {
+    const int64_t plane = static_cast<int64_t>(out_h) * out_w;
+    const int64_t row = static_cast<int64_t>(new_w) * 3;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < plane;
+         e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int oy = static_cast<int>(e / out_w), ox = static_cast<int>(e - static_cast<int64_t>(oy) * out_w);
+        const int yy = oy - top, xx = ox - left;
+        unsigned p0 = 0, p1 = 0, p2 = 0;
+        if (static_cast<unsigned>(yy) < static_cast<unsigned>(new_h) &&
+            static_cast<unsigned>(xx) < static_cast<unsigned>(new_w)) {
+            if constexpr (RESIZE) {
+                const int ymin = bounds[2 * yy], cnt = bounds[2 * yy + 1];
+                const int* k = kk + static_cast<int64_t>(yy) * ksize;
+                p0 = resample_v_at(img, row, xx * 3 + 0, ymin, cnt, k);
+                p1 = resample_v_at(img, row, xx * 3 + 1, ymin, cnt, k);
+                p2 = resample_v_at(img, row, xx * 3 + 2, ymin, cnt, k);
+            } else {
+                const uint8_t* s = img + yy * row + xx * 3;
+                p0 = s[0]; p1 = s[1]; p2 = s[2];
+            }
+        }
+        dst[e] = static_cast<float>(static_cast<double>(p0) - m0);
+        dst[plane + e] = static_cast<float>(static_cast<double>(p1) - m1);
+        dst[2 * plane + e] = static_cast<float>(static_cast<double>(p2) - m2);
+    }
+}
+
+struct ResizePlan {
+    Axis ah, av;
+    size_t off_bh, off_kh, off_bv, off_kv, total;  // tmp at offset 0
+};
+
+ResizePlan plan_resize(int n, int in_h, int in_w, int c, int out_h, int out_w) {
+    ResizePlan p;
+    p.ah = make_axis(in_w, out_w);
+    p.av = make_axis(in_h, out_h);
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    size_t o = up(static_cast<size_t>(n) * in_h * out_w * c);
+    p.off_bh = o; o += up(sizeof(int) * 2 * out_w);
+    p.off_kh = o; o += up(sizeof(int) * static_cast<size_t>(p.ah.ksize) * out_w);
+    p.off_bv = o; o += up(sizeof(int) * 2 * out_h);
+    p.off_kv = o; o += up(sizeof(int) * static_cast<size_t>(p.av.ksize) * out_h);
+    p.total = o;
+    return p;
+}
+
+unsigned blocks_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return static_cast<unsigned>(b < 1 ? 1 : b > 256 * 32 ? 256 * 32 : b);
+}
+
+// coefficient tables + horizontal pass; leaves the intermediate at workspace[0..)
+int run_horizontal(const uint8_t* src, int n, int in_h, int in_w, int c, int64_t image_stride, int64_t row_stride,
+                   int out_h, int out_w, const ResizePlan& p, unsigned char* ws, hipStream_t s) {
+    int* bh = reinterpret_cast<int*>(ws + p.off_bh);
+    int* kh = reinterpret_cast<int*>(ws + p.off_kh);
+    int* bv = reinterpret_cast<int*>(ws + p.off_bv);
+    int* kv = reinterpret_cast<int*>(ws + p.off_kv);
+    hipLaunchKernelGGL(coeffs_kernel, dim3((out_w + 255) / 256), dim3(256), 0, s, p.ah, bh, kh);
+    hipLaunchKernelGGL(coeffs_kernel, dim3((out_h + 255) / 256), dim3(256), 0, s, p.av, bv, kv);
+    hipLaunchKernelGGL(resample_h_u8, dim3(blocks_for(static_cast<int64_t>(n) * in_h * out_w * c)), dim3(256), 0, s,
+                       src, n, in_h, c, image_stride, row_stride, out_w, bh, kh, p.ah.ksize, ws);
+    return mrcnn::check_launch("resample_h_u8");
+}
+
+bool resize_args_ok(int in_h, int in_w, int c, int out_h, int out_w) {
+    return in_h >= 1 && in_w >= 1 && out_h >= 1 && out_w >= 1 && c >= 1 && c <= 4 && in_h <= 16384 && in_w <= 16384 &&
+           out_h <= 16384 && out_w <= 16384;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// full_masks: one workgroup per (detection, TILE_ROWS output rows). Tiles that miss the box are zero-filled; the
+// others stage the 8-bit mask, run the horizontal pass for the box's columns into LDS and the vertical pass for
+// their rows, threshold (> 127) and write 4 pixels per thread. Everything outside the box is 0.
+constexpr int TILE_ROWS = 32;
+
+struct PasteParams {
+    const float* masks;        // element (det, y, x, class) at det*sn + y*sy + x*sx + class*sc
+    int64_t sn, sy, sx, sc;
+    const int64_t* class_ids;  // [n]
+    const float* boxes;        // [n][4]
+    uint8_t* out;              // [n][H][W]
+    int mh, mw, C, H, W;
+    unsigned on_value;  // byte written where the resized mask > 127 (1: boolean view, 255: an 'L' image)
+    int off_hk, off_tmp, off_vb, off_vk;  // byte offsets into dynamic LDS (mask bytes at 0)
+};
+
+__global__ __launch_bounds__(256) void paste_masks_kernel(const PasteParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int det = blockIdx.y, row0 = blockIdx.x * TILE_ROWS;
+    const int row1 = min(row0 + TILE_ROWS, p.H);
+    const int tid = threadIdx.x;
+    const float* b = p.boxes + 4 * static_cast<int64_t>(det);
+    const double y1 = b[0], x1 = b[1], y2 = b[2], x2 = b[3];
+    const int bh = static_cast<int>(y2 - y1), bw = static_cast<int>(x2 - x1);  // data.py:295 int(box.height()), ...
+    const int top = static_cast<int>(y1), left = static_cast<int>(x1);         // :298,300
+    const int64_t cls = p.class_ids[det];
+    // boxes the reference cannot paste (empty, or not inside the canvas: PIL raises) give an all-zero mask
+    const bool valid = bh > 0 && bw > 0 && top >= 0 && left >= 0 && top + bh <= p.H && left + bw <= p.W &&
+                       cls >= 0 && cls < p.C;
+    uint8_t* out = p.out + static_cast<int64_t>(det) * p.H * p.W;
+    const int w4 = p.W >> 2;
+    if (!valid || row0 >= top + bh || row1 <= top) {
+        uint32_t* o = reinterpret_cast<uint32_t*>(out + static_cast<int64_t>(row0) * p.W);
+        const int n = (row1 - row0) * w4;
+        for (int i = tid; i < n; i += 256) o[i] = 0u;
+        return;
+    }
+    uint8_t* m8 = lds;
+    int* hk = reinterpret_cast<int*>(lds + p.off_hk);
+    uint8_t* tmp = lds + p.off_tmp;  // [mh][bw]
+    int* vb = reinterpret_cast<int*>(lds + p.off_vb);
+    int* vk = reinterpret_cast<int*>(lds + p.off_vk);
+
+    // mask channel * 255.0 (fp32, data.py:291) -> 'L' (Pillow f2l: clamp, truncate)
+    const float* msrc = p.masks + det * p.sn + cls * p.sc;
+    for (int i = tid; i < p.mh * p.mw; i += 256) {
+        const int my = i / p.mw, mx = i - my * p.mw;
+        const float v = msrc[my * p.sy + mx * p.sx] * 255.0f;
+        m8[i] = v <= 0.0f ? 0 : v >= 255.0f ? 255 : static_cast<uint8_t>(v);
+    }
+    // vertical coefficients of this tile's rows
+    Axis av;
+    av.in_size = p.mh; av.out_size = bh;
+    {
+        double fs = av.scale = static_cast<double>(static_cast<float>(p.mh)) / bh;
+        if (fs < 1.0) fs = 1.0;
+        av.support = fs; av.ksize = static_cast<int>(ceil(fs)) * 2 + 1; av.ss = 1.0 / fs;
+    }
+    Axis ah;
+    ah.in_size = p.mw; ah.out_size = bw;
+    {
+        double fs = ah.scale = static_cast<double>(static_cast<float>(p.mw)) / bw;
+        if (fs < 1.0) fs = 1.0;
+        ah.support = fs; ah.ksize = static_cast<int>(ceil(fs)) * 2 + 1; ah.ss = 1.0 / fs;
+    }
+    if (tid < TILE_ROWS) {
+        const int yy = row0 + tid - top;
+        int ymin = 0, cnt = 0;
+        if (yy >= 0 && yy < bh) axis_coeffs(av, yy, ymin, cnt, vk + tid * av.ksize, 1);
+        vb[2 * tid] = ymin;
+        vb[2 * tid + 1] = cnt;
+    }
+    __syncthreads();
+    // horizontal pass, a thread per box column (its coefficients live in its own LDS slot)
+    for (int x0 = 0; x0 < bw; x0 += 256) {
+        const int xx = x0 + tid;
+        if (xx < bw) {
+            int* k = hk + tid * ah.ksize;
+            int xmin, cnt;
+            axis_coeffs(ah, xx, xmin, cnt, k, 1);
+            for (int r = 0; r < p.mh; ++r) {
+                const uint8_t* s = m8 + r * p.mw + xmin;
+                int ss = 1 << (PRECISION_BITS - 1);
+                for (int x = 0; x < cnt; ++x) ss += s[x] * k[x];
+                tmp[r * bw + xx] = static_cast<uint8_t>(clip8(ss));
+            }
+        }
+    }
+    __syncthreads();
+    // vertical pass + threshold, 4 pixels per thread
+    for (int i = tid; i < (row1 - row0) * w4; i += 256) {
+        const int rr = i / w4, x4 = (i - rr * w4) * 4;
+        const int ymin = vb[2 * rr], cnt = vb[2 * rr + 1];
+        const int* k = vk + rr * av.ksize;
+        uint32_t packed = 0;
+        if (cnt > 0 && x4 + 3 >= left && x4 < left + bw) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = x4 + j - left;
+                if (xx >= 0 && xx < bw) {
+                    const uint8_t* s = tmp + ymin * bw + xx;
+                    int ss = 1 << (PRECISION_BITS - 1);
+                    for (int y = 0; y < cnt; ++y) ss += s[y * bw] * k[y];
+                    if (clip8(ss) > 127u) packed |= p.on_value << (8 * j);  // data.py:308 mask > 127
+                }
+            }
+        }
+        reinterpret_cast<uint32_t*>(out + static_cast<int64_t>(row0 + rr) * p.W)[x4 >> 2] = packed;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t mrcnn_resize_u8_workspace_bytes(int32_t n, int32_t in_h, int32_t in_w, int32_t channels,
+                                                  int32_t out_h, int32_t out_w) {
+    if (n < 1 || !resize_args_ok(in_h, in_w, channels, out_h, out_w)) return 0;
+    return plan_resize(n, in_h, in_w, channels, out_h, out_w).total;
+}
+
+extern "C" int mrcnn_resize_bilinear_u8(const uint8_t* src, int32_t n, int32_t in_h, int32_t in_w, int32_t channels,
+                                        int64_t src_image_stride, int64_t src_row_stride, uint8_t* dst,
+                                        int32_t out_h, int32_t out_w, void* workspace, size_t workspace_bytes,
+                                        mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(src && dst && workspace, "resize_u8: null pointer");
+    MRCNN_REQUIRE(n >= 1 && n <= 65536, "resize_u8: n=%d", n);
+    MRCNN_REQUIRE(src_row_stride >= static_cast<int64_t>(in_w) * channels && src_image_stride >= 0,
+                  "resize_u8: row stride %lld shorter than a row", static_cast<long long>(src_row_stride));
+    MRCNN_REQUIRE(resize_args_ok(in_h, in_w, channels, out_h, out_w),
+                  "resize_u8: bad shape %dx%dx%d -> %dx%d (sizes 1..16384, channels 1..4)", in_h, in_w, channels, out_h,
+                  out_w);
+    const ResizePlan p = plan_resize(n, in_h, in_w, channels, out_h, out_w);
+    MRCNN_REQUIRE(workspace_bytes >= p.total, "resize_u8: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+    hipStream_t s = mrcnn::as_stream(stream);
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    if (int rc = run_horizontal(src, n, in_h, in_w, channels, src_image_stride, src_row_stride, out_h, out_w, p, ws, s))
+        return rc;
+    const int64_t row = static_cast<int64_t>(out_w) * channels;
+    hipLaunchKernelGGL(resample_v_u8, dim3(blocks_for(row * out_h * n)), dim3(256), 0, s, ws, row, n, in_h, out_h,
+                       reinterpret_cast<const int*>(ws + p.off_bv), reinterpret_cast<const int*>(ws + p.off_kv),
+                       p.av.ksize, dst);
+    return mrcnn::check_launch("resample_v_u8");
+}
+
+extern "C" int mrcnn_mold_image_u8(const uint8_t* src, int32_t in_h, int32_t in_w, int32_t new_h, int32_t new_w,
+                                   int32_t top, int32_t left, int32_t out_h, int32_t out_w, const double mean_pixel[3],
+                                   float* dst, void* workspace, size_t workspace_bytes, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(src && dst && mean_pixel, "mold_image: null pointer");
+    MRCNN_REQUIRE(resize_args_ok(in_h, in_w, 3, new_h, new_w) && out_h >= 1 && out_w >= 1 && out_h <= 16384 &&
+                      out_w <= 16384, "mold_image: bad shape");
+    MRCNN_REQUIRE(top >= 0 && left >= 0 && top + new_h <= out_h && left + new_w <= out_w,
+                  "mold_image: the resized image (%dx%d at %d,%d) does not fit the %dx%d output", new_h, new_w, top,
+                  left, out_h, out_w);
+    hipStream_t s = mrcnn::as_stream(stream);
+    const unsigned grid = blocks_for(static_cast<int64_t>(out_h) * out_w);
+    if (new_h == in_h && new_w == in_w) {  // scale == 1 (utils.py:72): no resample at all
+        hipLaunchKernelGGL(mold_kernel<false>, dim3(grid), dim3(256), 0, s, src, new_h, new_w, top, left, out_h, out_w,
+                           nullptr, nullptr, 0, mean_pixel[0], mean_pixel[1], mean_pixel[2], dst);
+        return mrcnn::check_launch("mold_kernel");
+    }
+    const ResizePlan p = plan_resize(1, in_h, in_w, 3, new_h, new_w);
+    MRCNN_REQUIRE(workspace && workspace_bytes >= p.total, "mold_image: workspace too small (%zu < %zu)",
+                  workspace_bytes, p.total);
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    if (int rc = run_horizontal(src, 1, in_h, in_w, 3, 0, static_cast<int64_t>(in_w) * 3, new_h, new_w, p, ws, s))
+        return rc;
+    hipLaunchKernelGGL(mold_kernel<true>, dim3(grid), dim3(256), 0, s, ws, new_h, new_w, top, left, out_h, out_w,
+                       reinterpret_cast<const int*>(ws + p.off_bv), reinterpret_cast<const int*>(ws + p.off_kv),
+                       p.av.ksize, mean_pixel[0], mean_pixel[1], mean_pixel[2], dst);
+    return mrcnn::check_launch("mold_kernel");
+}
+
+extern "C" int mrcnn_paste_masks_u8(const float* masks, int64_t stride_n, int64_t stride_y, int64_t stride_x,
+                                    int64_t stride_c, int32_t n, int32_t mask_h, int32_t mask_w,
+                                    int32_t num_classes, const int64_t* class_ids, const float* boxes, int32_t height,
+                                    int32_t width, int32_t on_value, uint8_t* out, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(n >= 0, "paste_masks: n=%d", n);
+    MRCNN_REQUIRE(on_value >= 1 && on_value <= 255, "paste_masks: on_value=%d must be in [1,255]", on_value);
+    if (n == 0) return MRCNN_OK;
+    MRCNN_REQUIRE(masks && class_ids && boxes && out, "paste_masks: null pointer");
+    MRCNN_REQUIRE(mask_h >= 1 && mask_w >= 1 && mask_h <= 64 && mask_w <= 64 && num_classes >= 1,
+                  "paste_masks: mask %dx%d (1..64), classes %d", mask_h, mask_w, num_classes);
+    MRCNN_REQUIRE(height >= 1 && width >= 4 && width % 4 == 0 && height <= 16384 && width <= 16384 && n <= 65535,
+                  "paste_masks: canvas %dx%d (width %% 4 == 0 required), n=%d (<= 65535)", height, width, n);
+    PasteParams p;
+    p.masks = masks; p.sn = stride_n; p.sy = stride_y; p.sx = stride_x; p.sc = stride_c; p.class_ids = class_ids; p.boxes = boxes; p.out = out;
+    p.mh = mask_h; p.mw = mask_w; p.C = num_classes; p.H = height; p.W = width;
+    p.on_value = static_cast<unsigned>(on_value);
+    auto up = [](int v) { return (v + 15) & ~15; };
+    int o = up(mask_h * mask_w);
+    p.off_hk = o;
+    // per-thread coefficient slots of one 256-column chunk: ksize 3 when enlarging (<= 256*3 ints); when shrinking
+    // there are bw < mask_w columns of ksize <= 2*ceil(mask_w/bw)+1 taps: bw*ksize <= 5*mask_w ints
+    o += up(4 * (256 * 3 > 5 * mask_w ? 256 * 3 : 5 * mask_w));
+    p.off_tmp = o; o += up(mask_h * width);
+    p.off_vb = o; o += up(4 * 2 * TILE_ROWS);
+    p.off_vk = o; o += up(4 * TILE_ROWS * (2 * mask_h + 1));
+    MRCNN_REQUIRE(o <= 64 * 1024, "paste_masks: canvas width %d with %dx%d masks needs %d bytes of LDS (> 64 KiB)",
+                  width, mask_h, mask_w, o);
+    hipStream_t s = mrcnn::as_stream(stream);
+    hipLaunchKernelGGL(paste_masks_kernel, dim3((height + TILE_ROWS - 1) / TILE_ROWS, n), dim3(256), o, s, p);
+    return mrcnn::check_launch("paste_masks_kernel");
+}

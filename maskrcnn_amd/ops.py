@@ -486,3 +486,86 @@ def rpn_level_fused(x, w_shared, b_shared, w_head32, b_head, head_n: int = 18) -
 
 
 __all__ += ["rpn_level_fused"]
+
+
+# --------------------------------------------------------------------------------------------------
+# image pre-/post-processing (Pillow-exact 8-bit bilinear resample)
+# --------------------------------------------------------------------------------------------------
+def resize_bilinear_u8(image: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+    """uint8 [H,W], [H,W,C] (C <= 4) or a batch [N,H,W] of single-channel images (rows contiguous; image and row
+    strides free, so a cropped view needs no copy) → uint8 of the same rank at out_h x out_w; every image
+    == Image.fromarray(a).resize((out_w, out_h), Image.BILINEAR)."""
+    _need_gpu(image)
+    if image.dtype != torch.uint8 or image.dim() not in (2, 3):
+        raise RuntimeError(f"resize_bilinear_u8: expected a uint8 2-d or 3-d tensor, got {image.dtype} {tuple(image.shape)}")
+    a = image
+    if a.dim() == 3 and a.size(2) <= 4 and a.stride(2) == 1 and a.stride(1) == a.size(2):   # [H,W,C] interleaved
+        n, h, w, c = 1, a.size(0), a.size(1), a.size(2)
+        image_stride, row_stride = 0, a.stride(0)
+        out_shape = (out_h, out_w, c)
+    elif a.dim() == 2:
+        if a.stride(1) != 1:
+            a = a.contiguous()
+        n, h, w, c = 1, a.size(0), a.size(1), 1
+        image_stride, row_stride = 0, a.stride(0)
+        out_shape = (out_h, out_w)
+    else:                                                                                     # [N,H,W]
+        if a.stride(2) != 1:
+            a = a.contiguous()
+        n, h, w, c = a.size(0), a.size(1), a.size(2), 1
+        image_stride, row_stride = a.stride(0), a.stride(1)
+        out_shape = (n, out_h, out_w)
+    if out_h < 1 or out_w < 1:
+        raise ValueError("height and width must be > 0")       # PIL's message for an empty size
+    out = torch.empty(out_shape, dtype=torch.uint8, device=a.device)
+    if n == 0:
+        return out
+    nbytes = int(lib.mrcnn_resize_u8_workspace_bytes(n, h, w, c, out_h, out_w))
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=a.device)
+    check(lib.mrcnn_resize_bilinear_u8(a.data_ptr(), n, h, w, c, image_stride, row_stride, out.data_ptr(), out_h,
+                                       out_w, ws.data_ptr(), nbytes, _stream()))
+    return out
+
+
+def mold_image_u8(image: torch.Tensor, new_h: int, new_w: int, top: int, left: int, out: torch.Tensor,
+                  mean_pixel) -> None:
+    """uint8 RGB [h,w,3] → out fp32 [3,H,W] (one slot of the batch): resize to new_h x new_w, paste at (top,left) of a
+    zero canvas, subtract mean_pixel in double, HWC → CHW. One call replaces utils.py:72-88 + model.py:1754,1108."""
+    _need_gpu(image, out)
+    if image.dtype != torch.uint8 or image.dim() != 3 or image.size(2) != 3:
+        raise RuntimeError(f"mold_image_u8: expected uint8 [h,w,3], got {image.dtype} {tuple(image.shape)}")
+    assert out.dtype == torch.float32 and out.dim() == 3 and out.size(0) == 3 and out.is_contiguous()
+    a = image.contiguous()
+    h, w = a.shape[:2]
+    nbytes, ws = 0, None
+    if (new_h, new_w) != (h, w):
+        nbytes = int(lib.mrcnn_resize_u8_workspace_bytes(1, h, w, 3, new_h, new_w))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=a.device)
+    mean = (ctypes.c_double * 3)(*[float(m) for m in mean_pixel])
+    check(lib.mrcnn_mold_image_u8(a.data_ptr(), h, w, new_h, new_w, top, left, out.size(1), out.size(2), mean,
+                                  out.data_ptr(), _ptr(ws), nbytes, _stream()))
+
+
+def paste_masks(masks: torch.Tensor, class_ids: torch.Tensor, boxes: torch.Tensor, height: int, width: int,
+                channels_last: bool, as_l8: bool = False) -> torch.Tensor:
+    """datalib.full_masks (data.py:287-314) for N detections in one launch → bool [N,height,width] (as_l8: the same
+    mask as a uint8 0/255 'L' image, what decode_masks converts it to before resizing, data.py:271).
+    masks fp32 [N,C,mh,mw] (channels_last=False, the reference layout) or [N,mh,mw,C] (True), any strides;
+    class_ids int64 [N]; boxes fp32 [N,4] pixel (y1,x1,y2,x2)."""
+    _need_gpu(masks, class_ids, boxes)
+    if masks.dtype != torch.float32 or masks.dim() != 4:
+        raise RuntimeError(f"paste_masks: expected fp32 4-d masks, got {masks.dtype} {tuple(masks.shape)}")
+    n = masks.size(0)
+    if channels_last:
+        mh, mw, c = masks.shape[1:]
+        sn, sy, sx, sc = masks.stride()
+    else:
+        c, mh, mw = masks.shape[1:]
+        sn, sc, sy, sx = masks.stride()
+    class_ids = class_ids.to(torch.int64).contiguous()
+    boxes = boxes.to(torch.float32).contiguous()
+    assert class_ids.numel() == n and tuple(boxes.shape) == (n, 4)
+    out = torch.empty(n, height, width, dtype=torch.uint8, device=masks.device)
+    check(lib.mrcnn_paste_masks_u8(masks.data_ptr(), sn, sy, sx, sc, n, mh, mw, c, class_ids.data_ptr(),
+                                   boxes.data_ptr(), height, width, 255 if as_l8 else 1, out.data_ptr(), _stream()))
+    return out if as_l8 else out.view(torch.bool)

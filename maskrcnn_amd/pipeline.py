@@ -19,6 +19,7 @@ from dataclasses import dataclass
 
 import torch
 
+from . import image as imagelib
 from . import modules, ops
 from .anchors import pyramid_anchors
 from .config import InferenceConfig
@@ -163,3 +164,34 @@ class MaskRCNNInference:
             return det, dict(feature_maps=fms, rpn_scores=scores, rpn_deltas=deltas, rois=rois,
                              roi_counts=roi_counts, rpn_dets=rpn_dets, logits=logits, bbox=bbox)
         return det
+
+    # ---------------------------------------------------------------- images in, full-size masks out
+    @torch.no_grad()
+    def detect(self, images):
+        """MaskRCNN.detect (model.py:1095-1138) for a list of RGB uint8 [h,w,3] images of any sizes: resize + pad +
+        mean-subtract on the GPU (utils.resize_image, mold_image), predict, paste the masks at full size
+        (datalib.full_masks, which the reference calls inside predict, model.py:1190) and map boxes and masks back
+        to each original image (decode_boxes / decode_masks). One host synchronisation, at the end, to size the
+        per-image results. → per image (class_ids [n], scores [n], boxes [n,4], masks [n,h',w']) device tensors, or
+        (None, None, None, None) when nothing was detected (model.py:1119-1120). The reference returns Python
+        lists (:1132-1135); masks are bool when scale == 1 and uint8 grey levels otherwise, as in the reference."""
+        c = self.cfg
+        molded, windows, metas = imagelib.mold_inputs(images, c, self.device)
+        det = self.predict(molded, windows)
+        counts = det.counts.tolist()
+        results = []
+        for b, n in enumerate(counts):
+            if n == 0:
+                results.append((None, None, None, None))
+                continue
+            scale, _, _ = metas[b]
+            window = tuple(int(v) for v in windows[b])
+            ids, scores, boxes = det.class_ids[b, :n], det.scores[b, :n], det.boxes[b, :n]
+            m28 = det.masks[b, :n]                                             # [n,28,28,C] NHWC
+            if scale == 1:
+                masks = ops.paste_masks(m28, ids, boxes, c.image_height, c.image_width, channels_last=True)
+            else:
+                l8 = ops.paste_masks(m28, ids, boxes, c.image_height, c.image_width, channels_last=True, as_l8=True)
+                masks = imagelib.decode_masks(l8, scale, window)
+            results.append((ids, scores, imagelib.decode_boxes(boxes, scale, window), masks))
+        return results

@@ -6,7 +6,9 @@ checker — the product (maskrcnn_amd/, maskrcnn/) never does and fails loudly w
 
 Two layers:
   * native ops  — ctypes bindings to oracle/liboracle.so, the plain-C restatement of
-                  c++ext/maskrcnn/csrc/cpu/{nms_cpu.cpp,crop_cpu.cpp} (nms_ref.c / crop_ref.c).
+                  c++ext/maskrcnn/csrc/cpu/{nms_cpu.cpp,crop_cpu.cpp} (nms_ref.c / crop_ref.c) and of Pillow's
+                  8-bit bilinear resample (resample_ref.c: the third-party arithmetic behind utils.resize_image
+                  and data.full_masks; pinned against Pillow itself).
   * graph level — torch-CPU fp32 functional restatement of the model.py / data.py / utils.py pieces on
                   the path (each function cites the reference lines it follows). torch is used here as
                   the floating-point reference for conv/BN/etc. (fp32, CPU).
@@ -34,7 +36,7 @@ _lib = None
 
 def build() -> str:
     """Compile liboracle.so (gcc, seconds). Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("nms_ref.c", "crop_ref.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("nms_ref.c", "crop_ref.c", "resample_ref.c", "Makefile")]
     if (not os.path.exists(_LIB_PATH)
             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs)):
         subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True,
@@ -56,6 +58,15 @@ def _load():
         lib.oracle_crop_forward_f32.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, f32, i32, i32, vp]
         lib.oracle_crop_backward_f32.restype = ctypes.c_int
         lib.oracle_crop_backward_f32.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        lib.oracle_resample_ksize.restype = ctypes.c_int
+        lib.oracle_resample_ksize.argtypes = [ctypes.c_int, ctypes.c_int]
+        lib.oracle_resample_coeffs.restype = ctypes.c_int
+        lib.oracle_resample_coeffs.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp]
+        lib.oracle_resize_bilinear_u8.restype = ctypes.c_int
+        lib.oracle_resize_bilinear_u8.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int,
+                                                  ctypes.c_int]
+        lib.oracle_f32_to_l8.restype = None
+        lib.oracle_f32_to_l8.argtypes = [vp, i64, vp]
         _lib = lib
     return _lib
 
@@ -452,3 +463,118 @@ def predict(image, window, sd, cfg: Cfg, arch="resnet101", anchors=None):
         h = int(cfg.IMAGE_SHAPE[0])
         out["masks"] = mask_forward(fms[:4], boxes.float() * 1.0 / h, sd, cfg)  # :1188 (÷h only)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# image pre-/post-processing: utils.resize_image, model.mold_image, data.full_masks
+# ------------------------------------------------------------------------------------------------------
+def resample_coeffs(in_size: int, out_size: int):
+    """Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc (BILINEAR) → bounds [out,2], kk [out,ksize] int32."""
+    lib = _load()
+    ks = lib.oracle_resample_ksize(in_size, out_size)
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ks), dtype=np.int32)
+    got = lib.oracle_resample_coeffs(in_size, out_size, bounds.ctypes.data, kk.ctypes.data)
+    assert got == ks
+    return bounds, kk
+
+
+def pil_resize_u8(image: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """Image.fromarray(image).resize((out_w, out_h), Image.BILINEAR) for uint8 [H,W] or [H,W,C] arrays."""
+    a = np.ascontiguousarray(image, dtype=np.uint8)
+    squeeze = a.ndim == 2
+    if squeeze:
+        a = a[:, :, None]
+    h, w, c = a.shape
+    out = np.empty((out_h, out_w, c), dtype=np.uint8)
+    rc = _load().oracle_resize_bilinear_u8(a.ctypes.data, h, w, c, out.ctypes.data, out_h, out_w)
+    if rc != 0:
+        raise ValueError("height and width must be > 0")      # PIL's error for an empty size
+    return out[:, :, 0] if squeeze else out
+
+
+def f32_to_l8(a: np.ndarray) -> np.ndarray:
+    """Image.fromarray(float32 array).convert('L'): clamp to [0,255], truncate (Pillow Convert.c f2l)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty(a.shape, dtype=np.uint8)
+    _load().oracle_f32_to_l8(a.ctypes.data, a.size, out.ctypes.data)
+    return out
+
+
+def resize_image(image: np.ndarray, min_dim=None, max_dim=None, padding=False):
+    """utils.py:42-90, with scipy.misc.imresize(image, (h, w)) restated as the PIL bilinear resize it wraps.
+    image uint8 [h,w,3] → (image, window (y1,x1,y2,x2), scale, padding)."""
+    h, w = image.shape[:2]
+    window = (0, 0, h, w)
+    scale = 1
+    if min_dim:
+        scale = max(1, min_dim / min(h, w))                    # :62-64 scale up but not down
+    if max_dim:
+        image_max = max(h, w)
+        if round(image_max * scale) > max_dim:                 # :67-69
+            scale = max_dim / image_max
+    if scale != 1:
+        image = pil_resize_u8(image, round(h * scale), round(w * scale))   # :72-74 (Python round: half-to-even)
+    if padding:
+        h, w = image.shape[:2]
+        top_pad = (max_dim - h) // 2                           # :79-84
+        bottom_pad = max_dim - h - top_pad
+        left_pad = (max_dim - w) // 2
+        right_pad = max_dim - w - left_pad
+        padding = [(top_pad, bottom_pad), (left_pad, right_pad), (0, 0)]
+        image = np.pad(image, padding, mode="constant", constant_values=0)
+        window = (top_pad, left_pad, h + top_pad, w + left_pad)
+    return image, window, scale, padding
+
+
+def mold_image(image: np.ndarray, mean_pixel) -> torch.Tensor:
+    """model.py:1750-1754 + :1108-1110: float32(image) - MEAN_PIXEL (a float64 array, so the subtraction is in
+    double), HWC → [1,3,H,W], .float()."""
+    molded = image.astype(np.float32) - np.asarray(mean_pixel, dtype=np.float64)
+    return torch.from_numpy(molded.transpose(2, 0, 1)).float().unsqueeze(0)
+
+
+def full_masks(class_id: torch.Tensor, boxes: torch.Tensor, masks: torch.Tensor, height: int, width: int):
+    """data.py:287-314. class_id [N], boxes [N,4] pixel (y1,x1,y2,x2), masks [N,C,mh,mw] → bool [N,height,width].
+    transform.Resize((bh, bw)) / transform.Pad restated as the PIL calls they wrap."""
+    out = []
+    for i in range(class_id.size(0)):
+        mask = (masks[i][int(class_id[i].item())] * 255.0).cpu().numpy()      # :291
+        y1, x1, y2, x2 = boxes[i].tolist()
+        img = f32_to_l8(mask)                                                  # :294 fromarray(F).convert('L')
+        img = pil_resize_u8(img, int(y2 - y1), int(x2 - x1))                   # :295
+        top, left = int(y1), int(x1)                                           # :298-303
+        full = np.zeros((height, width), dtype=np.uint8)
+        full[top:top + img.shape[0], left:left + img.shape[1]] = img           # :305 transform.Pad, fill 0
+        out.append(torch.from_numpy(full) > 127)                               # :307-308
+    return torch.stack(out, dim=0)
+
+
+def decode_boxes(boxes: torch.Tensor, scale, window) -> torch.Tensor:
+    """data.py:331-343."""
+    if scale == 1:
+        return boxes
+    boxes = boxes.clone()
+    boxes[:, 0] -= window[0]
+    boxes[:, 1] -= window[1]
+    boxes[:, 2] -= window[0]
+    boxes[:, 3] -= window[1]
+    s = 1.0 / (scale + 1e-5)
+    return boxes * torch.Tensor([s, s, s, s])
+
+
+def decode_masks(masks: torch.Tensor, scale, window):
+    """data.py:264-284. masks bool [N,H,W] → uint8 [N,nh,nw] grey levels (bool array → PIL mode '1' → 'L' 0/255,
+    torchvision CenterCrop to the window's size, Resize by 1/scale)."""
+    if scale == 1:
+        return masks
+    out = []
+    th, tw = window[2] - window[0], window[3] - window[1]
+    for i in range(masks.size(0)):
+        img = masks[i].cpu().numpy().astype(np.uint8) * 255                    # :271
+        h, w = img.shape
+        i0, j0 = int(round((h - th) / 2.0)), int(round((w - tw) / 2.0))        # :272 CenterCrop
+        img = img[i0:i0 + th, j0:j0 + tw]
+        nh, nw = round(img.shape[0] * 1.0 / scale), round(img.shape[1] * 1.0 / scale)   # :275-276
+        out.append(torch.from_numpy(pil_resize_u8(img, nh, nw)))               # :277
+    return torch.stack(out, dim=0)

@@ -10,7 +10,7 @@ Sources of truth used here (nothing of theirs is copied into the repo — only i
     c++ext/maskrcnn/__init__.py:21-45 does (that file's legacy autograd.Function cannot run on
     torch >= 1.5).
 
-Usage:  python tests/golden/make_golden.py [nms crop roi_align anchors graph refine schema]
+Usage:  python tests/golden/make_golden.py [nms crop roi_align anchors graph refine schema image]
         (no argument: rewrite every fixture; deterministic)
 """
 import contextlib
@@ -406,6 +406,111 @@ def gen_schema(rconfig, rmodel):
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+def gen_image(rconfig, rutils, rmodel, rdata):
+    """Pre-/post-processing around predict. The pixel arithmetic is Pillow's (third-party,
+    installed here: the version is stored in the fixture); the two wrappers the reference calls it through are
+    absent from this image and are spelled as the PIL calls they make:
+        scipy.misc.imresize(a, (h, w))            == Image.fromarray(a).resize((w, h), Image.BILINEAR)   utils.py:73
+        transform.Resize((h, w))(img)             == img.resize((w, h), Image.BILINEAR)                  data.py:277,295
+        transform.CenterCrop((th, tw))(img)       == img.crop((j, i, j+tw, i+th)), i = int(round((h-th)/2.)), ...
+        transform.Pad((l, t, r, b))(img)          == zero canvas with img at (t, l)                      data.py:305
+    Everything else (padding, windows, mold_image, box decoding) is executed by the reference's own functions."""
+    import PIL
+    from PIL import Image
+    g = np.random.default_rng(2024)
+    out = {"pillow_version": np.array(PIL.__version__)}
+
+    # ---- plain resizes: up, down, mixed, 1-pixel, identity, RGB and L
+    cases = [(7, 9, 1, 28, 28), (28, 28, 1, 5, 9), (28, 28, 1, 1, 1), (28, 28, 1, 28, 28), (28, 28, 1, 27, 29),
+             (28, 28, 1, 200, 3), (60, 80, 3, 96, 128), (300, 200, 3, 128, 85), (33, 47, 3, 33, 47),
+             (64, 64, 3, 17, 130), (1, 1, 3, 9, 5), (50, 3, 1, 2, 77)]
+    out["resize_cases"] = np.array(cases, dtype=np.int64)
+    for i, (h, w, c, oh, ow) in enumerate(cases):
+        a = g.integers(0, 256, (h, w, c), dtype=np.uint8)
+        if i % 3 == 0:
+            a[a < 40] = 0
+            a[a > 215] = 255
+        src = a[:, :, 0] if c == 1 else a
+        out[f"resize_{i}_in"] = src
+        out[f"resize_{i}_out"] = np.array(Image.fromarray(src).resize((ow, oh), Image.BILINEAR))
+
+    # ---- float -> 'L' (Image.fromarray(F).convert('L'), data.py:294)
+    f = (g.random((28, 28), dtype=np.float32) * 300 - 20).astype(np.float32)
+    f[0, :6] = [0.0, 0.999, 1.0, 254.999, 255.0, 127.5]
+    out["f2l_in"] = f
+    out["f2l_out"] = np.array(Image.fromarray(f).convert("L"))
+
+    # ---- resize_image + mold_image + detect()'s transpose (utils.py:42-90, model.py:1750-1754,1108-1110)
+    cfg = rconfig.CocoInferenceConfig()
+    mold_cases = [(110, 128, 100, 128), (60, 80, 100, 128), (300, 200, 100, 128), (128, 128, 100, 128), (81, 47, 64, 128)]
+    out["mold_cases"] = np.array(mold_cases, dtype=np.int64)
+    for i, (h, w, min_dim, max_dim) in enumerate(mold_cases):
+        a = g.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        scale = max(1, min_dim / min(h, w))                                    # utils.py:62-69, evaluated here
+        if round(max(h, w) * scale) > max_dim:
+            scale = max_dim / max(h, w)
+        if scale != 1:
+            resized = np.array(Image.fromarray(a).resize((round(w * scale), round(h * scale)), Image.BILINEAR))
+        else:
+            resized = a
+        # the reference pads (and reports window/padding) itself; scale is 1 for an image already at its final size
+        padded, window, s1, padding = rutils.resize_image(resized, min_dim=None, max_dim=max_dim, padding=True)
+        assert s1 == 1
+        molded = rmodel.mold_image(padded, cfg)                                # float64: MEAN_PIXEL is a float64 array
+        molded = torch.from_numpy(molded.transpose(2, 0, 1)).float()           # model.py:1108
+        out[f"mold_{i}_in"] = a
+        out[f"mold_{i}_out"] = molded.numpy()
+        out[f"mold_{i}_window"] = np.array(window, dtype=np.int64)
+        out[f"mold_{i}_scale"] = np.array(scale, dtype=np.float64)
+        out[f"mold_{i}_padding"] = np.array(padding, dtype=np.int64)
+    out["mean_pixel"] = np.asarray(cfg.MEAN_PIXEL, dtype=np.float64)
+
+    # ---- full_masks (data.py:287-314) on a 128 x 192 canvas
+    H, W, C = 128, 192, 5
+    boxes = np.array([[10, 20, 60, 90], [0, 0, 128, 192], [100, 150, 128, 192], [5, 7, 10, 16], [64, 64, 65, 65],
+                      [30, 40, 58, 68], [31, 41, 58, 70], [0, 100, 3, 192], [90, 0, 128, 2], [17, 33, 117, 37]],
+                     dtype=np.float32)
+    n = boxes.shape[0]
+    masks = 1.0 / (1.0 + np.exp(-g.normal(0, 2.5, (n, C, 28, 28)))).astype(np.float32)
+    masks[1, :, :3, :3] = 0.0
+    masks[1, :, -3:, -3:] = 1.0
+    masks[2, :, 10:12, 10:12] = 0.5
+    masks[2, :, 12:14, 10:12] = 127.5 / 255.0
+    masks = masks.astype(np.float32)
+    class_id = g.integers(1, C, n).astype(np.int64)
+    full = []
+    for i in range(n):
+        m = torch.from_numpy(masks[i][class_id[i]]) * 255.0                    # data.py:291
+        box = rdata.Box.fromlist(torch.from_numpy(boxes[i]).tolist())
+        img = Image.fromarray(m.numpy()).convert("L")
+        img = img.resize((int(box.width()), int(box.height())), Image.BILINEAR)   # :295
+        top_pad, left_pad = int(box.top()), int(box.left())                    # :298-303
+        canvas = np.zeros((H, W), dtype=np.uint8)
+        canvas[top_pad:top_pad + img.height, left_pad:left_pad + img.width] = np.array(img)
+        full.append(canvas > 127)                                              # :307-308
+    out["fm_masks"], out["fm_class_id"], out["fm_boxes"] = masks, class_id, boxes
+    out["fm_out"] = np.stack(full)
+    out["fm_canvas"] = np.array([H, W], dtype=np.int64)
+
+    # ---- decode_boxes (run by the reference) and decode_masks (data.py:264-284, 331-343)
+    window = (16, 0, 112, 192)
+    for tag, scale in (("up", 1.6), ("down", 0.512)):
+        b = torch.from_numpy(boxes.copy())
+        out[f"dec_{tag}_boxes"] = rdata.decode_boxes(b, scale, rdata.Box.fromlist(list(window))).numpy()
+        th, tw = window[2] - window[0], window[3] - window[1]
+        dec = []
+        for i in range(n):
+            img = Image.fromarray(out["fm_out"][i]).convert("L")               # bool array -> mode '1' -> 0/255
+            i0, j0 = int(round((H - th) / 2.0)), int(round((W - tw) / 2.0))
+            img = img.crop((j0, i0, j0 + tw, i0 + th))
+            nh, nw = round(img.height * 1.0 / scale), round(img.width * 1.0 / scale)
+            dec.append(np.array(img.resize((nw, nh), Image.BILINEAR)))
+        out[f"dec_{tag}_masks"] = np.stack(dec)
+        out[f"dec_{tag}_scale"] = np.array(scale, dtype=np.float64)
+    out["dec_window"] = np.array(window, dtype=np.int64)
+    save("image", **out)
+
+
 def main():
     only = set(sys.argv[1:])
     want = lambda n: not only or n in only
@@ -424,6 +529,8 @@ def main():
         gen_refine(rconfig, rmodel)
     if want("schema"):
         gen_schema(rconfig, rmodel)
+    if want("image"):
+        gen_image(rconfig, rutils, rmodel, rdata)
 
 
 if __name__ == "__main__":

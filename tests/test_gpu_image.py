@@ -1,0 +1,228 @@
+"""GPU parity (-m gpu) of the image pre-/post-processing kernels (csrc/image.hip) through the C ABI: bit-exact against
+the golden vectors (made with Pillow + the reference's own functions) and against the CPU oracle on seeded random
+cases, at small and at full (1024 x 1024 canvas) size. Byte/integer work: every comparison is exact; the molded
+image is compared exactly too (float(double(u8) - mean) has one correct value)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return load_golden("image")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from maskrcnn_amd import ops as o
+    return o
+
+
+def test_resize_golden(ops, gold):
+    for i, (h, w, c, oh, ow) in enumerate(gold["resize_cases"].tolist()):
+        got = ops.resize_bilinear_u8(torch.from_numpy(gold[f"resize_{i}_in"]).to(DEV), oh, ow)
+        assert np.array_equal(got.cpu().numpy(), gold[f"resize_{i}_out"]), (i, h, w, c, oh, ow)
+
+
+def test_resize_random_vs_oracle(ops, oracle):
+    rng = np.random.default_rng(11)
+    for _ in range(60):
+        h, w = (int(v) for v in rng.integers(1, 200, 2))
+        oh, ow = (int(v) for v in rng.integers(1, 300, 2))
+        c = int(rng.choice([1, 3, 4]))
+        a = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+        src = a[:, :, 0] if c == 1 else a
+        got = ops.resize_bilinear_u8(torch.from_numpy(src).to(DEV), oh, ow).cpu().numpy()
+        assert np.array_equal(got, oracle.pil_resize_u8(src, oh, ow)), (h, w, c, oh, ow)
+
+
+def test_resize_full_size(ops, oracle):
+    rng = np.random.default_rng(12)
+    for (h, w, oh, ow) in ((480, 640, 768, 1024), (1500, 2000, 768, 1024), (1024, 1024, 1024, 1024)):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = ops.resize_bilinear_u8(torch.from_numpy(a).to(DEV), oh, ow).cpu().numpy()
+        assert np.array_equal(got, oracle.pil_resize_u8(a, oh, ow)), (h, w, oh, ow)
+    a = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)              # resizing to the same size is the identity
+    assert np.array_equal(ops.resize_bilinear_u8(torch.from_numpy(a).to(DEV), 64, 64).cpu().numpy(), a)
+
+
+def test_resize_batched_cropped_view(ops, oracle):
+    """[N,H,W] batches and non-contiguous (cropped) views: decode_masks's CenterCrop + Resize without a copy."""
+    rng = np.random.default_rng(13)
+    a = (rng.random((5, 96, 128)) > 0.5).astype(np.uint8) * 255
+    t = torch.from_numpy(a).to(DEV)
+    view = t[:, 10:90, 4:100]
+    got = ops.resize_bilinear_u8(view, 50, 60).cpu().numpy()
+    for i in range(5):
+        assert np.array_equal(got[i], oracle.pil_resize_u8(a[i, 10:90, 4:100], 50, 60))
+
+
+def test_mold_golden(ops, gold):
+    from maskrcnn_amd import image as imagelib
+    from maskrcnn_amd.config import InferenceConfig
+    mean = gold["mean_pixel"].tolist()
+    for i, (h, w, min_dim, max_dim) in enumerate(gold["mold_cases"].tolist()):
+        cfg = InferenceConfig(image_height=max_dim, image_width=max_dim, image_min_dim=min_dim, image_max_dim=max_dim,
+                              mean_pixel=tuple(mean))
+        molded, windows, metas = imagelib.mold_inputs([gold[f"mold_{i}_in"]], cfg, DEV)
+        assert np.array_equal(molded[0].cpu().numpy(), gold[f"mold_{i}_out"]), i
+        assert windows[0].tolist() == gold[f"mold_{i}_window"].tolist()
+        assert float(metas[0][0]) == float(gold[f"mold_{i}_scale"])
+
+
+def test_mold_batch_full_size_vs_oracle(ops, oracle):
+    from maskrcnn_amd import image as imagelib
+    from maskrcnn_amd.config import InferenceConfig
+    cfg = InferenceConfig()                                            # 1024 canvas, min 800 / max 1024
+    rng = np.random.default_rng(14)
+    images = [rng.integers(0, 256, s, dtype=np.uint8) for s in ((480, 640, 3), (1300, 900, 3), (1024, 1024, 3))]
+    molded, windows, metas = imagelib.mold_inputs(images, cfg, DEV)
+    for i, img in enumerate(images):
+        ref_img, window, scale, padding = oracle.resize_image(img, cfg.image_min_dim, cfg.image_max_dim, True)
+        ref = oracle.mold_image(ref_img, cfg.mean_pixel)[0]
+        assert tuple(windows[i].tolist()) == tuple(window) and metas[i][0] == scale
+        assert torch.equal(molded[i].cpu(), ref), i
+
+
+def test_resize_image_signature(ops, oracle):
+    from maskrcnn_amd import image as imagelib
+    rng = np.random.default_rng(15)
+    a = rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)
+    img, window, scale, padding = imagelib.resize_image(a, min_dim=100, max_dim=128, padding=True, device=DEV)
+    ref, rwin, rscale, rpad = oracle.resize_image(a, 100, 128, True)
+    assert np.array_equal(img.cpu().numpy(), ref) and tuple(window) == tuple(rwin) and scale == rscale and padding == rpad
+
+
+def test_full_masks_golden(ops, gold):
+    from maskrcnn_amd import image as imagelib
+    h, w = gold["fm_canvas"].tolist()
+    masks = torch.from_numpy(gold["fm_masks"]).to(DEV)                 # reference layout [N,C,28,28]
+    ids = torch.from_numpy(gold["fm_class_id"]).to(DEV)
+    boxes = torch.from_numpy(gold["fm_boxes"]).to(DEV)
+    got = imagelib.full_masks(ids, boxes, masks, h, w)
+    assert got.dtype == torch.bool and np.array_equal(got.cpu().numpy(), gold["fm_out"])
+    nhwc = masks.permute(0, 2, 3, 1).contiguous()                      # this library's mask-head layout
+    got2 = imagelib.full_masks(ids, boxes, nhwc, h, w, channels_last=True)
+    assert np.array_equal(got2.cpu().numpy(), gold["fm_out"])
+
+
+def test_decode_golden(ops, gold):
+    from maskrcnn_amd import image as imagelib
+    h, w = gold["fm_canvas"].tolist()
+    window = tuple(gold["dec_window"].tolist())
+    l8 = ops.paste_masks(torch.from_numpy(gold["fm_masks"]).to(DEV), torch.from_numpy(gold["fm_class_id"]).to(DEV),
+                         torch.from_numpy(gold["fm_boxes"]).to(DEV), h, w, channels_last=False, as_l8=True)
+    assert np.array_equal(l8.cpu().numpy(), gold["fm_out"].astype(np.uint8) * 255)
+    for tag in ("up", "down"):
+        scale = float(gold[f"dec_{tag}_scale"])
+        got = imagelib.decode_masks(l8, scale, window)
+        assert np.array_equal(got.cpu().numpy(), gold[f"dec_{tag}_masks"]), tag
+        b = imagelib.decode_boxes(torch.from_numpy(gold["fm_boxes"]).to(DEV), scale, window)
+        assert np.array_equal(b.cpu().numpy(), gold[f"dec_{tag}_boxes"])
+
+
+def _random_detections(rng, n, c, hh, ww):
+    y1 = rng.integers(0, hh - 1, n)
+    x1 = rng.integers(0, ww - 1, n)
+    bh = np.minimum(rng.integers(1, hh, n) // rng.choice([1, 2, 8, 40], n), hh - y1)
+    bw = np.minimum(rng.integers(1, ww, n) // rng.choice([1, 2, 8, 40], n), ww - x1)
+    boxes = np.stack([y1, x1, y1 + np.maximum(bh, 1), x1 + np.maximum(bw, 1)], 1).astype(np.float32)
+    masks = (1.0 / (1.0 + np.exp(-rng.normal(0, 3, (n, 28, 28, c))))).astype(np.float32)
+    return boxes, masks, rng.integers(1, c, n).astype(np.int64)
+
+
+def test_full_masks_full_size_vs_oracle(ops, oracle):
+    """BASELINE sizes: 50 detection slots on a 1024 x 1024 canvas, 81 classes, boxes from 1 pixel to the whole image."""
+    rng = np.random.default_rng(16)
+    n, c, hh, ww = 50, 81, 1024, 1024
+    boxes, masks, ids = _random_detections(rng, n, c, hh, ww)
+    boxes[0] = [0, 0, hh, ww]
+    boxes[1] = [1023, 1023, 1024, 1024]
+    boxes[2] = [100, 200, 100, 260]                                    # empty box: the reference raises; here all-zero
+    ids[3] = 0
+    boxes[3] = [0, 0, 0, 0]                                            # a padded detection slot
+    got = ops.paste_masks(torch.from_numpy(masks).to(DEV), torch.from_numpy(ids).to(DEV),
+                          torch.from_numpy(boxes).to(DEV), hh, ww, channels_last=True).cpu()
+    ok = [i for i in range(n) if i not in (2, 3)]
+    ref = oracle.full_masks(torch.from_numpy(ids[ok]), torch.from_numpy(boxes[ok]),
+                            torch.from_numpy(masks[ok]).permute(0, 3, 1, 2), hh, ww)
+    assert torch.equal(got[ok], ref)
+    assert not got[2].any() and not got[3].any()
+    # nothing is ever written outside the box
+    for i in ok[:10]:
+        y1, x1, y2, x2 = (int(v) for v in boxes[i])
+        m = got[i].clone()
+        m[y1:y2, x1:x2] = False
+        assert not m.any()
+
+
+def test_full_masks_rectangular_canvas(ops, oracle):
+    rng = np.random.default_rng(17)
+    n, c, hh, ww = 12, 7, 832, 1344                                    # BASELINE config 5 canvas
+    boxes, masks, ids = _random_detections(rng, n, c, hh, ww)
+    got = ops.paste_masks(torch.from_numpy(masks).to(DEV), torch.from_numpy(ids).to(DEV),
+                          torch.from_numpy(boxes).to(DEV), hh, ww, channels_last=True).cpu()
+    ref = oracle.full_masks(torch.from_numpy(ids), torch.from_numpy(boxes),
+                            torch.from_numpy(masks).permute(0, 3, 1, 2), hh, ww)
+    assert torch.equal(got, ref)
+
+
+def test_bad_arguments(ops):
+    from maskrcnn_amd._lib import MaskrcnnHipError
+    with pytest.raises(RuntimeError):
+        ops.resize_bilinear_u8(torch.zeros(4, 4, dtype=torch.float32, device=DEV), 2, 2)
+    with pytest.raises(RuntimeError):
+        ops.resize_bilinear_u8(torch.zeros(4, 4, dtype=torch.uint8), 2, 2)            # CPU tensor
+    with pytest.raises(ValueError):
+        ops.resize_bilinear_u8(torch.zeros(4, 4, dtype=torch.uint8, device=DEV), 0, 2)
+    with pytest.raises(MaskrcnnHipError):
+        ops.paste_masks(torch.zeros(1, 28, 28, 3, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV),
+                        torch.zeros(1, 4, device=DEV), 64, 66, channels_last=True)    # width % 4 != 0
+
+
+def test_detect_end_to_end(ops, oracle):
+    """detect(): images of different sizes in, per-image results out. The molded batch and the pasted / decoded masks
+    are checked against the oracle composed on the pipeline's own detections (the network in between is covered by
+    test_gpu_pipeline.py)."""
+    from maskrcnn_amd import image as imagelib
+    from maskrcnn_amd import modules
+    from maskrcnn_amd.config import InferenceConfig
+    from maskrcnn_amd.pipeline import MaskRCNNInference
+    cfg = InferenceConfig(image_height=256, image_width=256, image_min_dim=200, image_max_dim=256, backbone="resnet50",
+                          pre_nms_limit=300, proposal_count=100, detection_max_instances=10)
+    sd = modules.synthetic_state_dict("resnet50", seed=0, bn_seed=1)
+    g = torch.Generator().manual_seed(5)
+    sd["classifier.linear_class.weight"] = torch.randn(81, 1024, generator=g) * 0.05
+    sd["classifier.linear_class.bias"] = torch.randn(81, generator=g) * 0.5
+    net = MaskRCNNInference(sd, cfg, DEV)
+    rng = np.random.default_rng(18)
+    images = [rng.integers(0, 256, s, dtype=np.uint8) for s in ((120, 160, 3), (256, 256, 3), (400, 300, 3))]
+    results = net.detect(images)
+    assert len(results) == 3
+    molded, windows, metas = imagelib.mold_inputs(images, cfg, DEV)
+    det = net.predict(molded, windows)
+    for b, (ids, scores, boxes, masks) in enumerate(results):
+        n = int(det.counts[b])
+        if n == 0:
+            assert ids is None
+            continue
+        scale, window = metas[b][0], tuple(windows[b].tolist())
+        assert torch.equal(ids, det.class_ids[b, :n])
+        m28 = det.masks[b, :n].permute(0, 3, 1, 2).cpu()
+        bx = det.boxes[b, :n].cpu()
+        # random weights can give empty boxes: the reference raises on those (PIL), this library pastes nothing
+        ok = ((bx[:, 2] > bx[:, 0]) & (bx[:, 3] > bx[:, 1])).nonzero().flatten()
+        full = torch.zeros(n, 256, 256, dtype=torch.bool)
+        if len(ok):
+            full[ok] = oracle.full_masks(det.class_ids[b, :n].cpu()[ok], bx[ok], m28[ok], 256, 256)
+        ref_masks = oracle.decode_masks(full, scale, window)
+        assert torch.equal(masks.cpu(), ref_masks), b
+        assert torch.equal(boxes.cpu(), oracle.decode_boxes(det.boxes[b, :n].cpu(), scale, window))
+        if scale != 1:
+            h0, w0 = images[b].shape[:2]
+            assert abs(masks.shape[1] - h0) <= 1 and abs(masks.shape[2] - w0) <= 1
