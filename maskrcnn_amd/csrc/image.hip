@@ -189,10 +189,12 @@ bool resize_args_ok(int in_h, int in_w, int c, int out_h, int out_w) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// full_masks: one workgroup per (detection, TILE_ROWS output rows). Tiles that miss the box are zero-filled; the
-// others stage the 8-bit mask, run the horizontal pass for the box's columns into LDS and the vertical pass for
-// their rows, threshold (> 127) and write 4 pixels per thread. Everything outside the box is 0.
+// full_masks: the canvases are cleared with one memset (a pure HBM write stream: the bulk of the bytes), then one
+// workgroup per (detection, TILE_ROWS output rows) that touches the box stages the 8-bit mask, runs the horizontal
+// pass for the box's columns into LDS and the vertical pass for its rows, thresholds (> 127) and overwrites the
+// 16-byte groups that overlap the box. Workgroups whose rows miss the box exit at once.
 constexpr int TILE_ROWS = 32;
+constexpr int CHUNK = 256;  // box columns staged per pass (== the workgroup size: a thread per column)
 
 struct PasteParams {
     const float* masks;        // element (det, y, x, class) at det*sn + y*sy + x*sx + class*sc
@@ -200,14 +202,19 @@ struct PasteParams {
     const int64_t* class_ids;  // [n]
     const float* boxes;        // [n][4]
     uint8_t* out;              // [n][H][W]
-    int mh, mw, C, H, W;
+    int n, mh, mw, C, H, W;
     unsigned on_value;  // byte written where the resized mask > 127 (1: boolean view, 255: an 'L' image)
     int off_hk, off_tmp, off_vb, off_vk;  // byte offsets into dynamic LDS (mask bytes at 0)
 };
 
+template <int PX>  // pixels per thread in the store loops: 16 (one 16-byte store; needs W % 16 == 0) or 4
 __global__ __launch_bounds__(256) void paste_masks_kernel(const PasteParams p) {
+    typedef unsigned int store_t __attribute__((ext_vector_type(PX / 4)));
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int det = blockIdx.y, row0 = blockIdx.x * TILE_ROWS;
+    // consecutive workgroups (which the dispatcher deals round-robin to XCDs and CUs) take the same row tile of
+    // consecutive detections: tiles that hit their boxes then spread over the chip instead of piling onto the few
+    // CUs a (tile fastest) order would send every detection's tile t to
+    const int det = blockIdx.x % p.n, row0 = (blockIdx.x / p.n) * TILE_ROWS;
     const int row1 = min(row0 + TILE_ROWS, p.H);
     const int tid = threadIdx.x;
     const float* b = p.boxes + 4 * static_cast<int64_t>(det);
@@ -219,13 +226,7 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const PasteParams p) {
     const bool valid = bh > 0 && bw > 0 && top >= 0 && left >= 0 && top + bh <= p.H && left + bw <= p.W &&
                        cls >= 0 && cls < p.C;
     uint8_t* out = p.out + static_cast<int64_t>(det) * p.H * p.W;
-    const int w4 = p.W >> 2;
-    if (!valid || row0 >= top + bh || row1 <= top) {
-        uint32_t* o = reinterpret_cast<uint32_t*>(out + static_cast<int64_t>(row0) * p.W);
-        const int n = (row1 - row0) * w4;
-        for (int i = tid; i < n; i += 256) o[i] = 0u;
-        return;
-    }
+    if (!valid || row0 >= top + bh || row1 <= top) return;  // the canvas is already zero
     uint8_t* m8 = lds;
     int* hk = reinterpret_cast<int*>(lds + p.off_hk);
     uint8_t* tmp = lds + p.off_tmp;  // [mh][bw]
@@ -239,64 +240,92 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const PasteParams p) {
         const float v = msrc[my * p.sy + mx * p.sx] * 255.0f;
         m8[i] = v <= 0.0f ? 0 : v >= 255.0f ? 255 : static_cast<uint8_t>(v);
     }
-    // vertical coefficients of this tile's rows
-    Axis av;
-    av.in_size = p.mh; av.out_size = bh;
-    {
-        double fs = av.scale = static_cast<double>(static_cast<float>(p.mh)) / bh;
+    auto axis = [](int in_size, int out_size) {
+        Axis a;
+        a.in_size = in_size; a.out_size = out_size;
+        double fs = a.scale = static_cast<double>(static_cast<float>(in_size)) / out_size;
         if (fs < 1.0) fs = 1.0;
-        av.support = fs; av.ksize = static_cast<int>(ceil(fs)) * 2 + 1; av.ss = 1.0 / fs;
-    }
-    Axis ah;
-    ah.in_size = p.mw; ah.out_size = bw;
-    {
-        double fs = ah.scale = static_cast<double>(static_cast<float>(p.mw)) / bw;
-        if (fs < 1.0) fs = 1.0;
-        ah.support = fs; ah.ksize = static_cast<int>(ceil(fs)) * 2 + 1; ah.ss = 1.0 / fs;
-    }
-    if (tid < TILE_ROWS) {
-        const int yy = row0 + tid - top;
-        int ymin = 0, cnt = 0;
-        if (yy >= 0 && yy < bh) axis_coeffs(av, yy, ymin, cnt, vk + tid * av.ksize, 1);
+        a.support = 1.0 * fs; a.ksize = static_cast<int>(ceil(a.support)) * 2 + 1; a.ss = 1.0 / fs;
+        return a;
+    };
+    const Axis av = axis(p.mh, bh), ah = axis(p.mw, bw);
+    // vertical coefficients of this tile's rows that lie in the box, packed from the first such row
+    const int rfirst = max(top - row0, 0), rlast = min(top + bh, row1) - row0;  // tile rows [rfirst, rlast)
+    if (tid >= rfirst && tid < rlast) {
+        int ymin, cnt;
+        axis_coeffs(av, row0 + tid - top, ymin, cnt, vk + (tid - rfirst) * av.ksize, 1);
         vb[2 * tid] = ymin;
         vb[2 * tid + 1] = cnt;
     }
-    __syncthreads();
-    // horizontal pass, a thread per box column (its coefficients live in its own LDS slot)
-    for (int x0 = 0; x0 < bw; x0 += 256) {
-        const int xx = x0 + tid;
-        if (xx < bw) {
-            int* k = hk + tid * ah.ksize;
-            int xmin, cnt;
-            axis_coeffs(ah, xx, xmin, cnt, k, 1);
-            for (int r = 0; r < p.mh; ++r) {
-                const uint8_t* s = m8 + r * p.mw + xmin;
-                int ss = 1 << (PRECISION_BITS - 1);
-                for (int x = 0; x < cnt; ++x) ss += s[x] * k[x];
-                tmp[r * bw + xx] = static_cast<uint8_t>(clip8(ss));
-            }
-        }
-    }
-    __syncthreads();
-    // vertical pass + threshold, 4 pixels per thread
-    for (int i = tid; i < (row1 - row0) * w4; i += 256) {
-        const int rr = i / w4, x4 = (i - rr * w4) * 4;
-        const int ymin = vb[2 * rr], cnt = vb[2 * rr + 1];
-        const int* k = vk + rr * av.ksize;
-        uint32_t packed = 0;
-        if (cnt > 0 && x4 + 3 >= left && x4 < left + bw) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int xx = x4 + j - left;
-                if (xx >= 0 && xx < bw) {
-                    const uint8_t* s = tmp + ymin * bw + xx;
-                    int ss = 1 << (PRECISION_BITS - 1);
-                    for (int y = 0; y < cnt; ++y) ss += s[y * bw] * k[y];
-                    if (clip8(ss) > 127u) packed |= p.on_value << (8 * j);  // data.py:308 mask > 127
+    // Column chunks of CHUNK canvas pixels, aligned to the store groups. Per chunk: horizontal pass for its box
+    // columns (a thread per column; its coefficients live in its own LDS slot) into tmp [mh][CHUNK], then the
+    // vertical pass + threshold (data.py:308 mask > 127) for the tile's box rows, PX pixels and one store per thread.
+    const int cb = (left / PX) * PX;
+    for (int c0 = cb; c0 < left + bw; c0 += CHUNK) {
+        __syncthreads();  // mask / coefficients staged; previous chunk's tmp consumed
+        {
+            const int xx = c0 + tid - left;
+            if (xx >= 0 && xx < bw) {
+                int* k = hk + (tid - max(left - c0, 0)) * ah.ksize;  // slots packed from the first box column
+                int xmin, cnt;
+                axis_coeffs(ah, xx, xmin, cnt, k, 1);
+                if (ah.ksize == 3) {
+                    // not shrinking (the usual case): at most 3 taps. Taps beyond cnt have coefficient 0 and a clamped
+                    // index, so the rows' LDS reads are independent of each other and of cnt and can all be in flight
+                    const int k0 = k[0], k1 = k[1], k2 = k[2];
+                    const int i0 = xmin, i1 = min(xmin + 1, p.mw - 1), i2 = min(xmin + 2, p.mw - 1);
+#pragma unroll 4
+                    for (int r = 0; r < p.mh; ++r) {
+                        const uint8_t* s = m8 + r * p.mw;
+                        const int ss = (1 << (PRECISION_BITS - 1)) + s[i0] * k0 + s[i1] * k1 + s[i2] * k2;
+                        tmp[r * CHUNK + tid] = static_cast<uint8_t>(clip8(ss));
+                    }
+                } else {
+                    for (int r = 0; r < p.mh; ++r) {
+                        const uint8_t* s = m8 + r * p.mw + xmin;
+                        int ss = 1 << (PRECISION_BITS - 1);
+                        for (int x = 0; x < cnt; ++x) ss += s[x] * k[x];
+                        tmp[r * CHUNK + tid] = static_cast<uint8_t>(clip8(ss));
+                    }
                 }
             }
         }
-        reinterpret_cast<uint32_t*>(out + static_cast<int64_t>(row0 + rr) * p.W)[x4 >> 2] = packed;
+        __syncthreads();
+        constexpr int GPC = CHUNK / PX;  // store groups per chunk row
+        const int ngroups = min(GPC, (left + bw - c0 + PX - 1) / PX);
+        for (int i = tid; i < (rlast - rfirst) * ngroups; i += 256) {
+            const int ri = i / ngroups, gi = i - ri * ngroups, rr = rfirst + ri;
+            const int ymin = vb[2 * rr], cnt = vb[2 * rr + 1];
+            const int* k = vk + ri * av.ksize;
+            store_t packed = {};
+            if (av.ksize == 3) {  // at most 3 taps (see the horizontal pass): three PX-byte LDS reads per store group
+                const int k0 = k[0], k1 = k[1], k2 = k[2];
+                const store_t r0 = *reinterpret_cast<const store_t*>(tmp + ymin * CHUNK + gi * PX);
+                const store_t r1 = *reinterpret_cast<const store_t*>(tmp + min(ymin + 1, p.mh - 1) * CHUNK + gi * PX);
+                const store_t r2 = *reinterpret_cast<const store_t*>(tmp + min(ymin + 2, p.mh - 1) * CHUNK + gi * PX);
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    const int xx = c0 + gi * PX + j - left;
+                    const unsigned w0 = r0[j / 4], w1 = r1[j / 4], w2 = r2[j / 4];
+                    const int sh = 8 * (j & 3);
+                    const int ss = (1 << (PRECISION_BITS - 1)) + static_cast<int>((w0 >> sh) & 255u) * k0 +
+                                   static_cast<int>((w1 >> sh) & 255u) * k1 + static_cast<int>((w2 >> sh) & 255u) * k2;
+                    if (xx >= 0 && xx < bw && clip8(ss) > 127u) packed[j / 4] |= p.on_value << sh;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    const int cx = gi * PX + j, xx = c0 + cx - left;  // chunk column, box column
+                    if (xx >= 0 && xx < bw) {
+                        const uint8_t* s = tmp + ymin * CHUNK + cx;
+                        int ss = 1 << (PRECISION_BITS - 1);
+                        for (int y = 0; y < cnt; ++y) ss += s[y * CHUNK] * k[y];
+                        if (clip8(ss) > 127u) packed[j / 4] |= p.on_value << (8 * (j & 3));
+                    }
+                }
+            }
+            reinterpret_cast<store_t*>(out + static_cast<int64_t>(row0 + rr) * p.W + c0)[gi] = packed;
+        }
     }
 }
 
@@ -374,7 +403,7 @@ extern "C" int mrcnn_paste_masks_u8(const float* masks, int64_t stride_n, int64_
                   "paste_masks: canvas %dx%d (width %% 4 == 0 required), n=%d (<= 65535)", height, width, n);
     PasteParams p;
     p.masks = masks; p.sn = stride_n; p.sy = stride_y; p.sx = stride_x; p.sc = stride_c; p.class_ids = class_ids; p.boxes = boxes; p.out = out;
-    p.mh = mask_h; p.mw = mask_w; p.C = num_classes; p.H = height; p.W = width;
+    p.n = n; p.mh = mask_h; p.mw = mask_w; p.C = num_classes; p.H = height; p.W = width;
     p.on_value = static_cast<unsigned>(on_value);
     auto up = [](int v) { return (v + 15) & ~15; };
     int o = up(mask_h * mask_w);
@@ -382,12 +411,18 @@ extern "C" int mrcnn_paste_masks_u8(const float* masks, int64_t stride_n, int64_
     // per-thread coefficient slots of one 256-column chunk: ksize 3 when enlarging (<= 256*3 ints); when shrinking
     // there are bw < mask_w columns of ksize <= 2*ceil(mask_w/bw)+1 taps: bw*ksize <= 5*mask_w ints
     o += up(4 * (256 * 3 > 5 * mask_w ? 256 * 3 : 5 * mask_w));
-    p.off_tmp = o; o += up(mask_h * width);
+    p.off_tmp = o; o += up(mask_h * CHUNK);
     p.off_vb = o; o += up(4 * 2 * TILE_ROWS);
-    p.off_vk = o; o += up(4 * TILE_ROWS * (2 * mask_h + 1));
-    MRCNN_REQUIRE(o <= 64 * 1024, "paste_masks: canvas width %d with %dx%d masks needs %d bytes of LDS (> 64 KiB)",
-                  width, mask_h, mask_w, o);
+    // vertical coefficients of the tile's box rows: ksize 3 when enlarging (<= TILE_ROWS*3 ints); when shrinking there
+    // are bh < mask_h rows of <= 2*ceil(mask_h/bh)+1 taps: <= 5*mask_h ints
+    p.off_vk = o; o += up(4 * (TILE_ROWS * 3 > 5 * mask_h ? TILE_ROWS * 3 : 5 * mask_h));
     hipStream_t s = mrcnn::as_stream(stream);
-    hipLaunchKernelGGL(paste_masks_kernel, dim3((height + TILE_ROWS - 1) / TILE_ROWS, n), dim3(256), o, s, p);
+    hipError_t e = hipMemsetAsync(out, 0, static_cast<size_t>(n) * height * width, s);
+    if (e != hipSuccess) return mrcnn::fail(MRCNN_ERR_LAUNCH, "paste_masks: hipMemsetAsync: %s", hipGetErrorString(e));
+    const dim3 grid(static_cast<unsigned>((height + TILE_ROWS - 1) / TILE_ROWS) * n);
+    if (width % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0)
+        hipLaunchKernelGGL(paste_masks_kernel<16>, grid, dim3(256), o, s, p);
+    else
+        hipLaunchKernelGGL(paste_masks_kernel<4>, grid, dim3(256), o, s, p);
     return mrcnn::check_launch("paste_masks_kernel");
 }

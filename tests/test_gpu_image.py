@@ -161,9 +161,10 @@ def test_full_masks_full_size_vs_oracle(ops, oracle):
         assert not m.any()
 
 
-def test_full_masks_rectangular_canvas(ops, oracle):
+@pytest.mark.parametrize("hh,ww", [(832, 1344), (100, 132)])          # BASELINE config 5 canvas; a width % 16 != 0
+def test_full_masks_rectangular_canvas(ops, oracle, hh, ww):
     rng = np.random.default_rng(17)
-    n, c, hh, ww = 12, 7, 832, 1344                                    # BASELINE config 5 canvas
+    n, c = 12, 7
     boxes, masks, ids = _random_detections(rng, n, c, hh, ww)
     got = ops.paste_masks(torch.from_numpy(masks).to(DEV), torch.from_numpy(ids).to(DEV),
                           torch.from_numpy(boxes).to(DEV), hh, ww, channels_last=True).cpu()

@@ -4,6 +4,9 @@
   * RoIAlign (BASELINE config 2): 256 RoIs x 256 ch x 14x14 on one FPN level, NCHW drop-in entry point and
     the NHWC pyramid kernel; roofline = compulsory bytes (output + touched map once + boxes) / time vs 8 TB/s.
   * NMS: µs per call at N = 500 / 1000 / 2000 (threshold 0.7) and the batched 8 x 1000 form; latency-bound.
+  * image pre-/post-processing: mold_inputs of 8 camera-sized images and full_masks of 8 x 50
+    detections on a 1024^2 canvas; HBM-bound byte work, roofline = bytes that must move / time vs 8 TB/s, with the
+    CPU oracle (C restatement of Pillow's resample, 1 thread) and Pillow itself timed beside it.
 Prints one JSON object per line."""
 import json
 import os
@@ -82,9 +85,86 @@ def cpu_reference(g):
                           "ms": round((time.perf_counter() - t0) / 5 * 1e3, 2)}), flush=True)
 
 
+def image_bench(dev):
+    import time
+
+    import numpy as np
+
+    from maskrcnn_amd import image as imagelib
+    from maskrcnn_amd.config import InferenceConfig
+    cfg = InferenceConfig()
+    rng = np.random.default_rng(1234)
+    # ---- pre-processing: 8 images 480x640 -> 768x1024 -> 1024^2 canvas, fp32 CHW
+    images = [rng.integers(0, 256, (480, 640, 3), dtype=np.uint8) for _ in range(8)]
+    dimgs = [torch.from_numpy(a).to(dev) for a in images]
+    us = timeit(lambda: imagelib.mold_inputs(dimgs, cfg, dev), iters=20)
+    moved = 8 * (480 * 640 * 3 + 3 * 1024 * 1024 * 4)
+    print(json.dumps({"op": "mold_inputs (resize 480x640->768x1024, pad, mean, CHW)", "images": 8, "us": round(us, 1),
+                      "algorithmic_MB": round(moved / 1e6, 1), "GBps": round(moved / us / 1e3, 1),
+                      "frac_of_8TBps": round(moved / us / 1e3 / HBM_PEAK_GBS, 4),
+                      "launches": 8 * 4}), flush=True)
+    # ---- post-processing: 400 detections (8 images x 50) pasted at full size
+    n, c = 400, 81
+    cy, cx = rng.random(n), rng.random(n)
+    hh = np.exp(rng.random(n) * 3.4 - 3.9)
+    ww = np.exp(rng.random(n) * 3.4 - 3.9)
+    y1 = np.clip((cy - hh / 2) * 1024, 0, 1023).round()
+    x1 = np.clip((cx - ww / 2) * 1024, 0, 1023).round()
+    y2 = np.clip((cy + hh / 2) * 1024, y1 + 1, 1024).round()
+    x2 = np.clip((cx + ww / 2) * 1024, x1 + 1, 1024).round()
+    boxes = np.stack([y1, x1, y2, x2], 1).astype(np.float32)
+    masks = (1.0 / (1.0 + np.exp(-rng.normal(0, 3, (n, 28, 28, c))))).astype(np.float32)
+    ids = rng.integers(1, c, n).astype(np.int64)
+    dm, di, db = torch.from_numpy(masks).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(boxes).to(dev)
+    us = timeit(lambda: ops.paste_masks(dm, di, db, 1024, 1024, channels_last=True), iters=20)
+    moved = n * 1024 * 1024 + n * 28 * 28 * 4
+    print(json.dumps({"op": "full_masks (paste_masks, 28x28 -> box -> 1024^2 canvas)", "detections": n,
+                      "us": round(us, 1), "algorithmic_MB": round(moved / 1e6, 1), "GBps": round(moved / us / 1e3, 1),
+                      "frac_of_8TBps": round(moved / us / 1e3 / HBM_PEAK_GBS, 4),
+                      "mean_box_area_px": float(((y2 - y1) * (x2 - x1)).mean())}), flush=True)
+    # ---- CPU beside it: the oracle (test infrastructure) and, when importable, Pillow itself
+    try:
+        from oracle import oracle
+    except Exception:
+        return
+    t0 = time.perf_counter()
+    for a in images[:4]:
+        img, *_ = oracle.resize_image(a, cfg.image_min_dim, cfg.image_max_dim, True)
+        oracle.mold_image(img, cfg.mean_pixel)
+    print(json.dumps({"op": "mold_inputs_cpu_oracle (1 thread)", "images": 4,
+                      "ms_per_image": round((time.perf_counter() - t0) / 4 * 1e3, 2)}), flush=True)
+    t0 = time.perf_counter()
+    oracle.full_masks(torch.from_numpy(ids[:50]), torch.from_numpy(boxes[:50]),
+                      torch.from_numpy(masks[:50]).permute(0, 3, 1, 2), 1024, 1024)
+    print(json.dumps({"op": "full_masks_cpu_oracle (1 thread)", "detections": 50,
+                      "ms_per_50": round((time.perf_counter() - t0) * 1e3, 2)}), flush=True)
+    try:
+        from PIL import Image
+    except Exception:
+        return
+    t0 = time.perf_counter()
+    for a in images[:4]:
+        r = np.array(Image.fromarray(a).resize((1024, 768), Image.BILINEAR))
+        p = np.pad(r, [(128, 128), (0, 0), (0, 0)])
+        torch.from_numpy((p.astype(np.float32) - np.asarray(cfg.mean_pixel)).transpose(2, 0, 1)).float()
+    print(json.dumps({"op": "mold_inputs_cpu_pillow+numpy (the reference's third-party path, 1 thread)", "images": 4,
+                      "ms_per_image": round((time.perf_counter() - t0) / 4 * 1e3, 2)}), flush=True)
+    t0 = time.perf_counter()
+    for i in range(50):
+        m = Image.fromarray(masks[i, :, :, ids[i]] * 255.0).convert("L")
+        m = m.resize((int(x2[i] - x1[i]), int(y2[i] - y1[i])), Image.BILINEAR)
+        canvas = np.zeros((1024, 1024), dtype=np.uint8)
+        canvas[int(y1[i]):int(y1[i]) + m.height, int(x1[i]):int(x1[i]) + m.width] = np.array(m)
+        torch.from_numpy(canvas) > 127
+    print(json.dumps({"op": "full_masks_cpu_pillow+numpy (the reference's third-party path, 1 thread)",
+                      "detections": 50, "ms_per_50": round((time.perf_counter() - t0) * 1e3, 2)}), flush=True)
+
+
 def main():
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(1234)
+    if "--image-only" in sys.argv:
+        return image_bench(dev)
     cpu_reference(torch.Generator().manual_seed(1234))
     for hl in (256, 128, 64, 32):
         fm = torch.randn(1, 256, hl, hl, generator=g).to(dev)
@@ -129,6 +209,7 @@ def main():
     _, cnt = ops.nms_batched(d8, 0.7)
     print(json.dumps({"op": "nms", "segments": 8, "n": 1000, "threshold": 0.7,
                       "kept_mean": float(cnt.float().mean()), "us": round(us, 1)}), flush=True)
+    image_bench(dev)
 
 
 if __name__ == "__main__":
