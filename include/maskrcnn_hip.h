@@ -229,6 +229,32 @@ int mrcnn_detection_decode_f32(const float* logits, int64_t logit_stride, const 
                                float image_height, float image_width, float min_confidence, float* dets,
                                int32_t* nms_class_ids, int64_t* class_ids, mrcnn_stream_t stream);
 
+/* ---- selection steps of the two refine stages (no library sort / top-k / gather in the step) --------------------
+ * Total, deterministic order everywhere: descending score, ties by ascending index (ATen's sort, which the
+ * reference calls at model.py:1346,1478, leaves ties unspecified).
+ * mrcnn_topk_desc_f32 — replaces `scores.sort(descending=True)` + `[:pre_nms_limit]` of rpn_refine
+ *   (model.py:1345-1350): scores [batch][n] -> top_scores [batch][k], order int64 [batch][k]. k <= 4096, k <= n;
+ *   workspace >= mrcnn_topk_workspace_bytes(batch) bytes of device memory (contents irrelevant).
+ * mrcnn_proposal_select_f32 — replaces keep[:proposal_count] + gather + normalise (model.py:1366-1374):
+ *   dets [batch][k][5], keep int64 [batch][k] (NMS output, ascending, padded) with keep_counts [batch] ->
+ *   rois [batch][proposal_count][4] = box / (H,W,H,W), zero beyond counts[b] = min(keep_counts[b], proposal_count).
+ * mrcnn_detection_select_f32 — replaces the tail of mrn_refine (model.py:1475-1487) and the mask-head box
+ *   normalisation (model.py:1188): among the RoIs the class-aware NMS kept (keep / keep_counts, rows of
+ *   rois_per_image) that carry a foreground class (nms_class_ids > 0), the max_instances highest scores ->
+ *   out_class_ids int64, out_scores, out_boxes [batch][max_instances][4] (pixels), out_rois = boxes / (H,W,H,W),
+ *   out_counts [batch]; unused slots are zero. rois_per_image <= 4096. */
+size_t mrcnn_topk_workspace_bytes(int32_t batch);
+int mrcnn_topk_desc_f32(const float* scores, int32_t batch, int64_t n, int32_t k, float* top_scores, int64_t* order,
+                        void* workspace, size_t workspace_bytes, mrcnn_stream_t stream);
+int mrcnn_proposal_select_f32(const float* dets, const int64_t* keep, const int32_t* keep_counts, int32_t batch,
+                              int32_t k, int32_t proposal_count, float image_height, float image_width, float* rois,
+                              int32_t* counts, mrcnn_stream_t stream);
+int mrcnn_detection_select_f32(const float* dets, const int32_t* nms_class_ids, const int64_t* class_ids,
+                               const int64_t* keep, const int32_t* keep_counts, int32_t batch, int32_t rois_per_image,
+                               int32_t max_instances, float image_height, float image_width, int64_t* out_class_ids,
+                               float* out_scores, float* out_boxes, float* out_rois, int32_t* out_counts,
+                               mrcnn_stream_t stream);
+
 /* Layout conversions at the boundary (reference tensors are NCHW, model.py:1109). */
 int mrcnn_nchw_to_nhwc_f32(const float* x, int32_t batch, int32_t channels, int32_t height,
                            int32_t width, int32_t channels_padded, float* y, mrcnn_stream_t stream);

@@ -53,6 +53,12 @@ _SIGS = {
     "mrcnn_detection_decode_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
                                                     ctypes.POINTER(c_f32), c_f32, c_f32, c_f32, c_vp, c_vp, c_vp,
                                                     c_vp]),
+    "mrcnn_topk_workspace_bytes": (ctypes.c_size_t, [c_i32]),
+    "mrcnn_topk_desc_f32": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "mrcnn_proposal_select_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp,
+                                                   c_vp]),
+    "mrcnn_detection_select_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32,
+                                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mrcnn_nchw_to_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mrcnn_nhwc_to_nchw_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "mrcnn_resize_u8_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),

@@ -28,6 +28,7 @@ SOURCES = {
     "conv.hip": [],
     "conv_f16.hip": [],
     "misc.hip": ["-ffp-contract=off"],
+    "select.hip": ["-ffp-contract=off"],
     "image.hip": ["-ffp-contract=off"],   # Pillow's coefficient arithmetic, operation by operation in fp64
 }
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-fno-fast-math",

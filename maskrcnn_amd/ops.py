@@ -423,6 +423,60 @@ def detection_decode(logits, bbox, rois, roi_counts, windows, std_dev, image_hei
 __all__ += ["detection_decode"]
 
 
+def topk_desc(scores: torch.Tensor, k: int):
+    """scores fp32 [B,N] → (top [B,k], order int64 [B,k]): descending, ties by ascending index (model.py:1345-1350)."""
+    _need_gpu(scores)
+    assert scores.dtype == torch.float32 and scores.dim() == 2 and scores.is_contiguous()
+    b, n = scores.shape
+    top = torch.empty(b, k, dtype=torch.float32, device=scores.device)
+    order = torch.empty(b, k, dtype=torch.int64, device=scores.device)
+    nbytes = int(lib.mrcnn_topk_workspace_bytes(b))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=scores.device)
+    check(lib.mrcnn_topk_desc_f32(scores.data_ptr(), b, n, k, top.data_ptr(), order.data_ptr(), ws.data_ptr(), nbytes,
+                                  _stream()))
+    return top, order
+
+
+def proposal_select(dets, keep, keep_counts, proposal_count: int, image_height, image_width):
+    """dets [B,K,5], NMS keep int64 [B,K] + counts int32 [B] → (rois [B,P,4] normalised, zero-padded; counts int32 [B])
+    — keep[:proposal_count], gather, normalise (model.py:1366-1374) in one launch."""
+    _need_gpu(dets, keep, keep_counts)
+    assert dets.is_contiguous() and keep.is_contiguous() and keep.dtype == torch.int64
+    assert keep_counts.dtype == torch.int32 and keep_counts.is_contiguous()
+    b, k, _ = dets.shape
+    rois = torch.empty(b, proposal_count, 4, dtype=torch.float32, device=dets.device)
+    counts = torch.empty(b, dtype=torch.int32, device=dets.device)
+    check(lib.mrcnn_proposal_select_f32(dets.data_ptr(), keep.data_ptr(), keep_counts.data_ptr(), b, k,
+                                        proposal_count, float(image_height), float(image_width), rois.data_ptr(),
+                                        counts.data_ptr(), _stream()))
+    return rois, counts
+
+
+def detection_select(dets, nms_class_ids, class_ids, keep, keep_counts, max_instances: int, image_height,
+                     image_width):
+    """Tail of mrn_refine (model.py:1475-1487) in one launch → (class_ids int64 [B,D], scores [B,D], boxes [B,D,4]
+    pixels, rois [B,D,4] normalised for the mask head, counts int32 [B]); unused slots are zero."""
+    _need_gpu(dets, nms_class_ids, class_ids, keep, keep_counts)
+    assert dets.is_contiguous() and nms_class_ids.is_contiguous() and class_ids.is_contiguous()
+    assert keep.is_contiguous() and keep.dtype == torch.int64 and class_ids.dtype == torch.int64
+    assert nms_class_ids.dtype == torch.int32 and keep_counts.dtype == torch.int32
+    b, p, _ = dets.shape
+    d, dev = max_instances, dets.device
+    ids = torch.empty(b, d, dtype=torch.int64, device=dev)
+    scores = torch.empty(b, d, dtype=torch.float32, device=dev)
+    boxes = torch.empty(b, d, 4, dtype=torch.float32, device=dev)
+    rois = torch.empty(b, d, 4, dtype=torch.float32, device=dev)
+    counts = torch.empty(b, dtype=torch.int32, device=dev)
+    check(lib.mrcnn_detection_select_f32(dets.data_ptr(), nms_class_ids.data_ptr(), class_ids.data_ptr(),
+                                         keep.data_ptr(), keep_counts.data_ptr(), b, p, d, float(image_height),
+                                         float(image_width), ids.data_ptr(), scores.data_ptr(), boxes.data_ptr(),
+                                         rois.data_ptr(), counts.data_ptr(), _stream()))
+    return ids, scores, boxes, rois, counts
+
+
+__all__ += ["topk_desc", "proposal_select", "detection_select"]
+
+
 def deconv2x2(x: torch.Tensor, w, bias4: torch.Tensor, activation: int = 0, products: int = 0) -> torch.Tensor:
     """2x2 stride-2 transposed conv + bias + activation (Mask.forward's deconv, model.py:864,906-912) as one GEMM
     scattering into [B,2H,2W,Cout]. w: fp32 [4*Cout,1,1,Cin] (products = 0) or the (w_hi, w_lo) fp16 planes of it

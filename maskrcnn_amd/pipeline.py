@@ -10,8 +10,8 @@ Differences from the reference, all by design:
     host synchronisation anywhere and the whole step can be captured in a hipGraph;
   * the Python per-class loop (model.py:1454-1475) is one class-aware NMS launch per batch;
   * activations are channels-last (NHWC) between the NCHW boundary and the outputs.
-Heavy work (convs/GEMMs, RoIAlign, NMS) runs in libmaskrcnn_hip.so; torch does device memory, streams
-and the small elementwise/top-k glue (softmax over pairs, top-k, gathers, box decode).
+Every kernel of the step — convs/GEMMs, RoIAlign, NMS, the softmax / box-decode glue, top-k and the selection
+gathers — is in libmaskrcnn_hip.so; torch does device memory and streams.
 """
 from __future__ import annotations
 
@@ -23,21 +23,6 @@ from . import image as imagelib
 from . import modules, ops
 from .anchors import pyramid_anchors
 from .config import InferenceConfig
-
-
-def boxes_refine(boxes: torch.Tensor, deltas: torch.Tensor) -> torch.Tensor:
-    """data.py:124-148, same fp32 op order, on [..., 4] tensors."""
-    height = boxes[..., 2] - boxes[..., 0]
-    width = boxes[..., 3] - boxes[..., 1]
-    center_y = boxes[..., 0] + 0.5 * height
-    center_x = boxes[..., 1] + 0.5 * width
-    center_y = center_y + deltas[..., 0] * height
-    center_x = center_x + deltas[..., 1] * width
-    height = height * torch.exp(deltas[..., 2])
-    width = width * torch.exp(deltas[..., 3])
-    y1 = center_y - 0.5 * height
-    x1 = center_x - 0.5 * width
-    return torch.stack([y1, x1, y1 + height, x1 + width], dim=-1)
 
 
 @dataclass
@@ -71,11 +56,7 @@ class MaskRCNNInference:
         self.classifier = modules.FusedClassifier(state_dict, self.device, precision=precision)
         self.mask = modules.FusedMask(state_dict, self.device, precision=precision)
         self.anchors = pyramid_anchors(c).to(self.device)
-        f32 = dict(dtype=torch.float32, device=self.device)
-        self.std = torch.tensor(c.rpn_bbox_std_dev, **f32)
-        h, w = c.image_height, c.image_width
-        self.norm = torch.tensor([h, w, h, w], **f32)
-        self.image_area = float(h * w)
+        self.image_area = float(c.image_height * c.image_width)
 
     # ---------------------------------------------------------------- stage 1: proposals
     def rpn_heads(self, fms):
@@ -87,26 +68,23 @@ class MaskRCNNInference:
         counts int32 [B], plus the dets handed to NMS (for parity tests)."""
         c = self.cfg
         k = min(c.pre_nms_limit, self.anchors.size(0))
-        top, order = scores.topk(k, dim=1, sorted=True)                  # model.py:1345-1348
+        top, order = ops.topk_desc(scores, k)                            # model.py:1345-1348
         # gather + boxes_scale + boxes_refine + boxes_clamp_ (:1341-1358) in one launch
         dets = ops.proposal_decode(self.anchors, deltas, order, top, c.rpn_bbox_std_dev, c.image_height,
                                    c.image_width)
-        boxes = dets[..., :4]
-        keep, counts = ops.nms_batched(dets, c.rpn_nms_threshold)        # :1364, score order == index order
-        p = min(c.proposal_count, k)
-        counts = counts.clamp(max=p)                                     # keep[:proposal_count] :1366
-        idx = keep[:, :p]
-        valid = idx >= 0
-        rois = boxes.gather(1, idx.clamp(min=0).unsqueeze(-1).expand(-1, -1, 4)) / self.norm  # :1367-1374
-        rois = torch.where(valid.unsqueeze(-1), rois, torch.zeros_like(rois))
+        keep, kept = ops.nms_batched(dets, c.rpn_nms_threshold)          # :1364, score order == index order
+        # keep[:proposal_count], gather, normalise (:1366-1374) in one launch
+        rois, counts = ops.proposal_select(dets, keep, kept, min(c.proposal_count, k), c.image_height,
+                                           c.image_width)
         return rois, counts, dets
 
     # ---------------------------------------------------------------- stage 2: detections
     def detections(self, rois, roi_counts, logits, bbox, windows):
         """mrn_refine (model.py:1389-1487), batched and sync-free.
-        rois [B,P,4]; logits [B*P,C]; bbox [B*P,C,4]; windows [B,4] pixel (y1,x1,y2,x2)."""
+        rois [B,P,4]; logits [B*P,C]; bbox [B*P,C,4]; windows [B,4] pixel (y1,x1,y2,x2).
+        → class ids, scores, pixel boxes, normalised boxes for the mask head, counts."""
         c = self.cfg
-        b, p, _ = rois.shape
+        p = rois.size(1)
         # softmax/argmax (:791,1407-1415), delta gather, boxes_refine, scale, window clip, round (:1418-1432) and
         # the validity rule (:1437-1443) in one launch; excluded slots get a unique negative NMS class so they
         # neither suppress nor are suppressed in the class-aware pass that replaces the per-class loop (:1454-1475)
@@ -114,22 +92,10 @@ class MaskRCNNInference:
                                                     windows.to(torch.float32).contiguous(), c.rpn_bbox_std_dev,
                                                     c.image_height, c.image_width,
                                                     float(c.detection_min_confidence or 0.0))
-        boxes, class_scores = dets[..., :4], dets[..., 4]
-        valid = cls > 0
-        keep, _ = ops.nms_batched(dets, c.detection_nms_threshold, class_ids=cls)
-        kept = torch.zeros(b, p + 1, dtype=torch.bool, device=rois.device)
-        kept.scatter_(1, keep + 1, True)                                   # -1 padding lands in column 0
-        kept = kept[:, 1:] & valid
-        d = min(c.detection_max_instances, p)
-        masked = torch.where(kept, class_scores, torch.full_like(class_scores, -1.0))
-        top, idx = masked.topk(d, dim=1, sorted=True)                     # :1478-1480
-        ok = top >= 0
-        counts = ok.sum(dim=1).to(torch.int32)
-        out_ids = torch.where(ok, class_ids.gather(1, idx), torch.zeros_like(idx))
-        out_scores = torch.where(ok, top, torch.zeros_like(top))
-        out_boxes = boxes.gather(1, idx.unsqueeze(-1).expand(-1, -1, 4))
-        out_boxes = torch.where(ok.unsqueeze(-1), out_boxes, torch.zeros_like(out_boxes))
-        return out_ids, out_scores, out_boxes, counts
+        keep, kept = ops.nms_batched(dets, c.detection_nms_threshold, class_ids=cls)
+        # keep ∩ foreground, top detection_max_instances by score, gathers (:1475-1487) in one launch
+        return ops.detection_select(dets, cls, class_ids, keep, kept, min(c.detection_max_instances, p),
+                                    c.image_height, c.image_width)
 
     # ---------------------------------------------------------------- whole step
     @torch.no_grad()
@@ -148,15 +114,15 @@ class MaskRCNNInference:
         flat = rois.reshape(-1, 4).contiguous()
         pooled = ops.roi_align_pyramid(fms[:4], flat, c.pool_size, self.image_area, rois_per_image=p)
         logits, bbox = self.classifier(pooled)
-        ids, det_scores, boxes, counts = self.detections(rois, roi_counts, logits, bbox,
-                                                         windows.to(self.device))
+        ids, det_scores, boxes, mrois, counts = self.detections(rois, roi_counts, logits, bbox,
+                                                                windows.to(self.device))
         masks = None
         if with_masks:
             d = boxes.size(1)
             # the reference divides all four coordinates by h (model.py:1188), which is only right for
             # square inputs; here (y,x) are divided by (h,w)
-            mrois = (boxes / self.norm).reshape(-1, 4).contiguous()
-            mp = ops.roi_align_pyramid(fms[:4], mrois, c.mask_pool_size, self.image_area, rois_per_image=d)
+            mp = ops.roi_align_pyramid(fms[:4], mrois.view(-1, 4), c.mask_pool_size, self.image_area,
+                                       rois_per_image=d)
             m = self.mask(mp)
             masks = m.view(b, d, m.size(1), m.size(2), m.size(3))
         det = Detections(ids, det_scores, boxes, counts, masks)

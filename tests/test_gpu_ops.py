@@ -303,3 +303,92 @@ def test_detection_decode_vs_oracle_math(dev, oracle):
             assert torch.equal(nms_cls[b] > 0, valid)
             assert torch.equal(nms_cls[b][valid].long(), ids[b * P:(b + 1) * P][valid])
             assert nms_cls[b][~valid].unique().numel() == int((~valid).sum())   # unique negatives
+
+
+# --------------------------------------------------------------------------------------------------
+# selection kernels (csrc/select.hip): exact integer/compare work, compared bit for bit
+# --------------------------------------------------------------------------------------------------
+def _ref_topk(scores, k):
+    """descending score, ties by ascending index — a stable sort of the negated keys (CPU)."""
+    order = torch.sort(scores.cpu(), dim=1, descending=True, stable=True).indices[:, :k]
+    return scores.cpu().gather(1, order), order
+
+
+def test_topk_desc(dev):
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(21)
+    cases = [(8, 261888, 1000), (2, 261888, 500), (3, 1000, 1000), (1, 5, 3), (2, 70000, 4096), (1, 1, 1),
+             (4, 12345, 77)]
+    for b, n, k in cases:
+        s = torch.rand(b, n, generator=g)
+        top, order = ops.topk_desc(s.to(dev), k)
+        rt, ro = _ref_topk(s, k)
+        assert torch.equal(order.cpu(), ro) and torch.equal(top.cpu(), rt), (b, n, k)
+    # heavy ties (saturated scores), negative values, -0.0 / +0.0, infinities
+    s = torch.randint(0, 4, (3, 50000), generator=g).float() / 3.0
+    s[0, :100] = 1.0
+    s[1] = -s[1]
+    s[2, ::7] = float("inf")
+    s[2, 1::7] = float("-inf")
+    s[2, 2::7] = -0.0
+    for k in (1, 64, 1000, 4096):
+        top, order = ops.topk_desc(s.to(dev), k)
+        rt, ro = _ref_topk(s, k)
+        # -0.0 and +0.0 compare equal on the CPU sort; the kernel orders -0.0 below +0.0 — compare values, and
+        # indices wherever the value is not a zero
+        assert torch.equal(top.cpu(), rt), k
+        nz = rt != 0
+        assert torch.equal(order.cpu()[nz], ro[nz]), k
+    s = torch.full((2, 3000), 0.5)                                       # all equal: the first k indices
+    top, order = ops.topk_desc(s.to(dev), 1000)
+    assert torch.equal(order.cpu(), torch.arange(1000).expand(2, 1000))
+
+
+def test_proposal_select(dev):
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(22)
+    b, k, p = 4, 1000, 600
+    dets = torch.rand(b, k, 5, generator=g) * 1000
+    keep = torch.full((b, k), -1, dtype=torch.int64)
+    counts = torch.tensor([700, 600, 10, 0], dtype=torch.int32)
+    for i in range(b):
+        n = int(counts[i])
+        keep[i, :n] = torch.sort(torch.randperm(k, generator=g)[:n]).values
+    rois, cnt = ops.proposal_select(dets.to(dev), keep.to(dev), counts.to(dev), p, 1024, 768)
+    norm = torch.tensor([1024.0, 768.0, 1024.0, 768.0])
+    assert cnt.cpu().tolist() == [600, 600, 10, 0]
+    for i in range(b):
+        n = min(int(counts[i]), p)
+        ref = torch.zeros(p, 4)
+        ref[:n] = dets[i, keep[i, :n], :4] / norm                       # model.py:1367-1374
+        assert torch.equal(rois[i].cpu(), ref), i
+
+
+def test_detection_select(dev):
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(23)
+    for (b, p, d) in ((3, 1000, 50), (2, 200, 20), (1, 37, 37), (2, 4096, 100)):
+        dets = torch.rand(b, p, 5, generator=g)
+        dets[..., :4] = (dets[..., :4] * 900).round()
+        dets[0, : p // 2, 4] = dets[0, 0, 4]                              # ties → lowest index first
+        class_ids = torch.randint(0, 81, (b, p), generator=g)
+        nms_cls = torch.where(class_ids > 0, class_ids, -torch.arange(1, p + 1).expand(b, p)).to(torch.int32)
+        keep = torch.full((b, p), -1, dtype=torch.int64)
+        counts = torch.zeros(b, dtype=torch.int32)
+        for i in range(b):
+            n = int(torch.randint(0, p + 1, (1,), generator=g)) if i else p * 3 // 4
+            keep[i, :n] = torch.sort(torch.randperm(p, generator=g)[:n]).values
+            counts[i] = n
+        ids, scores, boxes, rois, cnt = ops.detection_select(dets.to(dev), nms_cls.to(dev), class_ids.to(dev),
+                                                             keep.to(dev), counts.to(dev), d, 1024, 1024)
+        for i in range(b):
+            kept = torch.zeros(p, dtype=torch.bool)
+            kept[keep[i, : int(counts[i])]] = True
+            cand = (kept & (nms_cls[i] > 0)).nonzero().flatten()
+            order = cand[torch.sort(dets[i, cand, 4], descending=True, stable=True).indices][:d]
+            n = len(order)
+            assert int(cnt[i]) == n
+            assert torch.equal(ids[i, :n].cpu(), class_ids[i, order]) and not ids[i, n:].any()
+            assert torch.equal(scores[i, :n].cpu(), dets[i, order, 4]) and not scores[i, n:].any()
+            assert torch.equal(boxes[i, :n].cpu(), dets[i, order, :4]) and not boxes[i, n:].any()
+            assert torch.equal(rois[i, :n].cpu(), dets[i, order, :4] / 1024.0) and not rois[i, n:].any()
