@@ -291,7 +291,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
     }
 
     // ---- epilogue: affine + residual + activation (conv_common.hpp) -------------------------------------
-    if constexpr (RES != 5) epilogue<TM, TN, WTM, WTN, RES>(p, acc, m0, n0, wm, wn, lane);
+    ResidualRegs<TM, TN, RES> rv;  // fetched in one burst, ahead of every store
+    if constexpr (RES != 5) load_residual<TM, TN, WTM, WTN, RES>(p, m0, n0, wm, wn, lane, rv);
+    if constexpr (RES != 5) epilogue<TM, TN, WTM, WTN, RES>(p, acc, rv, m0, n0, wm, wn, lane);
 }
 
 template <int BM, int BN, int WM, int WN, int BK>
@@ -366,12 +368,8 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
     // measured 3-20 % faster on the C2 layers. The stem (generic K) keeps BK = 32.
     if (cout <= 64) return (generic || force == 4) ? launch_conv<256, 64, 4, 1, 32>(p, generic, s)
                                                    : launch_conv<256, 64, 4, 1, 16>(p, generic, s);
-    // big tile (256x128, BK 16: 25% fewer LDS/global bytes per MFMA) once there is enough work to fill the chip
-    const long long big_tiles = ((M + 255) / 256) * ((cout + 127) / 128);
-    // measured on MI355X (round 1): no gain over 128x128 even on the largest layers (133.5 vs 133.2 TFLOP/s),
-    // a loss on mid-size ones; kept selectable for tuning only.
-    const bool use_big = force == 2 && big_tiles >= 1 && !generic;
-    if (use_big) return launch_conv<256, 128, 2, 2, 16>(p, generic, s);
+    // (a 256x128 BK16 tile — 25% fewer LDS/global bytes per MFMA — was measured in round 1: no gain over 128x128 even on
+    // the largest layers, 133.5 vs 133.2 TFLOP/s, and a loss on mid-size ones; removed)
     if (force == 3 && !generic) return launch_conv<128, 128, 2, 2, 16>(p, generic, s);  // 41 KB LDS: 3 workgroups/CU
     return launch_conv<128, 128, 2, 2, 32>(p, generic, s);
 }

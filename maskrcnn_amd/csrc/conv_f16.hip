@@ -254,7 +254,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParamsH p) {
     }
 
     // ---- epilogue: affine + residual + activation (conv_common.hpp) -------------------------------------
-    epilogue<TM, TN, WTM, WTN, RES>(p, acc, m0, n0, wm, wn, lane);
+    ResidualRegs<TM, TN, RES> rv;  // fetched in one burst, ahead of every store
+    load_residual<TM, TN, WTM, WTN, RES>(p, m0, n0, wm, wn, lane, rv);
+    epilogue<TM, TN, WTM, WTN, RES>(p, acc, rv, m0, n0, wm, wn, lane);
 }
 
 template <int BM, int BN, int WM, int WN, int PRODUCTS>
