@@ -229,6 +229,19 @@ int mrcnn_detection_decode_f32(const float* logits, int64_t logit_stride, const 
                                float image_height, float image_width, float min_confidence, float* dets,
                                int32_t* nms_class_ids, int64_t* class_ids, mrcnn_stream_t stream);
 
+/* 3x3 stride-1 SAME convolution + affine + ReLU as a fused Winograd F(2x2,3x3) on the fp32 MFMA: 2.25x fewer
+ * multiply-adds than mrcnn_conv_bn_act_nhwc_f32 for the same layer, all arithmetic in fp32 (the result differs by the
+ * transforms' rounding, a few 1e-7 relative per term). x [batch][H][W][cin] -> y [batch][H][W][cout], H and W even,
+ * cin % 8 == 0. u = the filter transformed once by mrcnn_winograd_weights_f32: w [cout][3][3][cin] (OHWI) ->
+ * u (16*cout*cin floats, k-blocked [cin/8][16][cout][8]). activation 0 (none) or 1 (ReLU). workspace: device memory of
+ * mrcnn_conv3x3_winograd_workspace_bytes(...) bytes (the k-blocked copy of x the kernel reads). */
+int mrcnn_winograd_weights_f32(const float* w, int32_t cout, int32_t cin, float* u, mrcnn_stream_t stream);
+size_t mrcnn_conv3x3_winograd_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t cin);
+int mrcnn_conv3x3_winograd_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                    const float* u, int32_t cout, const float* scale, const float* shift,
+                                    int32_t activation, float* y, void* workspace, size_t workspace_bytes,
+                                    mrcnn_stream_t stream);
+
 /* ---- selection steps of the two refine stages (no library sort / top-k / gather in the step) --------------------
  * Total, deterministic order everywhere: descending score, ties by ascending index (ATen's sort, which the
  * reference calls at model.py:1346,1478, leaves ties unspecified).

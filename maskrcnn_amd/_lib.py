@@ -53,6 +53,10 @@ _SIGS = {
     "mrcnn_detection_decode_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
                                                     ctypes.POINTER(c_f32), c_f32, c_f32, c_f32, c_vp, c_vp, c_vp,
                                                     c_vp]),
+    "mrcnn_winograd_weights_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "mrcnn_conv3x3_winograd_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32]),
+    "mrcnn_conv3x3_winograd_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32,
+                                                         c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "mrcnn_topk_workspace_bytes": (ctypes.c_size_t, [c_i32]),
     "mrcnn_topk_desc_f32": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "mrcnn_proposal_select_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp,

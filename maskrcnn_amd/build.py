@@ -27,6 +27,7 @@ SOURCES = {
     "crop.hip": ["-ffp-contract=off"],
     "conv.hip": [],
     "conv_f16.hip": [],
+    "conv_wino.hip": [],
     "misc.hip": ["-ffp-contract=off"],
     "select.hip": ["-ffp-contract=off"],
     "image.hip": ["-ffp-contract=off"],   # Pillow's coefficient arithmetic, operation by operation in fp64

@@ -1,0 +1,385 @@
+// 3x3 stride-1 SAME convolution + per-channel affine + ReLU as a fused Winograd F(2x2, 3x3) on the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32), channels-last. 2.25x fewer multiply-adds than the direct implicit GEMM of conv.hip for the
+// layers that hold three quarters of the step's FLOPs (FPN smoothing model.py:154-157, RPN conv_shared :605,624,
+// Bottleneck conv2 :182, the mask head's four 3x3 convs :880-903). All arithmetic is fp32; the result differs from
+// the direct kernel by the transforms' rounding (a few 1e-7 relative per term), well inside the 1e-4 parity bar.
+//
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A       g: 3x3 filter, d: 4x4 input patch, Y: 2x2 outputs
+//
+//   GEMM view   16 independent products, one per transform component xi: M_xi[T x N] = V_xi[T x C] U_xi[C x N],
+//               T = B*(H/2)*(W/2) tile positions, N = Cout, C = Cin. U is transformed once by wino_weights_kernel.
+//   tile        a workgroup owns 64 consecutive tile positions x 64 output channels; wave w owns transform row i = w
+//               (components 4w..4w+3) for the whole tile: 4 x (2 x 2) accumulator tiles = 256 registers per lane, so one
+//               wave per SIMD (__launch_bounds__(256, 1)) and one workgroup per CU (128 KB of LDS).
+//   layouts     both operands are k-blocked: x as [Cin/8][B*H*W][8] (kblock_kernel, one extra HBM pass over the input),
+//               U as [Cin/8][16][Cout][8], so that a k tile's loads use whole cache lines. In NHWC an 8-channel k
+//               tile is 32 bytes out of every 128-byte line and the kernel was bound by L2 -> L1 traffic (43 % MFMA).
+//   staging     per k tile of 8 input channels: waves 0-1 fetch their position's 4x4 patch (16 x 16-byte loads, zero
+//               padding by descriptor range check; neighbouring positions overlap, served by L1), apply B^T . B in
+//               registers and write the 16 components to LDS; waves 2-3 copy the 16 x 64 x 8 block of U.
+//               Double-buffered, one barrier per k tile; loads for k tile t+2 are in flight during the MFMAs of t+1.
+//   MFMA        per component and k tile: two ds_read_b128 per operand (lane half h holds channels 4h..4h+3, the k
+//               permutation of conv.hip) feed sixteen MFMAs.
+//   epilogue    M A in registers, A^T (M A) across the four waves through LDS, affine, ReLU, 256-byte channel runs.
+#include "conv_common.hpp"
+
+#include <cstdlib>
+
+namespace {
+
+using namespace mrcnn_conv;
+
+struct WinoParams {
+    const float* x;      // k-blocked input  [Cin/8][B*H*W][8]
+    const float* u;      // k-blocked filter [Cin/8][16][Cout][8]
+    const float* scale;  // [Cout] or null
+    const float* shift;  // [Cout] or null
+    float* y;            // [B][H][W][Cout]
+    int B, H, W, Cin, Cout, TH, TW, T, act;
+    unsigned x_plane, u_plane;  // bytes per 8-channel plane of x / u
+    int tiles_m, tiles_n;
+    unsigned x_bytes, u_bytes, y_bytes;
+};
+
+constexpr int WT = 64;   // tile positions per workgroup
+constexpr int WN = 64;   // output channels per workgroup
+constexpr int WK = 8;    // input channels per k tile
+constexpr int PLANE = WT * WK;  // floats per component plane (V and U alike: WT == WN)
+constexpr size_t WINO_LDS = sizeof(float) * 2 * 2 * 16 * PLANE;  // {V,U} x 2 buffers x 16 components = 128 KiB
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const WinoParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Vs = smem;                    // [2 buffers][16 components][2 quads][WT][4]
+    float* Us = smem + 2 * 16 * PLANE;   // [2 buffers][16 components][2 quads][WN][4]
+
+    ConvCommon tc;  // only the fields tile_origin reads
+    tc.tiles_m = p.tiles_m;
+    tc.tiles_n = p.tiles_n;
+    int m0, n0, nt;
+    if (!tile_origin(tc, WT, WN, m0, n0, nt)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ln = lane & 31, lh = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+
+    // ---- staging bookkeeping. On this MFMA every VALU instruction costs its four issue cycles on top of the MFMA
+    // time (measured: tools/mfma_valu_probe.hip — no co-execution, within a wave or across waves), so the loop
+    // carries no address arithmetic at all: per-thread byte offsets are fixed for the whole tile (voffset, out of
+    // range where the load must return zeros), the k tile's plane is the scalar soffset, LDS addresses are one base
+    // register plus instruction-immediate offsets, and the transform is spread evenly over all four waves.
+    //   V: thread = (position tid & 63, channel pair tid >> 6): sixteen 8-byte patch loads
+    //   U: eight 16-byte slots of the 16 x 64 x 8 block
+    unsigned voff[16], uoff[8];
+    {
+        const int pos = tid & 63, pair = tid >> 6;
+        const int P = m0 + pos;
+        const bool pv = P < p.T;
+        const int PP = pv ? P : 0;
+        const int b = PP / (p.TH * p.TW), rem = PP - b * p.TH * p.TW;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+        const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const int iy = iy0 + dy, ix = ix0 + dx;
+                const bool ok = pv && static_cast<unsigned>(iy) < static_cast<unsigned>(p.H) &&
+                                static_cast<unsigned>(ix) < static_cast<unsigned>(p.W);
+                voff[dy * 4 + dx] = ok ? static_cast<unsigned>(((b * p.H + iy) * p.W + ix) * WK + pair * 2) * 4u : OOB;
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int id = tid + 256 * i;  // float4 id inside the 16 x 64 x 8 block
+            const int xi = id >> 7, r = id & 127, q = r >> 6, ch = r & 63;
+            const int n = n0 + ch;
+            uoff[i] = n < p.Cout ? static_cast<unsigned>((xi * p.Cout + n) * WK + q * 4) * 4u : OOB;
+        }
+    }
+    // LDS float offsets inside a buffer: V component xi at v_lds + xi*PLANE; U slot i at u_lds + i*2*PLANE
+    // (id = tid + 256*i: xi = 2i + (tid >> 7), so consecutive slots are two planes apart)
+    const int v_lds = (tid >> 7) * (WT * 4) + (tid & 63) * 4 + ((tid >> 6) & 1) * 2;
+    const int u_lds = (tid >> 7) * PLANE + ((tid & 127) >> 6) * (WN * 4) + (tid & 63) * 4;
+
+    const int nk = (p.Cin + WK - 1) / WK;
+    f32x2 vl[16];  // raw patch of the k tile in flight
+    u32x4 ul[8];
+    auto plane_of = [&](int kt) { return static_cast<unsigned>(kt < nk ? kt : nk - 1); };  // past the end: reload, unused
+    auto v_load = [&](int i, int kt) {
+        const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, static_cast<int>(voff[i]),
+                                                             static_cast<int>(plane_of(kt) * p.x_plane), 0);
+        vl[i] = f32x2{__uint_as_float(r.x), __uint_as_float(r.y)};
+    };
+    auto u_load = [&](int i, int kt) {
+        ul[i] = __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, static_cast<int>(uoff[i]),
+                                                      static_cast<int>(plane_of(kt) * p.u_plane), 0);
+    };
+    // V = B^T d B on two channels at a time, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: first down the columns
+    // (t), then along the rows (one output component at a time)
+    f32x2 t[4][4];
+    auto column_pass = [&](int dx) {
+        const f32x2 d0 = vl[0 * 4 + dx], d1 = vl[1 * 4 + dx], d2 = vl[2 * 4 + dx], d3 = vl[3 * 4 + dx];
+        t[0][dx] = d0 - d2;
+        t[1][dx] = d1 + d2;
+        t[2][dx] = d2 - d1;
+        t[3][dx] = d1 - d3;
+    };
+    auto v_store = [&](int xi, float* vbuf) {
+        const int i = xi >> 2, j = xi & 3;
+        const f32x2 v = j == 0 ? t[i][0] - t[i][2] : j == 1 ? t[i][1] + t[i][2] : j == 2 ? t[i][2] - t[i][1]
+                                                                                         : t[i][1] - t[i][3];
+        *reinterpret_cast<f32x2*>(vbuf + xi * PLANE) = v;
+    };
+    auto u_store = [&](int i, float* ubuf) { *reinterpret_cast<u32x4*>(ubuf + i * 2 * PLANE) = ul[i]; };
+
+    // wave w owns transform row i = w: components xi = 4w + j, j = 0..3, for the WHOLE 64 x 64 workgroup tile
+    // (2 x 2 MFMA tiles per component: an operand fragment is reused twice, 0.25 LDS reads per MFMA as in conv.hip)
+    f32x16 acc[4][2][2];  // [j][position half][channel half]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][a][c][r] = 0.f;
+
+    // prologue: k tile 0 into buffer 0, loads of k tile 1 in flight
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v_load(i, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u_load(i, 0);
+#pragma unroll
+    for (int dx = 0; dx < 4; ++dx) column_pass(dx);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) v_store(xi, Vs + v_lds);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u_store(i, Us + u_lds);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v_load(i, 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u_load(i, 1);
+    __syncthreads();
+
+    // a component plane is [2 channel quads][64 rows][4 channels]: staging writes (a lane per row) and operand reads
+    // (a lane per row, lane half = quad) are both contiguous 16-byte runs across lanes — no LDS bank conflicts
+    const float* Aw = Vs + (wave * 4) * PLANE + lh * (WT * 4) + ln * 4;
+    const float* Bw = Us + (wave * 4) * PLANE + lh * (WN * 4) + ln * 4;
+    float4 fa[2][2], fb[2][2];  // [slot][half]
+    auto read_frags = [&](int slot, int buf, int j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            fa[slot][h] = *reinterpret_cast<const float4*>(Aw + buf * 16 * PLANE + j * PLANE + h * 32 * 4);
+            fb[slot][h] = *reinterpret_cast<const float4*>(Bw + buf * 16 * PLANE + j * PLANE + h * 32 * 4);
+        }
+    };
+    read_frags(0, 0, 0);
+    // ---- main loop: 64 MFMAs per k tile and wave (4 components x 2 x 2 tiles x 4 k steps), order pinned. Staging of
+    // k tile kt+1 (its loads were issued during k tile kt-1) is spread over MFMA slots 8..39 of every wave; the barrier
+    // sits before the last component, whose operands are already in registers, so that the first operands of k tile
+    // kt+1 are fetched behind it, not after it.
+    //   slot 8-11 column passes | 12-27 reissue the patch loads for k tile kt+2 | 16-31 one V component out each
+    //   slot 32-39 one U slot to LDS + reissue its load
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        float* vnext = Vs + (buf ^ 1) * 16 * PLANE + v_lds;
+        float* unext = Us + (buf ^ 1) * 16 * PLANE + u_lds;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cur = j & 1;
+            if (j + 1 < 4) {
+                read_frags(cur ^ 1, buf, j + 1);
+            } else {
+                __syncthreads();  // k tile kt+1 is complete in buf^1; everyone is done reading buf
+                read_frags(cur ^ 1, buf ^ 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const float4 fav = fa[cur][a], fbv = fb[cur][c];
+                        const float av = st == 0 ? fav.x : st == 1 ? fav.y : st == 2 ? fav.z : fav.w;
+                        const float bv = st == 0 ? fbv.x : st == 1 ? fbv.y : st == 2 ? fbv.z : fbv.w;
+                        acc[j][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j][a][c], 0, 0, 0);
+                        const int m = j * 16 + st * 4 + a * 2 + c;  // MFMA slot 0..63
+                        if (m >= 8 && m < 12) column_pass(m - 8);
+                        if (m >= 12 && m < 28) v_load(m - 12, kt + 2);
+                        if (m >= 16 && m < 32) v_store(m - 16, vnext);
+                        if (m >= 32 && m < 40) {
+                            u_store(m - 32, unext);
+                            u_load(m - 32, kt + 2);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1] ---------------------------------------------------------
+    // The wave holds row i = wave of M (4 columns j): the column combination (M A) happens in registers, the row
+    // combination crosses waves through LDS: Z[i][c][position][channel], 4 x 2 x 64 x 64 floats = the 128 KB the
+    // operand buffers occupied. Then every wave finishes 16 positions: affine, ReLU, 256-byte channel runs.
+    __syncthreads();  // (the behind-the-barrier operand prefetch of a k tile that does not exist is still in flight)
+    float* Z = smem;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pos = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, ch = c * 32 + ln;
+                const float m0v = acc[0][a][c][r], m1v = acc[1][a][c][r], m2v = acc[2][a][c][r], m3v = acc[3][a][c][r];
+                Z[((wave * 2 + 0) * WT + pos) * WN + ch] = m0v + m1v + m2v;
+                Z[((wave * 2 + 1) * WT + pos) * WN + ch] = m1v - m2v - m3v;
+            }
+    __syncthreads();
+    const int ch = lane, n = n0 + ch;
+    const bool n_ok = n < p.Cout;
+    const float sc = (n_ok && p.scale) ? p.scale[n] : 1.0f, sh = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const unsigned ncol = n_ok ? static_cast<unsigned>(n) * 4u : OOB;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const int pos = wave * 16 + q;
+        const int P = __builtin_amdgcn_readfirstlane(m0 + pos);
+        const bool pv = P < p.T;
+        const int PP = pv ? P : 0;
+        const int b = PP / (p.TH * p.TW), rem = PP - b * p.TH * p.TW;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float z0 = Z[((0 * 2 + c) * WT + pos) * WN + ch], z1 = Z[((1 * 2 + c) * WT + pos) * WN + ch];
+            const float z2 = Z[((2 * 2 + c) * WT + pos) * WN + ch], z3 = Z[((3 * 2 + c) * WT + pos) * WN + ch];
+            const float yv[2] = {z0 + z1 + z2, z1 - z2 - z3};
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float v = yv[a] * sc + sh;
+                if (p.act) v = v > 0.f ? v : 0.f;
+                const unsigned row = static_cast<unsigned>((b * p.H + 2 * ty + a) * p.W + 2 * tx + c) *
+                                     (static_cast<unsigned>(p.Cout) * 4u);
+                const unsigned o = (pv && n_ok) ? row + ncol : OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(o), 0, 0);
+            }
+        }
+    }
+}
+
+// U_xi[n][c] = (G g G^T)[i][j], xi = 4i + j, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; evaluated in double; stored
+// k-blocked [Cin/8][16][Cout][8] so that a k tile's 16 x 64 x 8 block is sixteen contiguous 2 KB runs.
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, int cout, int cin,
+                                                           float* __restrict__ u) {
+    const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (e >= static_cast<int64_t>(cout) * cin) return;
+    const int n = static_cast<int>(e / cin), c = static_cast<int>(e - static_cast<int64_t>(n) * cin);
+    double g[3][3];
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((static_cast<int64_t>(n) * 3 + ky) * 3 + kx) * cin + c];
+    double t[4][3];
+    for (int kx = 0; kx < 3; ++kx) {
+        t[0][kx] = g[0][kx];
+        t[1][kx] = 0.5 * (g[0][kx] + g[1][kx] + g[2][kx]);
+        t[2][kx] = 0.5 * (g[0][kx] - g[1][kx] + g[2][kx]);
+        t[3][kx] = g[2][kx];
+    }
+    for (int i = 0; i < 4; ++i) {
+        const double r[4] = {t[i][0], 0.5 * (t[i][0] + t[i][1] + t[i][2]), 0.5 * (t[i][0] - t[i][1] + t[i][2]), t[i][2]};
+        for (int j = 0; j < 4; ++j)
+            u[((static_cast<int64_t>(c >> 3) * 16 + (i * 4 + j)) * cout + n) * 8 + (c & 7)] = static_cast<float>(r[j]);
+    }
+}
+
+// NHWC [M][C] -> k-blocked [C/8][M][8] through LDS: reads are full rows, writes 32-byte pieces that are contiguous
+// across consecutive pixels. The Winograd kernel's patch loads then use every byte of the cache lines they touch
+// (in NHWC an 8-channel k tile is 32 bytes out of every 128-byte line: 4x the L2 -> L1 traffic, and the kernel was
+// bound by it).
+__global__ __launch_bounds__(256) void kblock_kernel(const float* __restrict__ x, int64_t M, int C,
+                                                     float* __restrict__ y) {
+    __shared__ float tile[32][64 + 1];  // 32 pixels x 64 channels
+    const int64_t m0 = static_cast<int64_t>(blockIdx.x) * 32;
+    const int c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 32 * 16; i += 256) {  // float4 reads: 16 per pixel row
+        const int r = i >> 4, q = i & 15;
+        const int64_t m = m0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M && c0 + q * 4 < C) v = *reinterpret_cast<const float4*>(x + m * C + c0 + q * 4);
+        tile[r][q * 4 + 0] = v.x; tile[r][q * 4 + 1] = v.y; tile[r][q * 4 + 2] = v.z; tile[r][q * 4 + 3] = v.w;
+    }
+    __syncthreads();
+    for (int i = tid; i < 8 * 32 * 2; i += 256) {  // (channel group, pixel, half): float4 writes
+        const int g = i >> 6, r = (i >> 1) & 31, h = i & 1;
+        const int64_t m = m0 + r;
+        const int c = c0 + g * 8 + h * 4;
+        if (m < M && c < C) {
+            const float4 v = make_float4(tile[r][g * 8 + h * 4 + 0], tile[r][g * 8 + h * 4 + 1],
+                                         tile[r][g * 8 + h * 4 + 2], tile[r][g * 8 + h * 4 + 3]);
+            *reinterpret_cast<float4*>(y + (static_cast<int64_t>(c >> 3) * M + m) * 8 + h * 4) = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mrcnn_winograd_weights_f32(const float* w, int32_t cout, int32_t cin, float* u, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(w && u, "winograd_weights: null pointer");
+    MRCNN_REQUIRE(cout >= 1 && cin >= 1 && 16LL * cout * cin < (1LL << 30), "winograd_weights: cout=%d cin=%d", cout, cin);
+    const int64_t n = static_cast<int64_t>(cout) * cin;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                       mrcnn::as_stream(stream), w, cout, cin, u);
+    return mrcnn::check_launch("wino_weights_kernel");
+}
+
+extern "C" size_t mrcnn_conv3x3_winograd_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t cin) {
+    if (batch < 1 || height < 1 || width < 1 || cin < 1) return 0;
+    return sizeof(float) * static_cast<size_t>(batch) * height * width * cin;
+}
+
+extern "C" int mrcnn_conv3x3_winograd_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
+                                               int32_t cin, const float* u, int32_t cout, const float* scale,
+                                               const float* shift, int32_t activation, float* y, void* workspace,
+                                               size_t workspace_bytes, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x && u && y && workspace, "conv3x3_winograd: null pointer");
+    MRCNN_REQUIRE(workspace_bytes >= mrcnn_conv3x3_winograd_workspace_bytes(batch, height, width, cin),
+                  "conv3x3_winograd: workspace too small");
+    MRCNN_REQUIRE(batch >= 1 && height >= 2 && width >= 2 && height % 2 == 0 && width % 2 == 0,
+                  "conv3x3_winograd: B=%d H=%d W=%d (even sizes required)", batch, height, width);
+    MRCNN_REQUIRE(cin >= 8 && cin % 8 == 0 && cout >= 1, "conv3x3_winograd: Cin=%d (%% 8 == 0 required) Cout=%d", cin, cout);
+    MRCNN_REQUIRE(activation == 0 || activation == 1, "conv3x3_winograd: activation must be 0 or 1");
+    const long long px = 1LL * batch * height * width;
+    MRCNN_REQUIRE(px * cin < (1LL << 30) && px * cout < (1LL << 30) && 16LL * cin * cout < (1LL << 30),
+                  "conv3x3_winograd: tensor too large (32-bit buffer byte offsets)");
+    hipStream_t st = mrcnn::as_stream(stream);
+    float* x8 = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(kblock_kernel, dim3(static_cast<unsigned>((px + 31) / 32), (cin + 63) / 64), dim3(256), 0, st, x,
+                       static_cast<int64_t>(px), cin, x8);
+    WinoParams p;
+    p.x = x8; p.u = u; p.scale = scale; p.shift = shift; p.y = y;
+    p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout;
+    p.TH = height / 2; p.TW = width / 2; p.T = batch * p.TH * p.TW; p.act = activation;
+    p.tiles_m = (p.T + WT - 1) / WT;
+    p.tiles_n = (cout + WN - 1) / WN;
+    p.x_bytes = static_cast<unsigned>(4LL * px * cin);
+    p.u_bytes = static_cast<unsigned>(4LL * 16 * cin * cout);
+    p.x_plane = static_cast<unsigned>(4LL * px * WK);
+    p.u_plane = static_cast<unsigned>(4LL * 16 * cout * WK);
+    p.y_bytes = static_cast<unsigned>(4LL * px * cout);
+    const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
+    MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd: grid too large");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_f32),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(WINO_LDS));
+        if (e != hipSuccess) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv3x3_wino_f32, dim3(static_cast<unsigned>(grid)), dim3(256), WINO_LDS, st, p);
+    return mrcnn::check_launch("conv3x3_wino_f32");
+}

@@ -623,3 +623,43 @@ def paste_masks(masks: torch.Tensor, class_ids: torch.Tensor, boxes: torch.Tenso
     check(lib.mrcnn_paste_masks_u8(masks.data_ptr(), sn, sy, sx, sc, n, mh, mw, c, class_ids.data_ptr(),
                                    boxes.data_ptr(), height, width, 255 if as_l8 else 1, out.data_ptr(), _stream()))
     return out if as_l8 else out.view(torch.bool)
+
+
+# --------------------------------------------------------------------------------------------------
+# Winograd F(2x2,3x3) 3x3 stride-1 SAME conv (csrc/conv_wino.hip)
+# --------------------------------------------------------------------------------------------------
+def winograd_weights(w_ohwi: torch.Tensor) -> torch.Tensor:
+    """[Cout,3,3,Cin] fp32 → the transformed filter G g G^T (evaluated in double), 16*Cout*Cin floats in the
+    kernel's k-blocked order [Cin/8][16][Cout][8] (returned with the logical shape [16,Cout,Cin])."""
+    _need_gpu(w_ohwi)
+    assert w_ohwi.dtype == torch.float32 and w_ohwi.is_contiguous() and tuple(w_ohwi.shape[1:3]) == (3, 3)
+    cout, cin = w_ohwi.size(0), w_ohwi.size(3)
+    u = torch.empty(16, cout, cin, dtype=torch.float32, device=w_ohwi.device)
+    check(lib.mrcnn_winograd_weights_f32(w_ohwi.data_ptr(), cout, cin, u.data_ptr(), _stream()))
+    return u
+
+
+def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, scale, shift, relu: bool = False, algo_cin=None):
+    """x NHWC fp32 [B,H,W,Cin] (H, W even; Cin % 8 == 0), u from winograd_weights → [B,H,W,Cout]:
+    relu(conv3x3_same(x) * scale + shift)."""
+    _need_gpu(x, u, scale, shift)
+    assert x.dtype == torch.float32 and x.is_contiguous() and u.is_contiguous()
+    b, h, w, cin = x.shape
+    cout = u.size(1)
+    assert u.size(2) == cin
+    y = torch.empty(b, h, w, cout, dtype=torch.float32, device=x.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    nbytes = int(lib.mrcnn_conv3x3_winograd_workspace_bytes(b, h, w, cin))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    check(lib.mrcnn_conv3x3_winograd_nhwc_f32(x.data_ptr(), b, h, w, cin, u.data_ptr(), cout, _ptr(scale), _ptr(shift),
+                                              1 if relu else 0, y.data_ptr(), ws.data_ptr(), nbytes, _stream()))
+    if prof is not None:
+        e1.record()
+        m, k = b * h * w, 9 * (algo_cin or cin)
+        # FLOPs are the algorithmic ones of the convolution (2*M*N*K), as for the direct kernel — not the reduced
+        # multiply count Winograd actually executes
+        prof.append((e0, e1, 2.0 * m * cout * k, (m, cout, k), 4.0 * (m * cin + m * cout + cout * k)))
+    return y
