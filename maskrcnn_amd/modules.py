@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -149,6 +151,12 @@ def pack_weight(w_oihw: torch.Tensor, device, cin_pad: int | None = None) -> tor
 PRECISIONS = ("f32", "f16x3", "f16")
 
 
+# f32 mode: 3x3 stride-1 SAME convs run the fused Winograd F(2x2,3x3) kernel (fp32 MFMA, 2.25x fewer multiply-adds;
+# results differ from the direct kernel by the transforms' rounding, ~1e-5 abs on unit-scale activations).
+# MRCNN_WINOGRAD=0 keeps every conv on the direct implicit-GEMM kernel (bitwise an fmaf chain).
+WINOGRAD = os.environ.get("MRCNN_WINOGRAD", "1") != "0"
+
+
 class ConvWeight:
     """A packed conv/GEMM weight [Cout,KH,KW,Cin] (OHWI) for one of the contraction modes:
        f32    exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)                      — the default, parity mode
@@ -159,8 +167,11 @@ class ConvWeight:
         assert precision in PRECISIONS, precision
         self.precision = precision
         self.shape = tuple(w_ohwi.shape)
+        self.u = None
         if precision == "f32":
             self.w = w_ohwi.contiguous()
+            if WINOGRAD and tuple(self.shape[1:3]) == (3, 3) and self.shape[3] % 8 == 0 and self.w.is_cuda:
+                self.u = ops.winograd_weights(self.w)
         else:
             cin = w_ohwi.size(3)
             if cin % 8:  # fp16 kernel loads 8 halves at a time
@@ -179,6 +190,9 @@ class ConvWeight:
     def conv(self, x, scale, shift, stride=1, pad=(0, 0, 0, 0), relu=False, residual=None, res_div=1,
              algo_cin=None):
         if self.precision == "f32":
+            if (self.u is not None and stride == 1 and tuple(pad) == (1, 1, 1, 1) and residual is None
+                    and relu in (False, True, 0, 1) and x.size(1) % 2 == 0 and x.size(2) % 2 == 0):
+                return ops.conv3x3_winograd(x, self.u, scale, shift, bool(relu), algo_cin)
             return ops.conv_bn_act(x, self.w, scale, shift, stride, pad, relu, residual, res_div, None,
                                    algo_cin)
         return ops.conv_bn_act_f16mfma(x, self.w_hi, self.w_lo, scale, shift, stride, pad, relu, residual,
@@ -212,7 +226,7 @@ class FusedBottleneck:
     @classmethod
     def from_state_dict(cls, sd, prefix, stride, device, precision="f32"):
         pre = (prefix + ".") if prefix and not prefix.endswith(".") else prefix
-        if precision != "f32":
+        if precision != "f32" or WINOGRAD:
             c1 = FusedConv(sd, pre + "conv1", pre + "bn1", device, stride=stride, relu=True, precision=precision)
             c2 = FusedConv(sd, pre + "conv2", pre + "bn2", device, relu=True, same_pad_kernel=3,
                            precision=precision)
@@ -235,7 +249,7 @@ class FusedBottleneck:
         return cls((w1, s1, t1, w2, s2, t2, w3, s3, t3, wd, sdn, tdn, int(stride)))
 
     def __call__(self, x):
-        if self.precision == "f32":
+        if self.convs is None:
             return torch.ops.maskrcnn.bottleneck_forward(x, *self.p)
         c1, c2, c3, cd = self.convs
         res = x if cd is None else cd(x)
@@ -321,7 +335,8 @@ class FusedRPN:
         w = torch.cat([sd[prefix + "conv_class.weight"], sd[prefix + "conv_bbox.weight"]], 0)
         self.b_head = torch.cat([sd[prefix + "conv_class.bias"], sd[prefix + "conv_bbox.bias"]]).float() \
             .contiguous().to(device)
-        if precision == "f32":
+        self.fused_level = precision == "f32" and not WINOGRAD
+        if self.fused_level:
             # fused level kernel: the 512-channel shared activation never leaves the chip (ops.rpn_level_fused)
             self.w_shared = pack_weight(sd[prefix + "conv_shared.weight"], device)
             self.b_shared = sd[prefix + "conv_shared.bias"].float().contiguous().to(device)
@@ -335,7 +350,7 @@ class FusedRPN:
             self.w_head = ConvWeight(pack_weight(w, device), precision)
 
     def __call__(self, p):
-        if self.precision == "f32":
+        if self.fused_level:
             return ops.rpn_level_fused(p, self.w_shared, self.b_shared, self.w_head32, self.b_head, self.head_n)
         return self.w_head.conv(self.shared(p), None, self.b_head)
 
