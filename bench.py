@@ -175,10 +175,16 @@ def main():
             net.predict(images, windows, with_masks=True)
         torch.cuda.synchronize()
         prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-        ms = sum(r[0].elapsed_time(r[1]) for r in prof)
+        times = [r[0].elapsed_time(r[1]) for r in prof]
+        ms = sum(times)
         flops = sum(r[2] for r in prof)
         algo_bytes = sum(r[4] for r in prof) / args.roofline_steps
         achieved = flops / (ms * 1e-3) / 1e12
+        # Winograd launches execute 2.25x fewer multiply-adds than the convolution's algorithmic count
+        is_w = [len(r) > 5 and r[5] == "winograd" for r in prof]
+        ms_w = sum(t for t, w in zip(times, is_w) if w)
+        fl_w = sum(r[2] for r, w in zip(prof, is_w) if w)
+        executed = (flops - fl_w + fl_w / 2.25) / (ms * 1e-3) / 1e12
         # HBM traffic of the conv launches of one step from the committed rocprofv3 PMC passes (separate runs of
         # this same command, FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied by profiles/summarize_pmc.py)
         traffic = None
@@ -195,14 +201,26 @@ def main():
                         for r in range(args.roofline_steps)) / args.roofline_steps
                 f, mnk = prof[i][2], prof[i][3]
                 rows.append({"i": i, "M": mnk[0], "N": mnk[1], "K": mnk[2], "ms": round(t, 4),
+                             "kernel": prof[i][5] if len(prof[i]) > 5 else "direct",
                              "tflops": round(f / (t * 1e-3) / 1e12, 1), "gflop": round(f / 1e9, 2)})
             with open(args.dump_conv, "w") as fh:
                 json.dump(rows, fh, indent=0)
         peak = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else F16_MFMA_PEAK_TFLOPS
-        roofline = {"bound": "mfma", "kernel": ("conv_igemm_f32" if args.precision == "f32" else "conv_igemm_f16")
-                    + " (all conv/GEMM launches of one step)",
+        kname = "conv_igemm_f16" if args.precision != "f32" else (
+            "conv3x3_wino_f32 + conv_igemm_f32" if ms_w > 0 else "conv_igemm_f32")
+        roofline = {"bound": "mfma", "kernel": kname + " (all conv/GEMM launches of one step)",
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "frac": round(achieved / peak, 4),
+                    "note": "achieved = ALGORITHMIC conv FLOPs (2*M*N*K of every layer) / summed launch time; the "
+                            "Winograd F(2x2,3x3) launches execute 2.25x fewer multiply-adds than that, which is how "
+                            "frac can exceed 1. executed_* count the multiply-adds the MFMA pipe really performs.",
+                    "executed_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4),
+                    "winograd": {"ms_per_step": round(ms_w / args.roofline_steps, 3),
+                                 "algorithmic_tflops": round(fl_w / (ms_w * 1e-3) / 1e12, 1) if ms_w else None,
+                                 "executed_tflops": round(fl_w / 2.25 / (ms_w * 1e-3) / 1e12, 1) if ms_w else None},
+                    "direct": {"ms_per_step": round((ms - ms_w) / args.roofline_steps, 3),
+                               "tflops": round((flops - fl_w) / ((ms - ms_w) * 1e-3) / 1e12, 1) if ms > ms_w else None},
+                    "traffic": traffic,
                     "traffic_note": "HBM bytes of all conv launches of one step (rocprofv3 --pmc, committed under "
                                     "profiles/); algorithmic bytes (each tensor once) alongside",
                     "algorithmic_bytes_per_step": int(algo_bytes),
@@ -269,6 +287,8 @@ def main():
                        "parallelism": f"dp{world}: image shards, replicated weights, one RCCL all-gather of "
                                       f"detections [{world * args.batch},{cfg.detection_max_instances},6]",
                        "hipgraph": bool(args.graph),
+                       "conv3x3": ("winograd F(2x2,3x3), fp32 arithmetic on the fp32 MFMA"
+                                   if (args.precision == "f32" and modules.WINOGRAD) else "direct implicit GEMM"),
                        "mean_valid_proposals": round(float(net_last_counts(net, images, windows)), 1),
                        "mean_detections": round(float(det.counts.float().mean().item()), 1)},
             "roofline": roofline, "cpu_baseline": cpu, "alt_precision": alt,

@@ -661,5 +661,5 @@ def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, scale, shift, relu: bool 
         m, k = b * h * w, 9 * (algo_cin or cin)
         # FLOPs are the algorithmic ones of the convolution (2*M*N*K), as for the direct kernel — not the reduced
         # multiply count Winograd actually executes
-        prof.append((e0, e1, 2.0 * m * cout * k, (m, cout, k), 4.0 * (m * cin + m * cout + cout * k)))
+        prof.append((e0, e1, 2.0 * m * cout * k, (m, cout, k), 4.0 * (m * cin + m * cout + cout * k), "winograd"))
     return y

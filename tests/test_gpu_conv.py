@@ -231,3 +231,88 @@ def test_rpn_level_fused_vs_torch_cpu(dev):
                                   ws.permute(0, 2, 3, 1).contiguous().to(dev), bs.to(dev), w32.to(dev), bh.to(dev))
         err = (got.cpu() - want).abs().max().item()
         assert err <= TOL, (b, h, w, err)
+
+
+# --------------------------------------------------------------------------------------------------
+# Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip): same 1e-4 bar against torch CPU, x ~ N(0,1), Xavier weights
+# --------------------------------------------------------------------------------------------------
+WINO_CASES = [
+    # (B, H, W, Cin, Cout, relu, affine)
+    (2, 16, 16, 64, 64, True, True),      # C2 conv2
+    (2, 32, 32, 256, 256, True, True),    # FPN smoothing / C4 conv2
+    (1, 32, 32, 256, 512, True, False),   # RPN conv_shared (bias only)
+    (7, 14, 14, 256, 256, True, True),    # mask head: 49 tile positions per RoI, ragged last workgroup
+    (2, 14, 14, 64, 96, False, True),     # Cout not a multiple of 64
+    (1, 2, 2, 8, 5, False, False),        # one tile position, one k tile
+    (1, 32, 48, 24, 40, True, True),      # non-square, three k tiles
+    (3, 16, 16, 512, 64, True, True),     # long K
+    (1, 6, 10, 16, 70, True, True),       # FPN P5 of the 192x320 configuration
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(str(v) for v in c[:5]))
+def test_conv3x3_winograd_vs_torch_cpu(dev, case):
+    from maskrcnn_amd import ops
+    b, h, w, cin, cout, relu, affine = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin))
+    scale = (torch.rand(cout, generator=g) + 0.5) if affine else None
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = _ref_conv(x, wt, scale, shift, 1, (1, 1, 1, 1), relu).permute(0, 2, 3, 1)
+    u = ops.winograd_weights(wt.permute(0, 2, 3, 1).contiguous().to(dev))
+    y = ops.conv3x3_winograd(x.permute(0, 2, 3, 1).contiguous().to(dev), u,
+                             None if scale is None else scale.to(dev), shift.to(dev), relu)
+    err = (y.cpu() - ref).abs().max().item()
+    assert err <= TOL, f"max abs err {err:.3e} (|ref|max {ref.abs().max().item():.2f})"
+
+
+def test_conv3x3_winograd_matches_direct_kernel_full_size(dev):
+    """BASELINE shapes (P3-level FPN smoothing at batch 8; the mask head's 400 x 14 x 14): within 1e-4 of the exact
+    direct kernel relative to the activation scale, and bit-identical run to run."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(77)
+    for (b, h, w, cin, cout) in ((8, 128, 128, 256, 256), (400, 14, 14, 256, 256)):
+        x = torch.randn(b, h, w, cin, generator=g).to(dev)
+        wt = (torch.randn(cout, 3, 3, cin, generator=g) * math.sqrt(2.0 / (9 * cin))).to(dev)
+        sh = (torch.randn(cout, generator=g) * 0.1).to(dev)
+        u = ops.winograd_weights(wt)
+        y = ops.conv3x3_winograd(x, u, None, sh, True)
+        yd = ops.conv_bn_act(x, wt, None, sh, 1, (1, 1, 1, 1), True)
+        assert (y - yd).abs().max().item() <= TOL * max(1.0, yd.abs().max().item())
+        assert torch.equal(y, ops.conv3x3_winograd(x, u, None, sh, True))
+
+
+def test_conv3x3_winograd_bad_arguments(dev):
+    from maskrcnn_amd import ops
+    from maskrcnn_amd._lib import MaskrcnnHipError
+    u = ops.winograd_weights(torch.zeros(8, 3, 3, 8, device=dev))
+    with pytest.raises(MaskrcnnHipError):
+        ops.conv3x3_winograd(torch.zeros(1, 5, 4, 8, device=dev), u, None, None)      # odd height
+    u12 = torch.zeros(16, 8, 12, device=dev)
+    with pytest.raises(MaskrcnnHipError):
+        ops.conv3x3_winograd(torch.zeros(1, 4, 4, 12, device=dev), u12, None, None)   # Cin % 8 != 0
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_winograd(torch.zeros(1, 4, 4, 8), u.cpu(), None, None)            # CPU tensors
+
+
+def test_winograd_switch_off_restores_direct_path(dev):
+    """MRCNN_WINOGRAD=0 (modules.WINOGRAD False): ConvWeight keeps 3x3 layers on the exact direct kernel."""
+    from maskrcnn_amd import modules, ops
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(64, 3, 3, 64, generator=g).to(dev) * 0.05
+    x = torch.randn(1, 8, 8, 64, generator=g).to(dev)
+    saved = modules.WINOGRAD
+    try:
+        modules.WINOGRAD = False
+        cw = modules.ConvWeight(w)
+        assert cw.u is None
+        assert torch.equal(cw.conv(x, None, None, 1, (1, 1, 1, 1)), ops.conv_bn_act(x, w, None, None, 1, (1, 1, 1, 1)))
+        modules.WINOGRAD = True
+        cw = modules.ConvWeight(w)
+        assert cw.u is not None
+        assert torch.equal(cw.conv(x, None, None, 1, (1, 1, 1, 1)), ops.conv3x3_winograd(x, cw.u, None, None))
+        # strided / padded-differently / odd-sized calls still take the direct kernel
+        assert torch.equal(cw.conv(x, None, None, 2, (0, 1, 0, 1)), ops.conv_bn_act(x, w, None, None, 2, (0, 1, 0, 1)))
+    finally:
+        modules.WINOGRAD = saved
