@@ -384,6 +384,17 @@ extern "C" int mrcnn_conv_bn_act_nhwc_f32(const float* x, int32_t batch, int32_t
                         pad_right, scale, shift, residual, res_div, activation, 0, y, stream);
 }
 
+extern "C" int mrcnn_conv_bn_act_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                     const float* w, int32_t cout, int32_t kh, int32_t kw, int32_t stride,
+                                     int32_t pad_top, int32_t pad_left, int32_t pad_bottom, int32_t pad_right,
+                                     const float* scale, const float* shift, const float* residual, int32_t res_div,
+                                     int32_t activation, float* y, int32_t y_layout, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(y_layout == MRCNN_LAYOUT_NHWC || y_layout == MRCNN_LAYOUT_KBLOCKED, "conv: bad y_layout");
+    return run_conv_f32(x, batch, height, width, cin, w, cout, kh, kw, stride, pad_top, pad_left, pad_bottom,
+                        pad_right, scale, shift, residual, res_div, activation,
+                        y_layout == MRCNN_LAYOUT_KBLOCKED ? 2 : 0, y, stream);
+}
+
 extern "C" int mrcnn_deconv2x2_bias_act_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
                                                  int32_t cin, const float* w, int32_t cout, const float* bias4,
                                                  int32_t activation, float* y, mrcnn_stream_t stream) {

@@ -20,7 +20,8 @@ struct ConvCommon {
     int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
     int M, K;          // GEMM sizes: M = B*OH*OW, K = KH*KW*Cin
     int res_div, act;  // act: 0 none, 1 ReLU (2 = sigmoid is the compile-time epilogue variant 3)
-    int out_mode;      // 0: y[m][n]; 1: 2x2 stride-2 transposed-conv scatter, n = (dy*2+dx)*Cout/4 + co
+    int out_mode;      // 0: y[m][n]; 1: 2x2 stride-2 transposed-conv scatter, n = (dy*2+dx)*Cout/4 + co;
+                       // 2: k-blocked y[n/8][m][n%8] (what the Winograd kernel reads; variants 0-3 only)
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;  // buffer-descriptor ranges (< 4 GiB each)
 };
@@ -144,13 +145,16 @@ __device__ __forceinline__ void epilogue(const ConvCommon& p, f32x16 (&acc)[TM][
         sc[jn] = (n_ok && p.scale) ? p.scale[n] : 1.0f;
         sh[jn] = (n_ok && p.shift) ? p.shift[n] : 0.0f;
         if constexpr (RES != 4) {
-            ncol[jn] = n_ok ? static_cast<unsigned>(n) * 4u : OOB;
+            ncol[jn] = !n_ok ? OOB
+                       : p.out_mode == 2 ? static_cast<unsigned>(n >> 3) * (static_cast<unsigned>(p.M) * 32u) +
+                                               static_cast<unsigned>(n & 7) * 4u
+                                         : static_cast<unsigned>(n) * 4u;
         } else {  // n = (dy*2 + dx)*cq + co  →  pixel (2i+dy, 2j+dx), channel co of the [B][2*OH][2*OW][cq] output
             const int cq = p.Cout >> 2, q = n / cq, co = n - q * cq;
             ncol[jn] = n_ok ? static_cast<unsigned>(((q >> 1) * 2 * p.OW + (q & 1)) * cq + co) * 4u : OOB;
         }
     }
-    const unsigned row_bytes = static_cast<unsigned>(p.Cout) * 4u;
+    const unsigned row_bytes = p.out_mode == 2 ? 32u : static_cast<unsigned>(p.Cout) * 4u;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mb = m0 + wm * WTM + i * 32 + 4 * lh;  // rows mb + (r&3) + 8*(r>>2)
@@ -191,10 +195,12 @@ inline int fill_common(ConvCommon& p, const char* who, const float* x, int batch
                        int res_div, int activation, int out_mode, float* y, int weight_elem_bytes) {
     if (!(activation >= 0 && activation <= 2))
         return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: activation must be 0 (none), 1 (ReLU) or 2 (sigmoid)", who);
-    if (residual && (activation == 2 || out_mode != 0))
+    if (residual && (activation == 2 || out_mode == 1))
         return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: a residual cannot be combined with sigmoid or the deconv scatter", who);
-    if (out_mode != 0 && activation == 2)
+    if (out_mode == 1 && activation == 2)
         return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: deconv scatter supports activation 0 or 1", who);
+    if (out_mode == 2 && cout % 8 != 0)
+        return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: a k-blocked output needs Cout %% 8 == 0", who);
     if (!(batch >= 1 && height >= 1 && width >= 1 && cin >= cin_multiple && cin % cin_multiple == 0 && cout >= 1))
         return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: bad shape B=%d H=%d W=%d Cin=%d (Cin %% %d == 0 required) Cout=%d",
                            who, batch, height, width, cin, cin_multiple, cout);

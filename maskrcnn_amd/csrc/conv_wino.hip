@@ -34,9 +34,10 @@ struct WinoParams {
     const float* u;      // k-blocked filter [Cin/8][16][Cout][8]
     const float* scale;  // [Cout] or null
     const float* shift;  // [Cout] or null
-    float* y;            // [B][H][W][Cout]
+    float* y;            // NHWC output [B][H][W][Cout], or null
+    float* yk;           // k-blocked output [Cout/8][B*H*W][8], or null
     int B, H, W, Cin, Cout, TH, TW, T, act;
-    unsigned x_plane, u_plane;  // bytes per 8-channel plane of x / u
+    unsigned x_plane, u_plane, yk_plane;  // bytes per 8-channel plane of x / u / the k-blocked output
     int tiles_m, tiles_n;
     unsigned x_bytes, u_bytes, y_bytes;
 };
@@ -49,6 +50,19 @@ constexpr size_t WINO_LDS = sizeof(float) * 2 * 2 * 16 * PLANE;  // {V,U} x 2 bu
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Two-lane packed fp32 add / subtract: ONE VALU issue for both channels of the pair (the compiler scalarises a float2
+// subtraction into two v_add_f32 with a negate modifier; on this MFMA every VALU instruction in the loop is paid for).
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -123,15 +137,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const WinoParams p) {
     f32x2 t[4][4];
     auto column_pass = [&](int dx) {
         const f32x2 d0 = vl[0 * 4 + dx], d1 = vl[1 * 4 + dx], d2 = vl[2 * 4 + dx], d3 = vl[3 * 4 + dx];
-        t[0][dx] = d0 - d2;
-        t[1][dx] = d1 + d2;
-        t[2][dx] = d2 - d1;
-        t[3][dx] = d1 - d3;
+        t[0][dx] = pk_sub(d0, d2);
+        t[1][dx] = pk_add(d1, d2);
+        t[2][dx] = pk_sub(d2, d1);
+        t[3][dx] = pk_sub(d1, d3);
     };
     auto v_store = [&](int xi, float* vbuf) {
         const int i = xi >> 2, j = xi & 3;
-        const f32x2 v = j == 0 ? t[i][0] - t[i][2] : j == 1 ? t[i][1] + t[i][2] : j == 2 ? t[i][2] - t[i][1]
-                                                                                         : t[i][1] - t[i][3];
+        const f32x2 v = j == 0 ? pk_sub(t[i][0], t[i][2]) : j == 1 ? pk_add(t[i][1], t[i][2])
+                      : j == 2 ? pk_sub(t[i][2], t[i][1]) : pk_sub(t[i][1], t[i][3]);
         *reinterpret_cast<f32x2*>(vbuf + xi * PLANE) = v;
     };
     auto u_store = [&](int i, float* ubuf) { *reinterpret_cast<u32x4*>(ubuf + i * 2 * PLANE) = ul[i]; };
@@ -228,17 +242,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const WinoParams p) {
     // combination crosses waves through LDS: Z[i][c][position][channel], 4 x 2 x 64 x 64 floats = the 128 KB the
     // operand buffers occupied. Then every wave finishes 16 positions: affine, ReLU, 256-byte channel runs.
     __syncthreads();  // (the behind-the-barrier operand prefetch of a k tile that does not exist is still in flight)
+    // Z[i][c][position / 4][channel][position % 4]: an accumulator's registers r..r+3 are four consecutive positions
+    // of one channel, so writer and reader both move 16 bytes per lane, contiguous across lanes
     float* Z = smem;
+    constexpr int ZP = (WT / 4) * WN * 4;  // floats per (i, c) plane
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pos = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, ch = c * 32 + ln;
-                const float m0v = acc[0][a][c][r], m1v = acc[1][a][c][r], m2v = acc[2][a][c][r], m3v = acc[3][a][c][r];
-                Z[((wave * 2 + 0) * WT + pos) * WN + ch] = m0v + m1v + m2v;
-                Z[((wave * 2 + 1) * WT + pos) * WN + ch] = m1v - m2v - m3v;
+            for (int rq = 0; rq < 4; ++rq) {
+                const int pq = a * 8 + 2 * rq + lh, ch = c * 32 + ln;  // positions 4*pq .. 4*pq+3
+                float4 z0, z1;
+                float* z0p = &z0.x;
+                float* z1p = &z1.x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = rq * 4 + e;
+                    const float m0v = acc[0][a][c][r], m1v = acc[1][a][c][r], m2v = acc[2][a][c][r], m3v = acc[3][a][c][r];
+                    z0p[e] = m0v + m1v + m2v;
+                    z1p[e] = m1v - m2v - m3v;
+                }
+                *reinterpret_cast<float4*>(Z + (wave * 2 + 0) * ZP + (pq * WN + ch) * 4) = z0;
+                *reinterpret_cast<float4*>(Z + (wave * 2 + 1) * ZP + (pq * WN + ch) * 4) = z1;
             }
     __syncthreads();
     const int ch = lane, n = n0 + ch;
@@ -246,27 +272,41 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const WinoParams p) {
     const float sc = (n_ok && p.scale) ? p.scale[n] : 1.0f, sh = (n_ok && p.shift) ? p.shift[n] : 0.0f;
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const unsigned ncol = n_ok ? static_cast<unsigned>(n) * 4u : OOB;
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
-        const int pos = wave * 16 + q;
-        const int P = __builtin_amdgcn_readfirstlane(m0 + pos);
-        const bool pv = P < p.T;
-        const int PP = pv ? P : 0;
-        const int b = PP / (p.TH * p.TW), rem = PP - b * p.TH * p.TW;
-        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+    const __amdgpu_buffer_rsrc_t yk_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.yk, 0, p.y_bytes, 0x00020000);
+    const unsigned kcol = static_cast<unsigned>(n >> 3) * p.yk_plane + static_cast<unsigned>(n & 7) * 4u;
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {  // this wave finishes positions 16*wave + 4*g .. +3
+        const int pq = wave * 4 + g;
+        float4 z[4][2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const float z0 = Z[((0 * 2 + c) * WT + pos) * WN + ch], z1 = Z[((1 * 2 + c) * WT + pos) * WN + ch];
-            const float z2 = Z[((2 * 2 + c) * WT + pos) * WN + ch], z3 = Z[((3 * 2 + c) * WT + pos) * WN + ch];
-            const float yv[2] = {z0 + z1 + z2, z1 - z2 - z3};
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                float v = yv[a] * sc + sh;
-                if (p.act) v = v > 0.f ? v : 0.f;
-                const unsigned row = static_cast<unsigned>((b * p.H + 2 * ty + a) * p.W + 2 * tx + c) *
-                                     (static_cast<unsigned>(p.Cout) * 4u);
-                const unsigned o = (pv && n_ok) ? row + ncol : OOB;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(o), 0, 0);
+            for (int c = 0; c < 2; ++c) z[i][c] = *reinterpret_cast<const float4*>(Z + (i * 2 + c) * ZP + (pq * WN + ch) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int P = __builtin_amdgcn_readfirstlane(m0 + pq * 4 + e);
+            const bool pv = P < p.T;
+            const int PP = pv ? P : 0;
+            const int b = PP / (p.TH * p.TW), rem = PP - b * p.TH * p.TW;
+            const int ty = rem / p.TW, tx = rem - ty * p.TW;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float z0 = (&z[0][c].x)[e], z1 = (&z[1][c].x)[e], z2 = (&z[2][c].x)[e], z3 = (&z[3][c].x)[e];
+                const float yv[2] = {z0 + z1 + z2, z1 - z2 - z3};
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float v = yv[a] * sc + sh;
+                    if (p.act) v = v > 0.f ? v : 0.f;
+                    const unsigned px = static_cast<unsigned>((b * p.H + 2 * ty + a) * p.W + 2 * tx + c);
+                    if (p.y) {
+                        const unsigned o = (pv && n_ok) ? px * (static_cast<unsigned>(p.Cout) * 4u) + ncol : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(o), 0, 0);
+                    }
+                    if (p.yk) {  // the layout the next Winograd conv reads: no transposition pass in between
+                        const unsigned o = (pv && n_ok) ? kcol + px * 32u : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yk_rsrc, static_cast<int>(o), 0, 0);
+                    }
+                }
             }
         }
     }
@@ -342,26 +382,34 @@ extern "C" size_t mrcnn_conv3x3_winograd_workspace_bytes(int32_t batch, int32_t 
     return sizeof(float) * static_cast<size_t>(batch) * height * width * cin;
 }
 
-extern "C" int mrcnn_conv3x3_winograd_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
-                                               int32_t cin, const float* u, int32_t cout, const float* scale,
-                                               const float* shift, int32_t activation, float* y, void* workspace,
-                                               size_t workspace_bytes, mrcnn_stream_t stream) {
-    MRCNN_REQUIRE(x && u && y && workspace, "conv3x3_winograd: null pointer");
-    MRCNN_REQUIRE(workspace_bytes >= mrcnn_conv3x3_winograd_workspace_bytes(batch, height, width, cin),
-                  "conv3x3_winograd: workspace too small");
+extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int32_t batch, int32_t height,
+                                          int32_t width, int32_t cin, const float* u, int32_t cout,
+                                          const float* scale, const float* shift, int32_t activation, float* y_nhwc,
+                                          float* y_kblocked, void* workspace, size_t workspace_bytes,
+                                          mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x && u && (y_nhwc || y_kblocked), "conv3x3_winograd: null pointer");
+    MRCNN_REQUIRE(x_layout == MRCNN_LAYOUT_NHWC || x_layout == MRCNN_LAYOUT_KBLOCKED, "conv3x3_winograd: bad x_layout");
+    MRCNN_REQUIRE(x_layout == MRCNN_LAYOUT_KBLOCKED ||
+                      (workspace && workspace_bytes >= mrcnn_conv3x3_winograd_workspace_bytes(batch, height, width, cin)),
+                  "conv3x3_winograd: an NHWC input needs a workspace of mrcnn_conv3x3_winograd_workspace_bytes()");
     MRCNN_REQUIRE(batch >= 1 && height >= 2 && width >= 2 && height % 2 == 0 && width % 2 == 0,
                   "conv3x3_winograd: B=%d H=%d W=%d (even sizes required)", batch, height, width);
     MRCNN_REQUIRE(cin >= 8 && cin % 8 == 0 && cout >= 1, "conv3x3_winograd: Cin=%d (%% 8 == 0 required) Cout=%d", cin, cout);
+    MRCNN_REQUIRE(y_kblocked == nullptr || cout % 8 == 0, "conv3x3_winograd: a k-blocked output needs Cout %% 8 == 0");
     MRCNN_REQUIRE(activation == 0 || activation == 1, "conv3x3_winograd: activation must be 0 or 1");
     const long long px = 1LL * batch * height * width;
     MRCNN_REQUIRE(px * cin < (1LL << 30) && px * cout < (1LL << 30) && 16LL * cin * cout < (1LL << 30),
                   "conv3x3_winograd: tensor too large (32-bit buffer byte offsets)");
     hipStream_t st = mrcnn::as_stream(stream);
-    float* x8 = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(kblock_kernel, dim3(static_cast<unsigned>((px + 31) / 32), (cin + 63) / 64), dim3(256), 0, st, x,
-                       static_cast<int64_t>(px), cin, x8);
+    const float* x8 = x;
+    if (x_layout == MRCNN_LAYOUT_NHWC) {
+        float* t = static_cast<float*>(workspace);
+        hipLaunchKernelGGL(kblock_kernel, dim3(static_cast<unsigned>((px + 31) / 32), (cin + 63) / 64), dim3(256), 0, st,
+                           x, static_cast<int64_t>(px), cin, t);
+        x8 = t;
+    }
     WinoParams p;
-    p.x = x8; p.u = u; p.scale = scale; p.shift = shift; p.y = y;
+    p.x = x8; p.u = u; p.scale = scale; p.shift = shift; p.y = y_nhwc; p.yk = y_kblocked;
     p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout;
     p.TH = height / 2; p.TW = width / 2; p.T = batch * p.TH * p.TW; p.act = activation;
     p.tiles_m = (p.T + WT - 1) / WT;
@@ -370,6 +418,7 @@ extern "C" int mrcnn_conv3x3_winograd_nhwc_f32(const float* x, int32_t batch, in
     p.u_bytes = static_cast<unsigned>(4LL * 16 * cin * cout);
     p.x_plane = static_cast<unsigned>(4LL * px * WK);
     p.u_plane = static_cast<unsigned>(4LL * 16 * cout * WK);
+    p.yk_plane = static_cast<unsigned>(4LL * px * 8);
     p.y_bytes = static_cast<unsigned>(4LL * px * cout);
     const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
     MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd: grid too large");
@@ -382,4 +431,22 @@ extern "C" int mrcnn_conv3x3_winograd_nhwc_f32(const float* x, int32_t batch, in
     }
     hipLaunchKernelGGL(conv3x3_wino_f32, dim3(static_cast<unsigned>(grid)), dim3(256), WINO_LDS, st, p);
     return mrcnn::check_launch("conv3x3_wino_f32");
+}
+
+extern "C" int mrcnn_conv3x3_winograd_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
+                                               int32_t cin, const float* u, int32_t cout, const float* scale,
+                                               const float* shift, int32_t activation, float* y, void* workspace,
+                                               size_t workspace_bytes, mrcnn_stream_t stream) {
+    return mrcnn_conv3x3_winograd_f32(x, MRCNN_LAYOUT_NHWC, batch, height, width, cin, u, cout, scale, shift,
+                                      activation, y, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mrcnn_nhwc_to_kblocked_f32(const float* x, int64_t pixels, int32_t channels, float* y,
+                                          mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x && y, "nhwc_to_kblocked: null pointer");
+    MRCNN_REQUIRE(pixels >= 1 && channels >= 8 && channels % 8 == 0 && pixels * channels < (1LL << 31),
+                  "nhwc_to_kblocked: pixels=%lld channels=%d", static_cast<long long>(pixels), channels);
+    hipLaunchKernelGGL(kblock_kernel, dim3(static_cast<unsigned>((pixels + 31) / 32), (channels + 63) / 64), dim3(256), 0,
+                       mrcnn::as_stream(stream), x, pixels, channels, y);
+    return mrcnn::check_launch("kblock_kernel");
 }

@@ -187,14 +187,23 @@ class ConvWeight:
             return ops.deconv2x2(x, self.w, bias4, activation, 0)
         return ops.deconv2x2(x, (self.w_hi, self.w_lo), bias4, activation, 3 if self.precision == "f16x3" else 1)
 
+    def takes_winograd(self, h, w, stride=1, pad=(1, 1, 1, 1), residual=None, relu=False):
+        """Would conv() run the Winograd kernel for an [., h, w, .] input with these arguments?"""
+        return (self.u is not None and stride == 1 and tuple(pad) == (1, 1, 1, 1) and residual is None
+                and relu in (False, True, 0, 1) and h % 2 == 0 and w % 2 == 0)
+
     def conv(self, x, scale, shift, stride=1, pad=(0, 0, 0, 0), relu=False, residual=None, res_div=1,
-             algo_cin=None):
+             algo_cin=None, out="nhwc"):
+        """out: "nhwc" (default), or for the f32 mode "kblocked" / "both" (ops.conv3x3_winograd): the layout the next
+        Winograd conv reads. x may itself be k-blocked (5-d) when this conv takes the Winograd kernel."""
         if self.precision == "f32":
-            if (self.u is not None and stride == 1 and tuple(pad) == (1, 1, 1, 1) and residual is None
-                    and relu in (False, True, 0, 1) and x.size(1) % 2 == 0 and x.size(2) % 2 == 0):
-                return ops.conv3x3_winograd(x, self.u, scale, shift, bool(relu), algo_cin)
+            hh, ww = (x.size(2), x.size(3)) if x.dim() == 5 else (x.size(1), x.size(2))
+            if self.takes_winograd(hh, ww, stride, pad, residual, relu):
+                return ops.conv3x3_winograd(x, self.u, scale, shift, bool(relu), algo_cin, out)
+            assert x.dim() == 4 and out in ("nhwc", "kblocked")
             return ops.conv_bn_act(x, self.w, scale, shift, stride, pad, relu, residual, res_div, None,
-                                   algo_cin)
+                                   algo_cin, out_kblocked=(out == "kblocked"))
+        assert out == "nhwc"
         return ops.conv_bn_act_f16mfma(x, self.w_hi, self.w_lo, scale, shift, stride, pad, relu, residual,
                                        res_div, 3 if self.precision == "f16x3" else 1, algo_cin)
 
@@ -209,10 +218,16 @@ class FusedConv:
         self.stride, self.relu, self.same_k, self.pad = stride, relu, same_pad_kernel, pad
         self.algo_cin = sd[conv + ".weight"].size(1)  # un-padded Cin for FLOP accounting
 
-    def __call__(self, x, residual=None, res_div=1):
-        pad = ops.same_pad(x.size(1), x.size(2), self.same_k, 1) if self.same_k else self.pad
-        return self.w.conv(x, self.scale, self.shift, self.stride, pad, self.relu, residual, res_div,
-                           self.algo_cin)
+    def pad_for(self, h, w):
+        return ops.same_pad(h, w, self.same_k, 1) if self.same_k else self.pad
+
+    def takes_winograd(self, h, w):
+        return self.w.takes_winograd(h, w, self.stride, self.pad_for(h, w), None, self.relu)
+
+    def __call__(self, x, residual=None, res_div=1, out="nhwc"):
+        hh, ww = (x.size(2), x.size(3)) if x.dim() == 5 else (x.size(1), x.size(2))
+        return self.w.conv(x, self.scale, self.shift, self.stride, self.pad_for(hh, ww), self.relu, residual, res_div,
+                           self.algo_cin, out)
 
 
 class FusedBottleneck:
@@ -253,7 +268,10 @@ class FusedBottleneck:
             return torch.ops.maskrcnn.bottleneck_forward(x, *self.p)
         c1, c2, c3, cd = self.convs
         res = x if cd is None else cd(x)
-        return c3(c2(c1(x)), residual=res)
+        oh, ow = -(-x.size(1) // c1.stride), -(-x.size(2) // c1.stride)
+        # conv1's output only feeds conv2: written directly in the layout the Winograd kernel reads
+        h = c1(x, out="kblocked" if (self.precision == "f32" and c2.takes_winograd(oh, ow)) else "nhwc")
+        return c3(c2(h), residual=res)
 
 
 class Bottleneck(nn.Module):
@@ -321,9 +339,19 @@ class FusedBackbone:
         p4 = self.lateral[4](c4, residual=p5, res_div=2)        # + nearest-upsampled P5 (model.py:150)
         p3 = self.lateral[3](c3, residual=p4, res_div=2)
         p2 = self.lateral[2](c2, residual=p3, res_div=2)
-        p5, p4, p3, p2 = self.smooth[5](p5), self.smooth[4](p4), self.smooth[3](p3), self.smooth[2](p2)
-        p6 = ops.maxpool(p5, 1, 2)                              # model.py:109,161
-        return [p2, p3, p4, p5, p6]
+        outs, self.kblocked = [], []
+        for k, p in ((2, p2), (3, p3), (4, p4), (5, p5)):
+            sm = self.smooth[k]
+            if sm.w.precision == "f32" and sm.takes_winograd(p.size(1), p.size(2)) and sm.w.shape[0] % 8 == 0:
+                # the smoothed map is read by RoIAlign (NHWC) and by the RPN's 3x3 conv (Winograd: k-blocked)
+                y, yk = sm(p, out="both")
+            else:
+                y, yk = sm(p), None
+            outs.append(y)
+            self.kblocked.append(yk)
+        outs.append(ops.maxpool(outs[3], 1, 2))                 # P6, model.py:109,161
+        self.kblocked.append(None)
+        return outs
 
 
 class FusedRPN:
@@ -349,9 +377,12 @@ class FusedRPN:
                                     precision=precision)
             self.w_head = ConvWeight(pack_weight(w, device), precision)
 
-    def __call__(self, p):
+    def __call__(self, p, p_kblocked=None):
+        """p: a pyramid level NHWC; p_kblocked: the same map k-blocked, when the producer wrote it (f32 Winograd mode)."""
         if self.fused_level:
             return ops.rpn_level_fused(p, self.w_shared, self.b_shared, self.w_head32, self.b_head, self.head_n)
+        if p_kblocked is not None and self.shared.takes_winograd(p.size(1), p.size(2)):
+            p = p_kblocked
         return self.w_head.conv(self.shared(p), None, self.b_head)
 
 
@@ -400,8 +431,10 @@ class FusedMask:
 
     def __call__(self, pooled):
         x = pooled
-        for c in self.convs:
-            x = c(x)
+        chain = self.convs[0].w.precision == "f32" and all(c.takes_winograd(x.size(1), x.size(2)) for c in self.convs)
+        for i, c in enumerate(self.convs):
+            # Winograd -> Winograd: intermediate maps stay in the k-blocked layout, no transposition passes
+            x = c(x, out="kblocked" if (chain and i + 1 < len(self.convs)) else "nhwc")
         y = self.w_de.deconv2x2(x, self.b_de, activation=1)   # [R,2h,2w,C]: deconv + bias + ReLU, scattered in place
         return self.conv5(y)                                  # 1x1 conv + bias + sigmoid (model.py:913-914)
 

@@ -199,8 +199,11 @@ CONV_PROFILE: list | None = None
 def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
                 shift: torch.Tensor | None, stride: int = 1, pad=(0, 0, 0, 0), relu: bool = False,
                 residual: torch.Tensor | None = None, res_div: int = 1,
-                out: torch.Tensor | None = None, algo_cin: int | None = None) -> torch.Tensor:
+                out: torch.Tensor | None = None, algo_cin: int | None = None,
+                out_kblocked: bool = False) -> torch.Tensor:
     """y = act(scale * conv(x, w) + shift + residual).
+
+    out_kblocked: write y as [Cout/8,B,OH,OW,8] (what conv3x3_winograd reads) instead of NHWC.
 
     relu: False/0 none, True/1 ReLU, 2 sigmoid.
     x [B,H,W,Cin] NHWC fp32 contiguous; w [Cout,KH,KW,Cin] (OHWI) contiguous; scale/shift [Cout] or
@@ -216,7 +219,10 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
     pt, pl, pb, pr = [int(v) for v in pad]
     oh = (h + pt + pb - kh) // stride + 1
     ow = (wd + pl + pr - kw) // stride + 1
-    if out is None:
+    if out_kblocked:
+        assert out is None and cout % 8 == 0
+        out = torch.empty(cout // 8, b, oh, ow, 8, dtype=torch.float32, device=x.device)
+    elif out is None:
         out = torch.empty(b, oh, ow, cout, dtype=torch.float32, device=x.device)
     else:
         assert out.is_contiguous() and tuple(out.shape) == (b, oh, ow, cout)
@@ -230,10 +236,10 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.mrcnn_conv_bn_act_nhwc_f32(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout, kh, kw,
-                                         int(stride), pt, pl, pb, pr, _ptr(scale), _ptr(shift),
-                                         _ptr(residual), int(res_div), int(relu),
-                                         out.data_ptr(), _stream()))
+    check(lib.mrcnn_conv_bn_act_f32(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout, kh, kw,
+                                    int(stride), pt, pl, pb, pr, _ptr(scale), _ptr(shift),
+                                    _ptr(residual), int(res_div), int(relu),
+                                    out.data_ptr(), 1 if out_kblocked else 0, _stream()))
     if prof is not None:
         e1.record()
         m, k = b * oh * ow, kh * kw * (algo_cin or cin)  # algorithmic: 2*MACs of the un-padded conv
@@ -639,27 +645,50 @@ def winograd_weights(w_ohwi: torch.Tensor) -> torch.Tensor:
     return u
 
 
-def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, scale, shift, relu: bool = False, algo_cin=None):
-    """x NHWC fp32 [B,H,W,Cin] (H, W even; Cin % 8 == 0), u from winograd_weights → [B,H,W,Cout]:
-    relu(conv3x3_same(x) * scale + shift)."""
+def nhwc_to_kblocked(x: torch.Tensor) -> torch.Tensor:
+    """[B,H,W,C] → [C/8,B,H,W,8]."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.size(3) % 8 == 0
+    b, h, w, c = x.shape
+    y = torch.empty(c // 8, b, h, w, 8, dtype=torch.float32, device=x.device)
+    check(lib.mrcnn_nhwc_to_kblocked_f32(x.data_ptr(), b * h * w, c, y.data_ptr(), _stream()))
+    return y
+
+
+def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, scale, shift, relu: bool = False, algo_cin=None,
+                     out: str = "nhwc"):
+    """relu(conv3x3_same(x) * scale + shift) with u from winograd_weights.
+    x: NHWC fp32 [B,H,W,Cin] or k-blocked [Cin/8,B,H,W,8] (H, W even; Cin % 8 == 0).
+    out: "nhwc" → [B,H,W,Cout]; "kblocked" → [Cout/8,B,H,W,8] (feeds the next Winograd conv without a transposition
+    pass); "both" → (nhwc, kblocked)."""
     _need_gpu(x, u, scale, shift)
-    assert x.dtype == torch.float32 and x.is_contiguous() and u.is_contiguous()
-    b, h, w, cin = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and u.is_contiguous() and out in ("nhwc", "kblocked", "both")
+    if x.dim() == 5:
+        layout = 1
+        g, b, h, w, _ = x.shape
+        cin = g * 8
+    else:
+        layout = 0
+        b, h, w, cin = x.shape
     cout = u.size(1)
     assert u.size(2) == cin
-    y = torch.empty(b, h, w, cout, dtype=torch.float32, device=x.device)
+    y = torch.empty(b, h, w, cout, dtype=torch.float32, device=x.device) if out != "kblocked" else None
+    yk = torch.empty(cout // 8, b, h, w, 8, dtype=torch.float32, device=x.device) if out != "nhwc" else None
+    nbytes, ws = 0, None
+    if layout == 0:
+        nbytes = int(lib.mrcnn_conv3x3_winograd_workspace_bytes(b, h, w, cin))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     prof = CONV_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    nbytes = int(lib.mrcnn_conv3x3_winograd_workspace_bytes(b, h, w, cin))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    check(lib.mrcnn_conv3x3_winograd_nhwc_f32(x.data_ptr(), b, h, w, cin, u.data_ptr(), cout, _ptr(scale), _ptr(shift),
-                                              1 if relu else 0, y.data_ptr(), ws.data_ptr(), nbytes, _stream()))
+    check(lib.mrcnn_conv3x3_winograd_f32(x.data_ptr(), layout, b, h, w, cin, u.data_ptr(), cout, _ptr(scale),
+                                         _ptr(shift), 1 if relu else 0, _ptr(y), _ptr(yk), _ptr(ws), nbytes, _stream()))
     if prof is not None:
         e1.record()
         m, k = b * h * w, 9 * (algo_cin or cin)
         # FLOPs are the algorithmic ones of the convolution (2*M*N*K), as for the direct kernel — not the reduced
         # multiply count Winograd actually executes
-        prof.append((e0, e1, 2.0 * m * cout * k, (m, cout, k), 4.0 * (m * cin + m * cout + cout * k), "winograd"))
-    return y
+        prof.append((e0, e1, 2.0 * m * cout * k, (m, cout, k),
+                     4.0 * (m * cin + m * cout * (2 if out == "both" else 1) + cout * k), "winograd"))
+    return y if out == "nhwc" else yk if out == "kblocked" else (y, yk)

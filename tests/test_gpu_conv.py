@@ -316,3 +316,31 @@ def test_winograd_switch_off_restores_direct_path(dev):
         assert torch.equal(cw.conv(x, None, None, 2, (0, 1, 0, 1)), ops.conv_bn_act(x, w, None, None, 2, (0, 1, 0, 1)))
     finally:
         modules.WINOGRAD = saved
+
+
+def test_kblocked_layout_chain(dev):
+    """The k-blocked tensors that let Winograd convs chain without a transposition pass: direct conv -> k-blocked,
+    Winograd reading k-blocked, Winograd writing NHWC + k-blocked; every path gives the same numbers as NHWC."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(31)
+    b, h, w, c0, c1, c2 = 2, 12, 20, 32, 72, 40
+    x = torch.randn(b, h, w, c0, generator=g).to(dev)
+    w1 = (torch.randn(c1, 1, 1, c0, generator=g) * 0.2).to(dev)
+    w2 = (torch.randn(c2, 3, 3, c1, generator=g) * 0.05).to(dev)
+    sh1, sh2 = torch.randn(c1, generator=g).to(dev) * 0.1, torch.randn(c2, generator=g).to(dev) * 0.1
+    u2 = ops.winograd_weights(w2)
+    y1 = ops.conv_bn_act(x, w1, None, sh1, relu=True)
+    y1k = ops.conv_bn_act(x, w1, None, sh1, relu=True, out_kblocked=True)
+    assert tuple(y1k.shape) == (c1 // 8, b, h, w, 8)
+    assert torch.equal(y1k.permute(1, 2, 3, 0, 4).reshape(b, h, w, c1), y1)          # same values, other layout
+    assert torch.equal(ops.nhwc_to_kblocked(y1), y1k)
+    ref = ops.conv3x3_winograd(y1, u2, None, sh2, True)
+    assert torch.equal(ops.conv3x3_winograd(y1k, u2, None, sh2, True), ref)           # k-blocked input
+    yn, yk = ops.conv3x3_winograd(y1k, u2, None, sh2, True, out="both")
+    assert torch.equal(yn, ref) and torch.equal(yk.permute(1, 2, 3, 0, 4).reshape(b, h, w, c2), ref)
+    assert torch.equal(ops.conv3x3_winograd(y1, u2, None, sh2, True, out="kblocked"), yk)
+    # residual + k-blocked output of the direct kernel
+    r = torch.randn(b, h, w, c1, generator=g).to(dev)
+    a = ops.conv_bn_act(x, w1, None, sh1, relu=True, residual=r)
+    ak = ops.conv_bn_act(x, w1, None, sh1, relu=True, residual=r, out_kblocked=True)
+    assert torch.equal(ak.permute(1, 2, 3, 0, 4).reshape(b, h, w, c1), a)
