@@ -86,11 +86,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const WinoParams p) {
     // carries no address arithmetic at all: per-thread byte offsets are fixed for the whole tile (voffset, out of
     // range where the load must return zeros), the k tile's plane is the scalar soffset, LDS addresses are one base
     // register plus instruction-immediate offsets, and the transform is spread evenly over all four waves.
-    //   V: thread = (position tid & 63, channel pair tid >> 6): sixteen 8-byte patch loads
+    //   V: thread = (position tid >> 2, channel pair tid & 3): sixteen 8-byte patch loads; a wave-level load covers 16
+    //      pixels x 32 contiguous bytes = 8 cache lines (a position per lane would touch 32)
     //   U: eight 16-byte slots of the 16 x 64 x 8 block
     unsigned voff[16], uoff[8];
     {
-        const int pos = tid & 63, pair = tid >> 6;
+        const int pos = tid >> 2, pair = tid & 3;  // four lanes = the 32 contiguous bytes of one pixel's k tile
         const int P = m0 + pos;
         const bool pv = P < p.T;
         const int PP = pv ? P : 0;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const WinoParams p) {
     }
     // LDS float offsets inside a buffer: V component xi at v_lds + xi*PLANE; U slot i at u_lds + i*2*PLANE
     // (id = tid + 256*i: xi = 2i + (tid >> 7), so consecutive slots are two planes apart)
-    const int v_lds = (tid >> 7) * (WT * 4) + (tid & 63) * 4 + ((tid >> 6) & 1) * 2;
+    const int v_lds = ((tid & 3) >> 1) * (WT * 4) + (tid >> 2) * 4 + (tid & 1) * 2;
     const int u_lds = (tid >> 7) * PLANE + ((tid & 127) >> 6) * (WN * 4) + (tid & 63) * 4;
 
     const int nk = (p.Cin + WK - 1) / WK;
