@@ -371,6 +371,11 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
     // (a 256x128 BK16 tile — 25% fewer LDS/global bytes per MFMA — was measured in round 1: no gain over 128x128 even on
     // the largest layers, 133.5 vs 133.2 TFLOP/s, and a loss on mid-size ones; removed)
     if (force == 3 && !generic) return launch_conv<128, 128, 2, 2, 16>(p, generic, s);  // 41 KB LDS: 3 workgroups/CU
+    // Bottleneck conv3 (1x1 expansion + residual, K = planes <= 256): latency-bound on load -> MFMA -> residual -> store
+    // per tile; a 128x64 BK16 tile (30 KB of LDS, 32 accumulator registers) keeps five workgroups per CU in flight
+    // instead of two: 7 % faster on those layers, slower on everything else (measured per layer, round 1)
+    if (!generic && force != 1 && (force == 5 || (p.K <= 256 && p.residual && p.res_div == 1 && cout >= 128)))
+        return launch_conv<128, 64, 2, 2, 16>(p, generic, s);
     return launch_conv<128, 128, 2, 2, 32>(p, generic, s);
 }
 
