@@ -239,8 +239,8 @@ int mrcnn_winograd_weights_f32(const float* w, int32_t cout, int32_t cin, float*
 /* The same convolution with explicit tensor layouts, so that chains of 3x3 convs skip the transposition pass:
  * x_layout MRCNN_LAYOUT_NHWC (workspace needed) or MRCNN_LAYOUT_KBLOCKED = [cin/8][batch][H][W][8] (what the kernel
  * reads; no workspace). Outputs: y_nhwc and/or y_kblocked ([cout/8][batch][H][W][8], cout % 8 == 0); either may be
- * NULL, not both. mrcnn_conv_bn_act_f32 is mrcnn_conv_bn_act_nhwc_f32 with a selectable output layout
- * (a k-blocked output feeds a Winograd conv directly); mrcnn_nhwc_to_kblocked_f32 is the standalone transposition. */
+ * NULL, not both. mrcnn_conv_bn_act_f32 is mrcnn_conv_bn_act_nhwc_f32 with selectable output and residual layouts
+ * (a k-blocked output feeds a Winograd conv directly; the FPN laterals read their half-size residual k-blocked); mrcnn_nhwc_to_kblocked_f32 is the standalone transposition. */
 #define MRCNN_LAYOUT_NHWC 0
 #define MRCNN_LAYOUT_KBLOCKED 1
 int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int32_t batch, int32_t height, int32_t width,
@@ -250,8 +250,8 @@ int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int32_t batch, 
 int mrcnn_conv_bn_act_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin, const float* w,
                           int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad_top, int32_t pad_left,
                           int32_t pad_bottom, int32_t pad_right, const float* scale, const float* shift,
-                          const float* residual, int32_t res_div, int32_t activation, float* y, int32_t y_layout,
-                          mrcnn_stream_t stream);
+                          const float* residual, int32_t res_div, int32_t residual_layout, int32_t activation,
+                          float* y, int32_t y_layout, mrcnn_stream_t stream);
 int mrcnn_nhwc_to_kblocked_f32(const float* x, int64_t pixels, int32_t channels, float* y, mrcnn_stream_t stream);
 size_t mrcnn_conv3x3_winograd_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t cin);
 int mrcnn_conv3x3_winograd_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin,

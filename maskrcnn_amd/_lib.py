@@ -60,7 +60,8 @@ _SIGS = {
     "mrcnn_conv3x3_winograd_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32,
                                                     c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "mrcnn_conv_bn_act_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
-                                               c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp]),
+                                               c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32,
+                                               c_vp]),
     "mrcnn_nhwc_to_kblocked_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "mrcnn_topk_workspace_bytes": (ctypes.c_size_t, [c_i32]),
     "mrcnn_topk_desc_f32": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),

@@ -350,11 +350,11 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
                         const float* w, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad_top,
                         int32_t pad_left, int32_t pad_bottom, int32_t pad_right, const float* scale,
                         const float* shift, const float* residual, int32_t res_div, int32_t relu,
-                        int32_t out_mode, float* y, mrcnn_stream_t stream) {
+                        int32_t out_mode, float* y, mrcnn_stream_t stream, int32_t res_kblocked = 0) {
     MRCNN_REQUIRE(x && w && y, "conv: null pointer");
     ConvParams p;
     if (int rc = fill_common(p, "conv", x, batch, height, width, cin, 4, cout, kh, kw, stride, pad_top, pad_left,
-                             pad_bottom, pad_right, scale, shift, residual, res_div, relu, out_mode, y, 4))
+                             pad_bottom, pad_right, scale, shift, residual, res_div, relu, out_mode, y, 4, res_kblocked))
         return rc;
     p.w = w;
     p.w_head = nullptr;
@@ -393,11 +393,15 @@ extern "C" int mrcnn_conv_bn_act_f32(const float* x, int32_t batch, int32_t heig
                                      const float* w, int32_t cout, int32_t kh, int32_t kw, int32_t stride,
                                      int32_t pad_top, int32_t pad_left, int32_t pad_bottom, int32_t pad_right,
                                      const float* scale, const float* shift, const float* residual, int32_t res_div,
-                                     int32_t activation, float* y, int32_t y_layout, mrcnn_stream_t stream) {
+                                     int32_t residual_layout, int32_t activation, float* y, int32_t y_layout,
+                                     mrcnn_stream_t stream) {
     MRCNN_REQUIRE(y_layout == MRCNN_LAYOUT_NHWC || y_layout == MRCNN_LAYOUT_KBLOCKED, "conv: bad y_layout");
+    MRCNN_REQUIRE(residual_layout == MRCNN_LAYOUT_NHWC || residual_layout == MRCNN_LAYOUT_KBLOCKED,
+                  "conv: bad residual_layout");
     return run_conv_f32(x, batch, height, width, cin, w, cout, kh, kw, stride, pad_top, pad_left, pad_bottom,
                         pad_right, scale, shift, residual, res_div, activation,
-                        y_layout == MRCNN_LAYOUT_KBLOCKED ? 2 : 0, y, stream);
+                        y_layout == MRCNN_LAYOUT_KBLOCKED ? 2 : 0, y, stream,
+                        residual_layout == MRCNN_LAYOUT_KBLOCKED ? 1 : 0);
 }
 
 extern "C" int mrcnn_deconv2x2_bias_act_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,

@@ -22,6 +22,7 @@ struct ConvCommon {
     int res_div, act;  // act: 0 none, 1 ReLU (2 = sigmoid is the compile-time epilogue variant 3)
     int out_mode;      // 0: y[m][n]; 1: 2x2 stride-2 transposed-conv scatter, n = (dy*2+dx)*Cout/4 + co;
                        // 2: k-blocked y[n/8][m][n%8] (what the Winograd kernel reads; variants 0-3 only)
+    int res_kblocked;  // the residual tensor is k-blocked [Cout/8][residual pixels][8] instead of NHWC
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;  // buffer-descriptor ranges (< 4 GiB each)
 };
@@ -91,12 +92,15 @@ __device__ __forceinline__ void load_residual(const ConvCommon& p, int m0, int n
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.residual), 0, p.r_bytes, 0x00020000);
         const int rh = p.OH >> 1, rw = p.OW >> 1;
-        const unsigned row_bytes = static_cast<unsigned>(p.Cout) * 4u;
+        const unsigned row_bytes = p.res_kblocked ? 32u : static_cast<unsigned>(p.Cout) * 4u;
+        const unsigned rplane = static_cast<unsigned>(RES == 1 ? p.M : p.M >> 2) * 32u;  // bytes per 8-channel plane
         unsigned ncol[TN];
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
             const int n = n0 + wn * WTN + jn * 32 + ln;
-            ncol[jn] = n < p.Cout ? static_cast<unsigned>(n) * 4u : OOB;
+            ncol[jn] = n >= p.Cout ? OOB
+                       : p.res_kblocked ? static_cast<unsigned>(n >> 3) * rplane + static_cast<unsigned>(n & 7) * 4u
+                                        : static_cast<unsigned>(n) * 4u;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -192,7 +196,8 @@ __device__ __forceinline__ void epilogue(const ConvCommon& p, f32x16 (&acc)[TM][
 inline int fill_common(ConvCommon& p, const char* who, const float* x, int batch, int height, int width, int cin,
                        int cin_multiple, int cout, int kh, int kw, int stride, int pad_top, int pad_left,
                        int pad_bottom, int pad_right, const float* scale, const float* shift, const float* residual,
-                       int res_div, int activation, int out_mode, float* y, int weight_elem_bytes) {
+                       int res_div, int activation, int out_mode, float* y, int weight_elem_bytes,
+                       int res_kblocked = 0) {
     if (!(activation >= 0 && activation <= 2))
         return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: activation must be 0 (none), 1 (ReLU) or 2 (sigmoid)", who);
     if (residual && (activation == 2 || out_mode == 1))
@@ -227,6 +232,9 @@ inline int fill_common(ConvCommon& p, const char* who, const float* x, int batch
     p.res_div = residual ? res_div : 1;
     p.act = activation;
     p.out_mode = out_mode;
+    p.res_kblocked = (residual && res_kblocked) ? 1 : 0;
+    if (p.res_kblocked && cout % 8 != 0)
+        return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: a k-blocked residual needs Cout %% 8 == 0", who);
     p.x_bytes = static_cast<unsigned>(4LL * batch * height * width * cin);
     p.w_bytes = static_cast<unsigned>(1LL * weight_elem_bytes * K * cout);
     p.y_bytes = static_cast<unsigned>(4LL * M * cout);

@@ -335,14 +335,21 @@ class FusedBackbone:
                 x = blk(x)
             cs.append(x)
         c2, c3, c4, c5 = cs
-        p5 = self.lateral[5](c5)
-        p4 = self.lateral[4](c4, residual=p5, res_div=2)        # + nearest-upsampled P5 (model.py:150)
-        p3 = self.lateral[3](c3, residual=p4, res_div=2)
-        p2 = self.lateral[2](c2, residual=p3, res_div=2)
+        # Lateral maps feed a Winograd conv (smoothing) and the next lateral's half-size residual read, nothing else:
+        # in the f32 Winograd mode they are written k-blocked only, and read back k-blocked by both consumers.
+        hw = {5: c5, 4: c4, 3: c3, 2: c2}
+        kb = all(self.lateral[k].w.precision == "f32" and self.smooth[k].takes_winograd(hw[k].size(1), hw[k].size(2))
+                 for k in (5, 4, 3, 2))
+        lay = "kblocked" if kb else "nhwc"
+        p5 = self.lateral[5](c5, out=lay)
+        p4 = self.lateral[4](c4, residual=p5, res_div=2, out=lay)   # + nearest-upsampled P5 (model.py:150)
+        p3 = self.lateral[3](c3, residual=p4, res_div=2, out=lay)
+        p2 = self.lateral[2](c2, residual=p3, res_div=2, out=lay)
         outs, self.kblocked = [], []
         for k, p in ((2, p2), (3, p3), (4, p4), (5, p5)):
             sm = self.smooth[k]
-            if sm.w.precision == "f32" and sm.takes_winograd(p.size(1), p.size(2)) and sm.w.shape[0] % 8 == 0:
+            hh, ww = (p.size(2), p.size(3)) if p.dim() == 5 else (p.size(1), p.size(2))
+            if sm.w.precision == "f32" and sm.takes_winograd(hh, ww) and sm.w.shape[0] % 8 == 0:
                 # the smoothed map is read by RoIAlign (NHWC) and by the RPN's 3x3 conv (Winograd: k-blocked)
                 y, yk = sm(p, out="both")
             else:

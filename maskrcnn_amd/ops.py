@@ -208,7 +208,7 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
     relu: False/0 none, True/1 ReLU, 2 sigmoid.
     x [B,H,W,Cin] NHWC fp32 contiguous; w [Cout,KH,KW,Cin] (OHWI) contiguous; scale/shift [Cout] or
     None; pad = (top, left, bottom, right) zero padding applied on the fly; residual [B,OH/res_div,
-    OW/res_div,Cout]. Returns y [B,OH,OW,Cout] NHWC."""
+    OW/res_div,Cout] (or the same tensor k-blocked, 5-d). Returns y [B,OH,OW,Cout] NHWC."""
     _need_gpu(x, w, scale, shift, residual)
     assert x.dtype == torch.float32 and w.dtype == torch.float32
     assert x.is_contiguous() and w.is_contiguous() and x.dim() == 4 and w.dim() == 4
@@ -228,9 +228,11 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
         assert out.is_contiguous() and tuple(out.shape) == (b, oh, ow, cout)
     for t in (scale, shift):
         assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == cout)
+    res_kblocked = residual is not None and residual.dim() == 5
     if residual is not None:
         assert residual.is_contiguous() and residual.dtype == torch.float32
-        assert tuple(residual.shape) == (b, oh // res_div, ow // res_div, cout), \
+        want = (cout // 8, b, oh // res_div, ow // res_div, 8) if res_kblocked else (b, oh // res_div, ow // res_div, cout)
+        assert tuple(residual.shape) == want, \
             f"residual {tuple(residual.shape)} vs output {(b, oh, ow, cout)} / {res_div}"
     prof = CONV_PROFILE
     if prof is not None:
@@ -238,7 +240,7 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
         e0.record()
     check(lib.mrcnn_conv_bn_act_f32(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout, kh, kw,
                                     int(stride), pt, pl, pb, pr, _ptr(scale), _ptr(shift),
-                                    _ptr(residual), int(res_div), int(relu),
+                                    _ptr(residual), int(res_div), 1 if res_kblocked else 0, int(relu),
                                     out.data_ptr(), 1 if out_kblocked else 0, _stream()))
     if prof is not None:
         e1.record()

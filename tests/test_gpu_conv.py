@@ -344,3 +344,10 @@ def test_kblocked_layout_chain(dev):
     a = ops.conv_bn_act(x, w1, None, sh1, relu=True, residual=r)
     ak = ops.conv_bn_act(x, w1, None, sh1, relu=True, residual=r, out_kblocked=True)
     assert torch.equal(ak.permute(1, 2, 3, 0, 4).reshape(b, h, w, c1), a)
+    # k-blocked residual, same size and half size (the FPN laterals' nearest-upsample + add)
+    rk = ops.nhwc_to_kblocked(r)
+    assert torch.equal(ops.conv_bn_act(x, w1, None, sh1, relu=True, residual=rk), a)
+    r2 = torch.randn(b, h // 2, w // 2, c1, generator=g).to(dev)
+    a2 = ops.conv_bn_act(x, w1, None, sh1, residual=r2, res_div=2)
+    a2k = ops.conv_bn_act(x, w1, None, sh1, residual=ops.nhwc_to_kblocked(r2), res_div=2, out_kblocked=True)
+    assert torch.equal(a2k.permute(1, 2, 3, 0, 4).reshape(b, h, w, c1), a2)
