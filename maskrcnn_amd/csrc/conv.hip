@@ -22,6 +22,7 @@
 #include "conv_common.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -39,9 +40,15 @@ constexpr size_t conv_lds_bytes() {
     return sizeof(float) * 2 * (BM + BN) * (BK + 4);
 }
 
-// GENERIC: Cin % 32 != 0 (stem, Cin = 4): a k tile may straddle taps, each 16-byte slot decodes its own tap.
-template <int BM, int BN, int WM, int WN, int BK, bool GENERIC, int RES>
+// MODE 0: Cin % 32 == 0, any kernel size / stride / padding: a k tile lies inside one tap.
+// MODE 1 (GENERIC): Cin % 32 != 0 (stem, Cin = 4): a k tile may straddle taps, each 16-byte slot decodes its own tap.
+// MODE 2 (POINTWISE): 1x1, no padding, Cin % 32 == 0 — every conv the direct kernel still runs in the Winograd mode
+//   except the stem. No address arithmetic in the loop: a thread's byte offsets are fixed for the whole tile (out of
+//   range for rows beyond M), the k tile is the scalar soffset of the buffer loads. (VALU instructions do not
+//   co-execute with this MFMA — tools/mfma_valu_probe.hip — so each one removed is four cycles per wave and k tile.)
+template <int BM, int BN, int WM, int WN, int BK, int MODE, int RES>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
+    constexpr bool GENERIC = MODE == 1, PW = MODE == 2;
     constexpr int LDS_STRIDE = BK + 4;           // floats; keeps ds_read_b128 conflict-free (BK = 16 or 32)
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
@@ -72,6 +79,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
         b_off[i] = (b_ok[i] ? n : 0) * p.K + kq * 4;
     }
 
+    unsigned a_voff[PW ? PA : 1], b_voff[PW ? PB : 1];  // POINTWISE: fixed byte offsets (k0 = 0), OOB where zero
+    if constexpr (PW) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            a_voff[i] = (m0 + r0 + RPP * i) < p.M ? static_cast<unsigned>(a_off[i] + kq * 4) * 4u : OOB;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) b_voff[i] = b_ok[i] ? static_cast<unsigned>(b_off[i]) * 4u : OOB;
+    }
     float4 ra[PA], rb[PB];
     // Predication without branches: loads go through raw buffer descriptors (hardware range check); an
     // out-of-image tap / out-of-range row gets a byte offset beyond num_records and returns zeros. The
@@ -130,6 +145,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
         t_k0 += BK;
     };
     auto load_piece = [&](int pc) {  // pc < PA: activation slot pc; else weight slot pc - PA
+        if constexpr (PW) {
+            // past the end of K the last k tile is loaded again (into a buffer nobody reads): soffset is not range-checked
+            const int kk = cur_k0 < p.K ? cur_k0 : p.K - BK;
+            const bool isa = pc < PA;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(isa ? x_rsrc : w_rsrc,
+                                                                  static_cast<int>(isa ? a_voff[isa ? pc : 0] : b_voff[isa ? 0 : pc - PA]),
+                                                                  kk * 4, 0);
+            const float4 f = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                                         __uint_as_float(v.w));
+            if (isa) ra[isa ? pc : 0] = f;
+            else rb[isa ? 0 : pc - PA] = f;
+            return;
+        }
         if (pc < PA) {
             const int i = pc;
             if constexpr (!GENERIC) {
@@ -297,7 +325,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
 }
 
 template <int BM, int BN, int WM, int WN, int BK>
-int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
+int launch_conv(ConvParams p, int mode, hipStream_t stream) {  // mode: 0 aligned taps, 1 generic, 2 pointwise
+    const bool generic = mode == 1;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.Cout + BN - 1) / BN;
     const long long grid = tile_grid(p);
@@ -313,9 +342,9 @@ int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
         return MRCNN_OK;
     };
     const int res = epilogue_variant(p, p.w_head != nullptr);
-    static bool attr_done[2][6] = {};
+    static bool attr_done[3][6] = {};
     auto go = [&](auto kern) -> int {
-        if (int rc = set_attr(reinterpret_cast<const void*>(kern), attr_done[generic ? 1 : 0][res])) return rc;
+        if (int rc = set_attr(reinterpret_cast<const void*>(kern), attr_done[mode][res])) return rc;
         hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
         return MRCNN_OK;
     };
@@ -323,23 +352,22 @@ int launch_conv(ConvParams p, bool generic, hipStream_t stream) {
     if constexpr (BM == 128 && BN == 128 && WM == 2 && WN == 2 && BK == 32) {
         if (res == 5) {
             if (generic) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: fused heads need Cin %% 32 == 0");
-            if ((rc = go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 5>))) return rc;
+            if ((rc = go(conv_igemm_f32<BM, BN, WM, WN, BK, 0, 5>))) return rc;
             return mrcnn::check_launch("conv_igemm_f32<heads>");
         }
     }
     if (res == 5) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: fused heads need the 128x128 tile");
-    if (generic)
-        rc = res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 0>)
-           : res == 1 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 1>)
-           : res == 2 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 2>)
-           : res == 3 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 3>)
-                      : go(conv_igemm_f32<BM, BN, WM, WN, BK, true, 4>);
-    else
-        rc = res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 0>)
-           : res == 1 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 1>)
-           : res == 2 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 2>)
-           : res == 3 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 3>)
-                      : go(conv_igemm_f32<BM, BN, WM, WN, BK, false, 4>);
+    auto by_res = [&](auto mode_tag) -> int {
+        constexpr int MD = decltype(mode_tag)::value;
+        return res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, MD, 0>)
+             : res == 1 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, MD, 1>)
+             : res == 2 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, MD, 2>)
+             : res == 3 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, MD, 3>)
+                        : go(conv_igemm_f32<BM, BN, WM, WN, BK, MD, 4>);
+    };
+    rc = mode == 1 ? by_res(std::integral_constant<int, 1>{})
+       : mode == 2 ? by_res(std::integral_constant<int, 2>{})
+                   : by_res(std::integral_constant<int, 0>{});
     if (rc) return rc;
     return mrcnn::check_launch("conv_igemm_f32");
 }
@@ -361,22 +389,25 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
     p.head_n = 0;
     const long long M = p.M;
     const bool generic = (cin % 32) != 0;
+    const bool pointwise = !generic && kh == 1 && kw == 1 && pad_top == 0 && pad_left == 0 && pad_bottom == 0 &&
+                           pad_right == 0 && getenv("MRCNN_CONV_NO_PW") == nullptr;
+    const int mode = generic ? 1 : pointwise ? 2 : 0;
     hipStream_t s = mrcnn::as_stream(stream);
     static const int force = getenv("MRCNN_CONV_TILE") ? atoi(getenv("MRCNN_CONV_TILE")) : 0;  // tuning aid
-    if (cout <= 32) return launch_conv<128, 32, 4, 1, 32>(p, generic, s);
+    if (cout <= 32) return launch_conv<128, 32, 4, 1, 32>(p, mode, s);
     // Cout <= 64: 256x64 tile. BK = 16 keeps its LDS at 51 KB (two workgroups per CU; BK = 32 needs 92 KB = one):
     // measured 3-20 % faster on the C2 layers. The stem (generic K) keeps BK = 32.
-    if (cout <= 64) return (generic || force == 4) ? launch_conv<256, 64, 4, 1, 32>(p, generic, s)
-                                                   : launch_conv<256, 64, 4, 1, 16>(p, generic, s);
+    if (cout <= 64) return (generic || force == 4) ? launch_conv<256, 64, 4, 1, 32>(p, mode, s)
+                                                   : launch_conv<256, 64, 4, 1, 16>(p, mode, s);
     // (a 256x128 BK16 tile — 25% fewer LDS/global bytes per MFMA — was measured in round 1: no gain over 128x128 even on
     // the largest layers, 133.5 vs 133.2 TFLOP/s, and a loss on mid-size ones; removed)
-    if (force == 3 && !generic) return launch_conv<128, 128, 2, 2, 16>(p, generic, s);  // 41 KB LDS: 3 workgroups/CU
+    if (force == 3 && !generic) return launch_conv<128, 128, 2, 2, 16>(p, mode, s);  // 41 KB LDS: 3 workgroups/CU
     // Bottleneck conv3 (1x1 expansion + residual, K = planes <= 256): latency-bound on load -> MFMA -> residual -> store
     // per tile; a 128x64 BK16 tile (30 KB of LDS, 32 accumulator registers) keeps five workgroups per CU in flight
     // instead of two: 7 % faster on those layers, slower on everything else (measured per layer, round 1)
     if (!generic && force != 1 && (force == 5 || (p.K <= 256 && p.residual && p.res_div == 1 && cout >= 128)))
-        return launch_conv<128, 64, 2, 2, 16>(p, generic, s);
-    return launch_conv<128, 128, 2, 2, 32>(p, generic, s);
+        return launch_conv<128, 64, 2, 2, 16>(p, mode, s);
+    return launch_conv<128, 128, 2, 2, 32>(p, mode, s);
 }
 
 extern "C" int mrcnn_conv_bn_act_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
@@ -461,7 +492,7 @@ extern "C" int mrcnn_rpn_level_fused_f32(const float* x, int32_t batch, int32_t 
     p.w_head = w_head32;
     p.head_n = head_n;
     hipStream_t s = mrcnn::as_stream(stream);
-    if (int rc = launch_conv<128, 128, 2, 2, 32>(p, false, s)) return rc;
+    if (int rc = launch_conv<128, 128, 2, 2, 32>(p, 0, s)) return rc;
     const int64_t MC = M * head_n;
     int64_t blocks = (MC + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
