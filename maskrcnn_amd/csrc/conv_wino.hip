@@ -24,6 +24,7 @@
 #include "conv_common.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -313,6 +314,267 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const WinoParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Eight-wave variant: the same workgroup tile (64 positions x 64 channels, 128 KB of LDS) and k-blocked operands, but
+// 512 threads — wave w owns TWO components (2w, 2w+1) for the whole tile: 128 accumulator registers, so TWO waves per
+// SIMD. With one wave per SIMD every LDS / VMEM / scalar instruction and every wait sits on the MFMA critical path
+// (there is nobody else to issue); with two, one wave's staging and stalls overlap the other's MFMAs (VALU still does
+// not: tools/mfma_valu_probe.hip). Waves 0-3 stage V (patch loads + input transform), waves 4-7 stage U; wave w and
+// w+4 share a SIMD, so each SIMD carries one of each. The output transform needs all 16 components of a position:
+// M.A is split into partial sums per wave (columns j = 0,1 or 2,3), exchanged through LDS in two rounds of 32
+// positions (8 waves x 2 partials x 32 x 64 floats = the 128 KB the operand buffers occupied).
+__global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32(const WinoParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Vs = smem;
+    float* Us = smem + 2 * 16 * PLANE;
+
+    ConvCommon tc;
+    tc.tiles_m = p.tiles_m;
+    tc.tiles_n = p.tiles_n;
+    int m0, n0, nt;
+    if (!tile_origin(tc, WT, WN, m0, n0, nt)) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 31, lh = lane >> 5;
+    const bool v_role = wave < 4;
+    const int st = tid & 255;  // index inside the staging group (V: waves 0-3, U: waves 4-7)
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+
+    // fixed per-thread byte offsets (see the four-wave kernel): V role 16 patch taps, U role 8 slots (in off[0..7])
+    unsigned off[16];
+    if (v_role) {
+        const int pos = st >> 2, pair = st & 3;
+        const int P = m0 + pos;
+        const bool pv = P < p.T;
+        const int PP = pv ? P : 0;
+        const int b = PP / (p.TH * p.TW), rem = PP - b * p.TH * p.TW;
+        const int ty = rem / p.TW, tx = rem - ty * p.TW;
+        const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                const int iy = iy0 + dy, ix = ix0 + dx;
+                const bool ok = pv && static_cast<unsigned>(iy) < static_cast<unsigned>(p.H) &&
+                                static_cast<unsigned>(ix) < static_cast<unsigned>(p.W);
+                off[dy * 4 + dx] = ok ? static_cast<unsigned>(((b * p.H + iy) * p.W + ix) * WK + pair * 2) * 4u : OOB;
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int id = st + 256 * i;
+            const int xi = id >> 7, r = id & 127, q = r >> 6, ch = r & 63;
+            const int n = n0 + ch;
+            off[i] = n < p.Cout ? static_cast<unsigned>((xi * p.Cout + n) * WK + q * 4) * 4u : OOB;
+        }
+#pragma unroll
+        for (int i = 8; i < 16; ++i) off[i] = OOB;
+    }
+    const int v_lds = ((st & 3) >> 1) * (WT * 4) + (st >> 2) * 4 + (st & 1) * 2;
+    const int u_lds = (st >> 7) * PLANE + ((st & 127) >> 6) * (WN * 4) + (st & 63) * 4;
+
+    const int nk = (p.Cin + WK - 1) / WK;
+    auto plane_of = [&](int kt) { return static_cast<unsigned>(kt < nk ? kt : nk - 1); };
+    // one register file for both roles: V uses ld as 16 x (2 floats), U as 8 x (4 dwords)
+    u32x2 ld[16];
+    auto v_load = [&](int i, int kt) {
+        ld[i] = __builtin_amdgcn_raw_buffer_load_b64(x_rsrc, static_cast<int>(off[i]),
+                                                     static_cast<int>(plane_of(kt) * p.x_plane), 0);
+    };
+    auto u_load = [&](int i, int kt) {
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, static_cast<int>(off[i]),
+                                                              static_cast<int>(plane_of(kt) * p.u_plane), 0);
+        ld[2 * i] = u32x2{r.x, r.y};
+        ld[2 * i + 1] = u32x2{r.z, r.w};
+    };
+    auto f2 = [](u32x2 v) { return f32x2{__uint_as_float(v.x), __uint_as_float(v.y)}; };
+    f32x2 t[4][4];
+    auto column_pass = [&](int dx) {
+        const f32x2 d0 = f2(ld[0 * 4 + dx]), d1 = f2(ld[1 * 4 + dx]), d2 = f2(ld[2 * 4 + dx]), d3 = f2(ld[3 * 4 + dx]);
+        t[0][dx] = pk_sub(d0, d2);
+        t[1][dx] = pk_add(d1, d2);
+        t[2][dx] = pk_sub(d2, d1);
+        t[3][dx] = pk_sub(d1, d3);
+    };
+    auto v_store = [&](int xi, float* vbuf) {
+        const int i = xi >> 2, j = xi & 3;
+        const f32x2 v = j == 0 ? pk_sub(t[i][0], t[i][2]) : j == 1 ? pk_add(t[i][1], t[i][2])
+                      : j == 2 ? pk_sub(t[i][2], t[i][1]) : pk_sub(t[i][1], t[i][3]);
+        *reinterpret_cast<f32x2*>(vbuf + xi * PLANE) = v;
+    };
+    auto u_store = [&](int i, float* ubuf) {
+        *reinterpret_cast<u32x4*>(ubuf + i * 2 * PLANE) = u32x4{ld[2 * i].x, ld[2 * i].y, ld[2 * i + 1].x, ld[2 * i + 1].y};
+    };
+
+    f32x16 acc[2][2][2];  // [component of the pair][position half][channel half]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][a][c][r] = 0.f;
+
+    // prologue: k tile 0 into buffer 0, loads of k tile 1 in flight
+    if (v_role) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v_load(i, 0);
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) column_pass(dx);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) v_store(xi, Vs + v_lds);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v_load(i, 1);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u_load(i, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u_store(i, Us + u_lds);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u_load(i, 1);
+    }
+    __syncthreads();
+
+    const float* Aw = Vs + (wave * 2) * PLANE + lh * (WT * 4) + ln * 4;
+    const float* Bw = Us + (wave * 2) * PLANE + lh * (WN * 4) + ln * 4;
+    float4 fa[2], fb[2];  // operand fragments of the component being multiplied (the partner wave covers their latency)
+    auto read_frags = [&](int buf, int j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            fa[h] = *reinterpret_cast<const float4*>(Aw + buf * 16 * PLANE + j * PLANE + h * 32 * 4);
+            fb[h] = *reinterpret_cast<const float4*>(Bw + buf * 16 * PLANE + j * PLANE + h * 32 * 4);
+        }
+    };
+    // main loop: 32 MFMAs per k tile and wave. Staging of k tile kt+1 is spread over slots 0..23 (V: 4 column passes,
+    // 16 loads for kt+2, 16 component stores; U: 8 stores + 8 loads), one barrier at the end of the k tile — the stalls
+    // (operand reads, the barrier) are covered by the other wave of the SIMD.
+    // the two staging roles run separate copies of the loop (wave-uniform, decided once): no per-slot branches, and each
+    // copy gets its own register allocation
+    auto main_loop = [&](auto role) {
+        constexpr bool VROLE = decltype(role)::value;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            float* vnext = Vs + (buf ^ 1) * 16 * PLANE + v_lds;
+            float* unext = Us + (buf ^ 1) * 16 * PLANE + u_lds;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                read_frags(buf, j);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int stp = 0; stp < 4; ++stp) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const float4 fav = fa[a], fbv = fb[c];
+                            const float av = stp == 0 ? fav.x : stp == 1 ? fav.y : stp == 2 ? fav.z : fav.w;
+                            const float bv = stp == 0 ? fbv.x : stp == 1 ? fbv.y : stp == 2 ? fbv.z : fbv.w;
+                            acc[j][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j][a][c], 0, 0, 0);
+                            const int m = j * 16 + stp * 4 + a * 2 + c;  // MFMA slot 0..31
+                            if constexpr (VROLE) {
+                                if (m < 4) column_pass(m);
+                                if (m >= 4 && m < 20) v_load(m - 4, kt + 2);
+                                if (m >= 8 && m < 24) v_store(m - 8, vnext);
+                            } else {
+                                if (m >= 4 && m < 12) {
+                                    u_store(m - 4, unext);
+                                    u_load(m - 4, kt + 2);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // k tile kt+1 complete in buf^1, everyone done reading buf
+        }
+    };
+    if (v_role) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+
+    // ---- epilogue: wave = (i = wave >> 1, jh = wave & 1) holds M_i,2jh and M_i,2jh+1 ------------------------------
+    //   (M A)_i0 = M_i0 + M_i1 + M_i2,  (M A)_i1 = M_i1 - M_i2 - M_i3:  jh = 0 contributes (M_i0 + M_i1,  M_i1),
+    //                                                                    jh = 1 contributes (M_i2, -M_i2 - M_i3)
+    const int n = n0 + (tid & 63);
+    const bool n_ok = n < p.Cout;
+    const float sc = (n_ok && p.scale) ? p.scale[n] : 1.0f, sh = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yk_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.yk, 0, p.y_bytes, 0x00020000);
+    const unsigned ncol = n_ok ? static_cast<unsigned>(n) * 4u : OOB;
+    const unsigned kcol = static_cast<unsigned>(n >> 3) * p.yk_plane + static_cast<unsigned>(n & 7) * 4u;
+    float* Z = smem;  // [wave][2 partials][8 position quads][64 channels][4 positions]
+    constexpr int ZQ = 8 * WN * 4;  // floats per (wave, partial) plane
+    const int jh = wave & 1;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {  // position half
+        __syncthreads();  // operand buffers (or the previous round's Z) are no longer read
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int pq = 2 * rq + lh, ch = c * 32 + ln;
+                float4 zp, zq;
+                float* zpp = &zp.x;
+                float* zqp = &zq.x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = rq * 4 + e;
+                    const float ma = h == 0 ? acc[0][0][c][r] : acc[0][1][c][r];
+                    const float mb = h == 0 ? acc[1][0][c][r] : acc[1][1][c][r];
+                    zpp[e] = jh == 0 ? ma + mb : ma;
+                    zqp[e] = jh == 0 ? mb : -ma - mb;
+                }
+                *reinterpret_cast<float4*>(Z + (wave * 2 + 0) * ZQ + (pq * WN + ch) * 4) = zp;
+                *reinterpret_cast<float4*>(Z + (wave * 2 + 1) * ZQ + (pq * WN + ch) * 4) = zq;
+            }
+        __syncthreads();
+        // 512 threads finish 32 positions: thread = (channel tid & 63, position quad tid >> 6)
+        const int pq = tid >> 6, ch = tid & 63;
+        float4 y0[4], y1[4];  // (M A)_i0, (M A)_i1 for i = 0..3, four positions each
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 p0 = *reinterpret_cast<const float4*>(Z + ((2 * i) * 2 + 0) * ZQ + (pq * WN + ch) * 4);
+            const float4 p1 = *reinterpret_cast<const float4*>(Z + ((2 * i + 1) * 2 + 0) * ZQ + (pq * WN + ch) * 4);
+            const float4 q0 = *reinterpret_cast<const float4*>(Z + ((2 * i) * 2 + 1) * ZQ + (pq * WN + ch) * 4);
+            const float4 q1 = *reinterpret_cast<const float4*>(Z + ((2 * i + 1) * 2 + 1) * ZQ + (pq * WN + ch) * 4);
+            y0[i] = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
+            y1[i] = make_float4(q0.x + q1.x, q0.y + q1.y, q0.z + q1.z, q0.w + q1.w);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int P = __builtin_amdgcn_readfirstlane(m0 + h * 32 + pq * 4 + e);
+            const bool pv = P < p.T;
+            const int PP = pv ? P : 0;
+            const int b = PP / (p.TH * p.TW), rem = PP - b * p.TH * p.TW;
+            const int ty = rem / p.TW, tx = rem - ty * p.TW;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float z0 = c == 0 ? (&y0[0].x)[e] : (&y1[0].x)[e], z1 = c == 0 ? (&y0[1].x)[e] : (&y1[1].x)[e];
+                const float z2 = c == 0 ? (&y0[2].x)[e] : (&y1[2].x)[e], z3 = c == 0 ? (&y0[3].x)[e] : (&y1[3].x)[e];
+                const float yv[2] = {z0 + z1 + z2, z1 - z2 - z3};
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float v = yv[a] * sc + sh;
+                    if (p.act) v = v > 0.f ? v : 0.f;
+                    const unsigned px = static_cast<unsigned>((b * p.H + 2 * ty + a) * p.W + 2 * tx + c);
+                    if (p.y) {
+                        const unsigned o = (pv && n_ok) ? px * (static_cast<unsigned>(p.Cout) * 4u) + ncol : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(o), 0, 0);
+                    }
+                    if (p.yk) {
+                        const unsigned o = (pv && n_ok) ? kcol + px * 32u : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yk_rsrc, static_cast<int>(o), 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // U_xi[n][c] = (G g G^T)[i][j], xi = 4i + j, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; evaluated in double; stored
 // k-blocked [Cin/8][16][Cout][8] so that a k tile's 16 x 64 x 8 block is sixteen contiguous 2 KB runs.
 __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, int cout, int cin,
@@ -425,12 +687,19 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
     MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd: grid too large");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_f32),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(WINO_LDS));
-        if (e != hipSuccess) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        for (const void* f : {reinterpret_cast<const void*>(conv3x3_wino_f32),
+                              reinterpret_cast<const void*>(conv3x3_wino8_f32)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(WINO_LDS));
+            if (e != hipSuccess)
+                return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv3x3_wino_f32, dim3(static_cast<unsigned>(grid)), dim3(256), WINO_LDS, st, p);
+    static const bool four_waves = getenv("MRCNN_WINO_WAVES") && atoi(getenv("MRCNN_WINO_WAVES")) == 4;
+    if (four_waves)
+        hipLaunchKernelGGL(conv3x3_wino_f32, dim3(static_cast<unsigned>(grid)), dim3(256), WINO_LDS, st, p);
+    else
+        hipLaunchKernelGGL(conv3x3_wino8_f32, dim3(static_cast<unsigned>(grid)), dim3(512), WINO_LDS, st, p);
     return mrcnn::check_launch("conv3x3_wino_f32");
 }
 
