@@ -328,14 +328,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32(const WinoParams p) 
     float* Vs = smem;
     float* Us = smem + 2 * 16 * PLANE;
 
-    ConvCommon tc;
-    tc.tiles_m = p.tiles_m;
-    tc.tiles_n = p.tiles_n;
-    int m0, n0, nt;
-    if (!tile_origin(tc, WT, WN, m0, n0, nt)) return;
-
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Persistent workgroups (p.persistent: one per CU, gridDim a multiple of 8): workgroup b takes the tiles b,
+    // b + gridDim, ... of the XCD-aware virtual grid, so it stays on its XCD and the CUs of an XCD work on neighbouring
+    // tiles at any time; this saves a workgroup launch (128 KB of LDS, eight waves) per tile.
+    const int total_tiles = 8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    int m0, n0;
+    {
+        const int xcd = tile & 7, seq = tile >> 3;
+        const int mt_lo = (xcd * p.tiles_m) >> 3, mt_hi = ((xcd + 1) * p.tiles_m) >> 3;
+        const int mt = mt_lo + seq / p.tiles_n;
+        if (mt >= mt_hi) continue;  // uniform
+        m0 = mt * WT;
+        n0 = (seq % p.tiles_n) * WN;
+    }
     const int ln = lane & 31, lh = lane >> 5;
     const bool v_role = wave < 4;
     const int st = tid & 255;  // index inside the staging group (V: waves 0-3, U: waves 4-7)
@@ -573,6 +581,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32(const WinoParams p) 
             }
         }
     }
+    __syncthreads();  // Z is read out: the next tile may overwrite the operand buffers
+    }  // tiles
 }
 
 // U_xi[n][c] = (G g G^T)[i][j], xi = 4i + j, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; evaluated in double; stored
@@ -698,8 +708,19 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
     static const bool four_waves = getenv("MRCNN_WINO_WAVES") && atoi(getenv("MRCNN_WINO_WAVES")) == 4;
     if (four_waves)
         hipLaunchKernelGGL(conv3x3_wino_f32, dim3(static_cast<unsigned>(grid)), dim3(256), WINO_LDS, st, p);
-    else
-        hipLaunchKernelGGL(conv3x3_wino8_f32, dim3(static_cast<unsigned>(grid)), dim3(512), WINO_LDS, st, p);
+    else {
+        static int num_cu = 0;
+        if (num_cu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+                return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd: cannot query the device");
+            num_cu = prop.multiProcessorCount >= 8 ? (prop.multiProcessorCount / 8) * 8 : 8;
+        }
+        static const bool persistent = !(getenv("MRCNN_WINO_PERSISTENT") && atoi(getenv("MRCNN_WINO_PERSISTENT")) == 0);
+        const long long launch = (persistent && grid > num_cu) ? num_cu : grid;
+        hipLaunchKernelGGL(conv3x3_wino8_f32, dim3(static_cast<unsigned>(launch)), dim3(512), WINO_LDS, st, p);
+    }
     return mrcnn::check_launch("conv3x3_wino_f32");
 }
 
