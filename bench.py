@@ -191,8 +191,11 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic.json")
         if (args.precision == "f32" and args.batch == 8 and (H, W) == (1024, 1024) and args.arch == "resnet50"
                 and os.path.exists(tpath)):
-            with open(tpath) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_step")
+            try:
+                with open(tpath) as fh:
+                    traffic = json.load(fh).get("hbm_bytes_per_step")
+            except (OSError, ValueError):
+                traffic = None
         if args.dump_conv:
             per = len(prof) // args.roofline_steps
             rows = []

@@ -4,6 +4,7 @@ HBM bytes of all conv launches of ONE batch-8 step. gfx950 corrections per MI355
 counters are in KiB; FETCH_SIZE under-reports wide coalesced reads by exactly 2x → doubled."""
 import csv
 import json
+import re
 import sys
 
 
@@ -12,7 +13,9 @@ def step_sum(path, counter):
     # every launch of the conv path: the direct implicit-GEMM kernel, the Winograd kernel and its k-blocking pre-pass
     conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm_f32", "conv3x3_wino_f32", "kblock_kernel"))]
     # a batch-8 step starts at the stem launch: the GENERIC (<..., true, RES>) instantiation with the largest grid
-    stems = [i for i, r in enumerate(conv) if "conv_igemm_f32" in r["Kernel_Name"] and ", true," in r["Kernel_Name"]]
+    # the stem is the only launch of the GENERIC instantiation (template argument MODE = 1)
+    stem_re = re.compile(r"conv_igemm_f32<\d+, \d+, \d+, \d+, \d+, (1|true), \d+>")
+    stems = [i for i, r in enumerate(conv) if stem_re.search(r["Kernel_Name"])]
     big = max(int(conv[i]["Grid_Size"]) for i in stems)
     starts = [i for i in stems if int(conv[i]["Grid_Size"]) == big]
     i0 = starts[-1]
