@@ -11,7 +11,7 @@ import sys
 def step_sum(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     # every launch of the conv path: the direct implicit-GEMM kernel, the Winograd kernel and its k-blocking pre-pass
-    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm_f32", "conv3x3_wino_f32", "kblock_kernel"))]
+    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm_f32", "conv3x3_wino", "kblock_kernel"))]
     # a batch-8 step starts at the stem launch: the GENERIC (<..., true, RES>) instantiation with the largest grid
     # the stem is the only launch of the GENERIC instantiation (template argument MODE = 1)
     stem_re = re.compile(r"conv_igemm_f32<\d+, \d+, \d+, \d+, \d+, (1|true), \d+>")
