@@ -259,6 +259,14 @@ int mrcnn_conv3x3_winograd_nhwc_f32(const float* x, int32_t batch, int32_t heigh
                                     int32_t activation, float* y, void* workspace, size_t workspace_bytes,
                                     mrcnn_stream_t stream);
 
+/* The ResNet stem as its own kernel (model.py:223-226): conv 7x7 stride 2 pad 3, 4 input channels (RGB + one zero
+ * channel) -> 64, + affine + ReLU. x [batch][H][W][4], w [64][7][7][4] (OHWI), y [batch][H/2][W/2][64]; H, W even.
+ * Same arithmetic as mrcnn_conv_bn_act_nhwc_f32 on this layer (exact fp32 MFMA; the accumulation order over k is
+ * identical), 3x faster: filter resident in LDS, input patch staged per 16x16 output tile, no addressing in the loop. */
+int mrcnn_stem_conv7x7_s2_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width, const float* w,
+                                   const float* scale, const float* shift, int32_t activation, float* y,
+                                   mrcnn_stream_t stream);
+
 /* ---- selection steps of the two refine stages (no library sort / top-k / gather in the step) --------------------
  * Total, deterministic order everywhere: descending score, ties by ascending index (ATen's sort, which the
  * reference calls at model.py:1346,1478, leaves ties unspecified).

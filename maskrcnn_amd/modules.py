@@ -155,6 +155,9 @@ PRECISIONS = ("f32", "f16x3", "f16")
 # results differ from the direct kernel by the transforms' rounding, ~1e-5 abs on unit-scale activations).
 # MRCNN_WINOGRAD=0 keeps every conv on the direct implicit-GEMM kernel (bitwise an fmaf chain).
 WINOGRAD = os.environ.get("MRCNN_WINOGRAD", "1") != "0"
+# f32 mode: the 7x7 stride-2 stem runs its own kernel (same fp32 MFMA arithmetic as the generic one, 3x faster);
+# MRCNN_STEM_KERNEL=0 sends it through the generic implicit-GEMM kernel.
+STEM_KERNEL = os.environ.get("MRCNN_STEM_KERNEL", "1") != "0"
 
 
 class ConvWeight:
@@ -327,7 +330,12 @@ class FusedBackbone:
 
     def __call__(self, image_nchw):
         x = ops.nchw_to_nhwc(image_nchw.contiguous(), self.cin_pad)   # 3 → 4 (8) channels, zero-padded
-        x = self.stem(x)                                        # conv7x7 s2 p3 + BN + ReLU
+        st = self.stem                                          # conv7x7 s2 p3 + BN + ReLU
+        if (st.w.precision == "f32" and st.w.shape == (64, 7, 7, 4) and x.size(1) % 2 == 0 and x.size(2) % 2 == 0
+                and STEM_KERNEL):
+            x = ops.stem_conv(x, st.w.w, st.scale, st.shift, True, st.algo_cin)   # dedicated kernel (csrc/stem.hip)
+        else:
+            x = st(x)
         x = ops.maxpool(x, 3, 2, ops.same_pad(x.size(1), x.size(2), 3, 2))
         cs = []
         for blocks in self.stages:

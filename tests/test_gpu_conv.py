@@ -351,3 +351,31 @@ def test_kblocked_layout_chain(dev):
     a2 = ops.conv_bn_act(x, w1, None, sh1, residual=r2, res_div=2)
     a2k = ops.conv_bn_act(x, w1, None, sh1, residual=ops.nhwc_to_kblocked(r2), res_div=2, out_kblocked=True)
     assert torch.equal(a2k.permute(1, 2, 3, 0, 4).reshape(b, h, w, c1), a2)
+
+
+def test_stem_kernel_vs_generic_and_torch(dev):
+    """csrc/stem.hip against the generic implicit-GEMM kernel on the same layer (same fp32 MFMA products; the k order
+    inside a tap differs, so equality is to rounding) and against torch CPU (1e-4), incl. ragged tiles and batch > 1."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(41)
+    for (b, h, w) in ((2, 64, 64), (1, 38, 70), (3, 32, 16), (1, 2, 2)):
+        x = torch.randn(b, h, w, 4, generator=g)
+        x[..., 3] = 0
+        wt = torch.randn(64, 7, 7, 4, generator=g) * math.sqrt(2.0 / 147)
+        wt[..., 3] = 0
+        sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+        y = ops.stem_conv(x.to(dev), wt.to(dev), sc.to(dev), sh.to(dev), True)
+        yd = ops.conv_bn_act(x.to(dev), wt.to(dev), sc.to(dev), sh.to(dev), 2, (3, 3, 3, 3), True)
+        ref = _ref_conv(x.permute(0, 3, 1, 2), wt.permute(0, 3, 1, 2), sc, sh, 2, (3, 3, 3, 3), True).permute(0, 2, 3, 1)
+        assert tuple(y.shape) == (b, h // 2, w // 2, 64)
+        assert (y - yd).abs().max().item() <= 2e-5
+        assert (y.cpu() - ref).abs().max().item() <= TOL
+    # the headline shape, against the generic kernel
+    x = torch.randint(0, 256, (2, 1024, 1024, 4), generator=g).float() - 120.0
+    x[..., 3] = 0
+    wt = torch.randn(64, 7, 7, 4, generator=g) * math.sqrt(2.0 / 147)
+    wt[..., 3] = 0
+    sh = torch.randn(64, generator=g) * 0.1
+    y = ops.stem_conv(x.to(dev), wt.to(dev), None, sh.to(dev), True)
+    yd = ops.conv_bn_act(x.to(dev), wt.to(dev), None, sh.to(dev), 2, (3, 3, 3, 3), True)
+    assert (y - yd).abs().max().item() <= 1e-4 * max(1.0, yd.abs().max().item())
