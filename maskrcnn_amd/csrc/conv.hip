@@ -484,7 +484,8 @@ extern "C" int mrcnn_rpn_level_fused_f32(const float* x, int32_t batch, int32_t 
     p.stride = 1; p.pad_t = 1; p.pad_l = 1; p.OH = height; p.OW = width;
     p.M = static_cast<int>(M);
     p.K = 9 * cin;
-    p.res_div = 1; p.act = 1; p.out_mode = 0;
+    p.res_div = 1; p.act = 1; p.out_mode = 0; p.res_kblocked = 0;
+    p.ow_shift = p.ohw_shift = -1;  // (pixel decode by division: this entry point is not on the default path)
     p.x_bytes = static_cast<unsigned>(4LL * M * cin);
     p.w_bytes = static_cast<unsigned>(4LL * p.K * cout);
     p.y_bytes = static_cast<unsigned>(4LL * tiles_n * M * head_n);

@@ -22,6 +22,7 @@ struct ConvCommon {
     int res_div, act;  // act: 0 none, 1 ReLU (2 = sigmoid is the compile-time epilogue variant 3)
     int out_mode;      // 0: y[m][n]; 1: 2x2 stride-2 transposed-conv scatter, n = (dy*2+dx)*Cout/4 + co;
                        // 2: k-blocked y[n/8][m][n%8] (what the Winograd kernel reads; variants 0-3 only)
+    int ow_shift, ohw_shift;  // log2(OW), log2(OH*OW) when both are powers of two, else -1 (pixel decode without division)
     int res_kblocked;  // the residual tensor is k-blocked [Cout/8][residual pixels][8] instead of NHWC
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;  // buffer-descriptor ranges (< 4 GiB each)
@@ -32,6 +33,24 @@ struct ConvCommon {
 //   3 sigmoid (no residual), 4 2x2 stride-2 transposed-conv scatter (no residual), 5 fused 1x1 heads (conv.hip)
 inline int epilogue_variant(const ConvCommon& p, bool fused_heads) {
     return fused_heads ? 5 : p.out_mode == 1 ? 4 : (p.act == 2 ? 3 : (p.residual ? p.res_div : 0));
+}
+
+// Output pixel m -> (image b, row oy, column ox). Every layer of the 1024^2 / 832x1344 pyramids has power-of-two or small
+// sizes; with powers of two this is two shifts instead of two integer divisions (~40 VALU instructions each, and the
+// half-size-residual epilogue decodes 16 rows per accumulator tile).
+__device__ __forceinline__ void decode_pixel(const ConvCommon& p, int m, int& b, int& oy, int& ox) {
+    if (p.ow_shift >= 0) {
+        b = m >> p.ohw_shift;
+        const int rem = m & ((1 << p.ohw_shift) - 1);
+        oy = rem >> p.ow_shift;
+        ox = rem & ((1 << p.ow_shift) - 1);
+    } else {
+        const int ohw = p.OH * p.OW;
+        b = m / ohw;
+        const int rem = m - b * ohw;
+        oy = rem / p.OW;
+        ox = rem - oy * p.OW;
+    }
 }
 
 // XCD-aware tile order: XCD x (= blockIdx % 8) owns the M tiles [x*tiles_m/8, (x+1)*tiles_m/8) and walks N
@@ -59,8 +78,8 @@ __device__ __forceinline__ void row_setup(const ConvCommon& p, int m0, int r0, i
     for (int i = 0; i < PA; ++i) {
         const int m = m0 + r0 + RPP * i;
         if (m < p.M) {
-            const int b = m / ohw, rem = m - b * ohw;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            int b, oy, ox;
+            decode_pixel(p, m, b, oy, ox);
             a_iy[i] = oy * p.stride - p.pad_t;
             a_ix[i] = ox * p.stride - p.pad_l;
             a_off[i] = ((b * p.H + a_iy[i]) * p.W + a_ix[i]) * p.Cin;
@@ -114,8 +133,8 @@ __device__ __forceinline__ void load_residual(const ConvCommon& p, int m0, int n
                     rrow = ok ? static_cast<unsigned>(m) * row_bytes : OOB;
                 } else {  // residual at half size: (oy/2, ox/2) (FPN nearest-neighbour upsample + add)
                     const int mm = ok ? m : 0;
-                    const int b = mm / ohw, rem = mm - b * ohw;
-                    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                    int b, oy, ox;
+                    decode_pixel(p, mm, b, oy, ox);
                     rrow = ok ? static_cast<unsigned>((b * rh + (oy >> 1)) * rw + (ox >> 1)) * row_bytes : OOB;
                 }
 #pragma unroll
@@ -171,8 +190,8 @@ __device__ __forceinline__ void epilogue(const ConvCommon& p, f32x16 (&acc)[TM][
                 yrow[r] = ok ? static_cast<unsigned>(m) * row_bytes : OOB;
             } else {
                 const int mm = ok ? m : 0;
-                const int b = mm / ohw, rem = mm - b * ohw;
-                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                int b, oy, ox;
+                decode_pixel(p, mm, b, oy, ox);
                 yrow[r] = ok ? static_cast<unsigned>((b * 2 * p.OH + 2 * oy) * (2 * p.OW) + 2 * ox) * (row_bytes >> 2)
                              : OOB;
             }
@@ -229,6 +248,12 @@ inline int fill_common(ConvCommon& p, const char* who, const float* x, int batch
                            "%s: tensor too large (each tensor < 2^30 elements: 32-bit buffer byte offsets)", who);
     p.M = static_cast<int>(M);
     p.K = static_cast<int>(K);
+    {
+        auto log2_exact = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+        const int sw = log2_exact(p.OW), sh = log2_exact(p.OH);
+        p.ow_shift = (sw >= 0 && sh >= 0) ? sw : -1;
+        p.ohw_shift = (sw >= 0 && sh >= 0) ? sw + sh : -1;
+    }
     p.res_div = residual ? res_div : 1;
     p.act = activation;
     p.out_mode = out_mode;
