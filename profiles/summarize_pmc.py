@@ -11,16 +11,16 @@ import sys
 def step_sum(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     # every launch of the conv path: the direct implicit-GEMM kernel, the Winograd kernel and its k-blocking pre-pass
-    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm_f32", "conv3x3_wino", "kblock_kernel"))]
-    # a batch-8 step starts at the stem launch: the GENERIC (<..., true, RES>) instantiation with the largest grid
-    # the stem is the only launch of the GENERIC instantiation (template argument MODE = 1)
+    conv = [r for r in rows if any(k in r["Kernel_Name"] for k in ("conv_igemm_f32", "conv3x3_wino", "stem7x7", "kblock_kernel"))]
+    # a step starts at the stem launch (its own kernel, or the GENERIC instantiation of the direct kernel — template
+    # argument MODE = 1). bench.py also runs batch-1 passes (head calibration, the final statistics pass): the batch-8
+    # steps are the ones whose launches carry the most workgroups in total; the last of them is taken.
     stem_re = re.compile(r"conv_igemm_f32<\d+, \d+, \d+, \d+, \d+, (1|true), \d+>")
-    stems = [i for i, r in enumerate(conv) if stem_re.search(r["Kernel_Name"])]
-    big = max(int(conv[i]["Grid_Size"]) for i in stems)
-    starts = [i for i in stems if int(conv[i]["Grid_Size"]) == big]
-    i0 = starts[-1]
-    nxt = [i for i in stems if i > i0]
-    i1 = nxt[0] if nxt else len(conv)
+    stems = [i for i, r in enumerate(conv) if "stem7x7" in r["Kernel_Name"] or stem_re.search(r["Kernel_Name"])]
+    bounds = list(zip(stems, stems[1:] + [len(conv)]))
+    size = [sum(int(r["Grid_Size"]) for r in conv[a:b]) for a, b in bounds]
+    big = max(size)
+    i0, i1 = [bd for bd, sz in zip(bounds, size) if sz == big][-1]
     step = conv[i0:i1]
     return sum(float(r["Counter_Value"]) for r in step) * 1024.0, len(step)
 
