@@ -8,19 +8,24 @@
 //
 //   GEMM view   16 independent products, one per transform component xi: M_xi[T x N] = V_xi[T x C] U_xi[C x N],
 //               T = B*(H/2)*(W/2) tile positions, N = Cout, C = Cin. U is transformed once by wino_weights_kernel.
-//   tile        a workgroup owns 64 consecutive tile positions x 64 output channels; wave w owns transform row i = w
-//               (components 4w..4w+3) for the whole tile: 4 x (2 x 2) accumulator tiles = 256 registers per lane, so one
-//               wave per SIMD (__launch_bounds__(256, 1)) and one workgroup per CU (128 KB of LDS).
-//   layouts     both operands are k-blocked: x as [Cin/8][B*H*W][8] (kblock_kernel, one extra HBM pass over the input),
-//               U as [Cin/8][16][Cout][8], so that a k tile's loads use whole cache lines. In NHWC an 8-channel k
-//               tile is 32 bytes out of every 128-byte line and the kernel was bound by L2 -> L1 traffic (43 % MFMA).
-//   staging     per k tile of 8 input channels: waves 0-1 fetch their position's 4x4 patch (16 x 16-byte loads, zero
-//               padding by descriptor range check; neighbouring positions overlap, served by L1), apply B^T . B in
-//               registers and write the 16 components to LDS; waves 2-3 copy the 16 x 64 x 8 block of U.
+//   tile        a workgroup owns 64 consecutive tile positions x 64 output channels (128 KB of LDS: V and U, 16 component
+//               planes each, double-buffered; one workgroup per CU). Two kernels share everything but the wave layout:
+//               conv3x3_wino8_f32 (default): 512 threads, wave w owns components 2w, 2w+1 for the whole tile (128
+//               accumulator registers, two waves per SIMD), persistent workgroups;
+//               conv3x3_wino_f32 (MRCNN_WINO_WAVES=4): 256 threads, wave w owns components 4w..4w+3 (256 accumulator
+//               registers in AGPRs, one wave per SIMD).
+//   layouts     both operands are k-blocked: x as [Cin/8][B*H*W][8] (an NHWC input costs one kblock_kernel pass; producers
+//               can write it directly), U as [Cin/8][16][Cout][8], so that a k tile's loads use whole cache lines.
+//   staging     per k tile of 8 input channels a thread fetches a position's 4x4 patch for one channel pair (16 x 8-byte
+//               loads, zero padding by descriptor range check), applies B^T . B with packed adds and writes 16 components
+//               to LDS; the 16 x 64 x 8 block of U is copied through registers. No address arithmetic in the loop: fixed
+//               per-thread voffsets, the k tile's plane as scalar soffset, immediate LDS offsets — VALU instructions do
+//               not co-execute with this MFMA (tools/mfma_valu_probe.hip), every one of them costs MFMA time.
 //               Double-buffered, one barrier per k tile; loads for k tile t+2 are in flight during the MFMAs of t+1.
 //   MFMA        per component and k tile: two ds_read_b128 per operand (lane half h holds channels 4h..4h+3, the k
 //               permutation of conv.hip) feed sixteen MFMAs.
-//   epilogue    M A in registers, A^T (M A) across the four waves through LDS, affine, ReLU, 256-byte channel runs.
+//   epilogue    M A in registers, A^T (M A) across waves through LDS, affine, ReLU, 256-byte channel runs, NHWC and/or
+//               k-blocked.
 #include "conv_common.hpp"
 
 #include <cstdlib>
