@@ -13,10 +13,14 @@ fixed-shape detections. Workload at every N: BASELINE.json configs[2] per GPU (R
 synthetic 1024x1024) → weak scaling; N=8 is configs[3] (batch 64 sharded over 8 GPUs). Inputs are resident
 in HBM before the timed region. fp32 throughout (exact-fp32 MFMA).
 
-Prints ONE JSON line on rank 0 with the driver's contract fields plus `roofline` (the conv implicit-GEMM
-kernel: algorithmic conv FLOPs / its summed launch durations, HIP events on the launch stream, measured
-in an instrumented pass right after the timed region) and `cpu_baseline` (the CPU oracle's predict() on a
-bounded sample of the same workload, timed on this host's cores).
+Prints ONE JSON line on rank 0 with the driver's contract fields plus
+  `roofline`      the dominant kernel (conv3x3_wino8_f32): the multiply-adds it EXECUTES (2*M*N*K / 2.25 for Winograd
+                  F(2x2,3x3)) / its summed launch durations — HIP events on the launch stream around every conv
+                  launch, in an instrumented pass right after the timed region — against the fp32-MFMA peak, so
+                  `frac` <= 1; the convolution-equivalent (algorithmic) rate and the whole conv path sit beside it;
+  `roofline_ops`  RoIAlign (BASELINE config 2 shape + the pipeline's pyramid call; HBM-bound) and NMS 8 x 1000
+                  (latency-bound), measured in the same run after the timed region;
+  `cpu_baseline`  the CPU oracle's predict() on a bounded sample of the same workload, timed on this host's cores.
 """
 import argparse
 import contextlib
@@ -31,6 +35,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak (spec)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured float4 copy)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 
 
@@ -60,6 +65,140 @@ def calibrate_heads_(sd, make_net, images, windows):
         if done:
             break
     return net
+
+
+def conv_roofline(prof, args, H, W, modules):
+    """prof: ops.CONV_PROFILE rows (start event, end event, algorithmic FLOPs = 2*M*N*K of the convolution, (M,N,K),
+    algorithmic bytes = every operand/result tensor once, kernel tag) of `args.roofline_steps` steps."""
+    steps = args.roofline_steps
+    times = [r[0].elapsed_time(r[1]) for r in prof]   # ms
+    tag = [r[5] if len(r) > 5 else "direct" for r in prof]
+    # multiply-adds the MFMA pipe really performs: Winograd F(2x2,3x3) needs 16 products per 2x2 outputs and channel
+    # pair instead of 36
+    executed = [r[2] / 2.25 if t == "winograd" else r[2] for r, t in zip(prof, tag)]
+    peak = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else F16_MFMA_PEAK_TFLOPS
+
+    def agg(sel):
+        ms = sum(t for t, k in zip(times, sel) if k)
+        n = sum(sel)
+        if n == 0 or ms <= 0:
+            return None
+        ex = sum(e for e, k in zip(executed, sel) if k)
+        al = sum(r[2] for r, k in zip(prof, sel) if k)
+        return {"launches_per_step": n // steps, "ms_per_step": round(ms / steps, 3),
+                "avg_launch_us": round(ms / n * 1e3, 2),
+                "executed_tflops": round(ex / (ms * 1e-3) / 1e12, 2),
+                "executed_frac": round(ex / (ms * 1e-3) / 1e12 / peak, 4),
+                "algorithmic_tflops": round(al / (ms * 1e-3) / 1e12, 2),
+                "algorithmic_bytes_per_step": int(sum(r[4] for r, k in zip(prof, sel) if k) / steps)}
+
+    whole = agg([True] * len(prof))
+    by_tag = {t: agg([x == t for x in tag]) for t in sorted(set(tag))}
+    dominant = max(by_tag, key=lambda t: by_tag[t]["ms_per_step"])
+    dom = by_tag[dominant]
+    kernel_of = {"winograd": "conv3x3_wino8_f32", "direct": "conv_igemm_f32", "stem": "stem7x7_s2_f32",
+                 "f16": "conv_igemm_f16", "rpn_fused": "conv_igemm_f32<heads>", "bottleneck": "bottleneck_fused_f32"}
+    if args.dump_conv:
+        per = len(prof) // steps
+        rows = []
+        for i in range(per):
+            t = sum(times[i + r * per] for r in range(steps)) / steps
+            f, mnk = prof[i][2], prof[i][3]
+            rows.append({"i": i, "M": mnk[0], "N": mnk[1], "K": mnk[2], "ms": round(t, 4), "kernel": tag[i],
+                         "tflops": round(f / (t * 1e-3) / 1e12, 1),
+                         "executed_tflops": round(executed[i] / (t * 1e-3) / 1e12, 1), "gflop": round(f / 1e9, 2),
+                         "algorithmic_MB": round(prof[i][4] / 1e6, 1),
+                         "algorithmic_GBps": round(prof[i][4] / (t * 1e-3) / 1e9, 0)})
+        with open(args.dump_conv, "w") as fh:
+            json.dump(rows, fh, indent=0)
+    # HBM traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, summarised per kernel by
+    # profiles/summarize_pmc.py into a file that records the mode it was taken in; anything else → null
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            same = (tj.get("precision") == args.precision and tj.get("batch") == args.batch
+                    and tj.get("image") == [H, W] and tj.get("arch") == args.arch
+                    and tj.get("proposals") == args.proposals and tj.get("winograd") == bool(modules.WINOGRAD)
+                    and tj.get("stem_kernel") == bool(modules.STEM_KERNEL)
+                    and tj.get("fused_bottleneck") == bool(getattr(modules, "FUSED_BOTTLENECK", False)))
+            k = tj.get("per_kernel", {}).get(kernel_of.get(dominant, dominant))
+            if same and k and k.get("launches_per_step") == dom["launches_per_step"]:
+                traffic = k["hbm_bytes_per_step"]
+                traffic_src = "profiles/r02_hbm_traffic.json"
+        except (OSError, ValueError, KeyError):
+            traffic = None
+    return {"bound": "mfma", "kernel": kernel_of.get(dominant, dominant),
+            "achieved": dom["executed_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["executed_frac"],
+            "definition": "achieved = multiply-adds the kernel executes x 2 (Winograd F(2x2,3x3): 2*M*N*K / 2.25) / "
+                          "summed launch durations of that kernel in one step (HIP events on the launch stream); "
+                          "frac = achieved / fp32-MFMA peak",
+            "launches_per_step": dom["launches_per_step"], "ms_per_step": dom["ms_per_step"],
+            "avg_launch_us": dom["avg_launch_us"],
+            "algorithmic_tflops": dom["algorithmic_tflops"],
+            "algorithmic_speedup": round(dom["algorithmic_tflops"] / dom["executed_tflops"], 3),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_note": "HBM bytes of this kernel's launches of one step (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
+                            "separate passes; null when the committed profile was taken in another mode)",
+            "algorithmic_bytes": dom["algorithmic_bytes_per_step"],
+            "conv_path": dict(whole, conv_gflop_per_image=round(sum(r[2] for r in prof) / steps / args.batch / 1e9, 1)),
+            "by_kernel": by_tag}
+
+
+def op_rooflines(dev, ops):
+    """The two non-conv hot ops, HIP-event timed on the launch stream after the timed region:
+    RoIAlign is HBM-bound (compulsory bytes = output + every touched map once + boxes), NMS latency-bound."""
+    def timeit(fn, iters=30, warm=5):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3  # us
+
+    out = []
+    g = torch.Generator().manual_seed(1234)
+    # BASELINE configs[1]: 256 RoIs x 256 ch x 14x14 on P2 of one 1024^2 image, the NCHW drop-in entry point
+    fm = torch.randn(1, 256, 256, 256, generator=g).to(dev)
+    c = torch.rand(256, 2, generator=g)
+    hw = torch.rand(256, 2, generator=g) * 0.10 + 0.02
+    boxes = torch.cat([c - hw / 2, c + hw / 2], 1).clamp(0, 1).to(dev)
+    ind = torch.zeros(256, dtype=torch.int32, device=dev)
+    algo = 256 * 256 * 14 * 14 * 4 + fm.numel() * 4 + 256 * 20
+    us = timeit(lambda: ops.crop(fm, boxes, ind, 0.0, 14, 14))
+    out.append({"op": "crop_forward_nchw (configs[1]: 256 RoIs x 256 ch x 14x14 on P2)", "bound": "hbm",
+                "us": round(us, 2), "algorithmic_bytes": algo, "achieved": round(algo / us / 1e3, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / us / 1e3 / HBM_PEAK_GBS, 4)})
+    del fm
+    # the pipeline's classifier-head call: 8 images x 1000 RoIs x 7x7 over the four NHWC levels, one launch
+    fms = [torch.randn(8, 1024 // s, 1024 // s, 256, generator=g).to(dev) for s in (4, 8, 16, 32)]
+    c = torch.rand(8000, 2, generator=g)
+    hw = torch.exp(torch.rand(8000, 2, generator=g) * 3.4 - 3.9)
+    rois = torch.cat([c - hw / 2, c + hw / 2], 1).clamp(0, 1).to(dev)
+    us = timeit(lambda: ops.roi_align_pyramid(fms, rois, 7, 1024.0 * 1024.0, rois_per_image=1000))
+    algo = 8000 * 49 * 256 * 4 + sum(f.numel() for f in fms) * 4 + 8000 * 16
+    out.append({"op": "roi_align_pyramid_nhwc (8 x 1000 RoIs x 7x7, P2..P5)", "bound": "hbm", "us": round(us, 2),
+                "algorithmic_bytes": algo, "achieved": round(algo / us / 1e3, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(algo / us / 1e3 / HBM_PEAK_GBS, 4)})
+    del fms
+    # NMS, 8 segments x 1000 boxes, threshold 0.7 (the proposal stage of one step)
+    d8 = torch.cat([torch.rand(8, 1000, 2, generator=g) * 900, torch.zeros(8, 1000, 2),
+                    torch.rand(8, 1000, 1, generator=g)], 2)
+    d8[..., 2:4] = d8[..., :2] + torch.exp(torch.rand(8, 1000, 2, generator=g) * 2.5 + 2.0)
+    d8 = d8.to(dev)
+    us = timeit(lambda: ops.nms_batched(d8, 0.7))
+    _, cnt = ops.nms_batched(d8, 0.7)
+    out.append({"op": "nms_batched (8 segments x 1000 boxes, thr 0.7)", "bound": "latency", "us": round(us, 2),
+                "boxes_per_s": round(8000 / us * 1e6), "kept_mean": float(cnt.float().mean()),
+                "note": "moves 160 KB and does <= 4M IoU tests: neither HBM nor MFMA bound; 3 launches "
+                        "(sort, pair mask over the chip, scan), kernel boundary ~1.5 us each"})
+    return out
 
 
 def cpu_baseline(sd, cfg, n_images, seed):
@@ -111,7 +250,8 @@ def main():
     from maskrcnn_amd import dist as mdist
     rank, local, world = mdist.init_from_env()
     if world != args.gpus:
-        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch with "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local)
@@ -132,14 +272,17 @@ def main():
     windows = torch.tensor([[0.0, 0.0, float(H), float(W)]] * args.batch, device=dev)
 
     make_net = lambda s, prec=args.precision: MaskRCNNInference(s, cfg, dev, precision=prec)
-    # the head calibration uses ONE fixed image on every rank, so all ranks end up with identical (replicated) weights
+    # the head calibration uses ONE fixed batch on every rank, so all ranks end up with identical (replicated) weights;
+    # it has the workload's batch size so that every launch of the run (and of a rocprofv3 trace of it) has the
+    # workload's shape
     gc = torch.Generator().manual_seed(999)
-    cal = (torch.randint(0, 256, (1, H, W, 3), generator=gc).float() - mean).permute(0, 3, 1, 2).contiguous().to(dev)
-    net = calibrate_heads_(sd, make_net, cal, windows[:1])
+    cal = (torch.randint(0, 256, (args.batch, H, W, 3), generator=gc).float() - mean).permute(0, 3, 1, 2).contiguous()
+    net = calibrate_heads_(sd, make_net, cal.to(dev), windows)
+    del cal
 
     def step():
         det = net.predict(images, windows, with_masks=True)
-        return mdist.all_gather_detections(det.packed(), det.counts), det
+        return mdist.all_gather_detections(det.packed(), det.counts, global_batch=world * args.batch), det
 
     runner = step
     if args.graph:
@@ -169,67 +312,15 @@ def main():
 
     # ---- roofline pass: per-launch HIP events around every conv launch (same stream) ----------------
     roofline = None
+    roofline_ops = None
     if rank == 0 and args.roofline_steps > 0:
         ops.CONV_PROFILE = []
         for _ in range(args.roofline_steps):
             net.predict(images, windows, with_masks=True)
         torch.cuda.synchronize()
         prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-        times = [r[0].elapsed_time(r[1]) for r in prof]
-        ms = sum(times)
-        flops = sum(r[2] for r in prof)
-        algo_bytes = sum(r[4] for r in prof) / args.roofline_steps
-        achieved = flops / (ms * 1e-3) / 1e12
-        # Winograd launches execute 2.25x fewer multiply-adds than the convolution's algorithmic count
-        is_w = [len(r) > 5 and r[5] == "winograd" for r in prof]
-        ms_w = sum(t for t, w in zip(times, is_w) if w)
-        fl_w = sum(r[2] for r, w in zip(prof, is_w) if w)
-        executed = (flops - fl_w + fl_w / 2.25) / (ms * 1e-3) / 1e12
-        # HBM traffic of the conv launches of one step from the committed rocprofv3 PMC passes (separate runs of
-        # this same command, FETCH_SIZE / WRITE_SIZE, gfx950 corrections applied by profiles/summarize_pmc.py)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic.json")
-        if (args.precision == "f32" and args.batch == 8 and (H, W) == (1024, 1024) and args.arch == "resnet50"
-                and os.path.exists(tpath)):
-            try:
-                with open(tpath) as fh:
-                    traffic = json.load(fh).get("hbm_bytes_per_step")
-            except (OSError, ValueError):
-                traffic = None
-        if args.dump_conv:
-            per = len(prof) // args.roofline_steps
-            rows = []
-            for i in range(per):
-                t = sum(prof[i + r * per][0].elapsed_time(prof[i + r * per][1])
-                        for r in range(args.roofline_steps)) / args.roofline_steps
-                f, mnk = prof[i][2], prof[i][3]
-                rows.append({"i": i, "M": mnk[0], "N": mnk[1], "K": mnk[2], "ms": round(t, 4),
-                             "kernel": prof[i][5] if len(prof[i]) > 5 else "direct",
-                             "tflops": round(f / (t * 1e-3) / 1e12, 1), "gflop": round(f / 1e9, 2)})
-            with open(args.dump_conv, "w") as fh:
-                json.dump(rows, fh, indent=0)
-        peak = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else F16_MFMA_PEAK_TFLOPS
-        kname = "conv_igemm_f16" if args.precision != "f32" else (
-            "conv3x3_wino_f32 + conv_igemm_f32" if ms_w > 0 else "conv_igemm_f32")
-        roofline = {"bound": "mfma", "kernel": kname + " (all conv/GEMM launches of one step)",
-                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4),
-                    "note": "achieved = ALGORITHMIC conv FLOPs (2*M*N*K of every layer) / summed launch time; the "
-                            "Winograd F(2x2,3x3) launches execute 2.25x fewer multiply-adds than that, which is how "
-                            "frac can exceed 1. executed_* count the multiply-adds the MFMA pipe really performs.",
-                    "executed_tflops": round(executed, 2), "executed_frac": round(executed / peak, 4),
-                    "winograd": {"ms_per_step": round(ms_w / args.roofline_steps, 3),
-                                 "algorithmic_tflops": round(fl_w / (ms_w * 1e-3) / 1e12, 1) if ms_w else None,
-                                 "executed_tflops": round(fl_w / 2.25 / (ms_w * 1e-3) / 1e12, 1) if ms_w else None},
-                    "direct": {"ms_per_step": round((ms - ms_w) / args.roofline_steps, 3),
-                               "tflops": round((flops - fl_w) / ((ms - ms_w) * 1e-3) / 1e12, 1) if ms > ms_w else None},
-                    "traffic": traffic,
-                    "traffic_note": "HBM bytes of all conv launches of one step (rocprofv3 --pmc, committed under "
-                                    "profiles/); algorithmic bytes (each tensor once) alongside",
-                    "algorithmic_bytes_per_step": int(algo_bytes),
-                    "launches_per_step": len(prof) // args.roofline_steps,
-                    "conv_gflop_per_image": round(flops / args.roofline_steps / args.batch / 1e9, 1),
-                    "conv_ms_per_step": round(ms / args.roofline_steps, 3)}
+        roofline = conv_roofline(prof, args, H, W, modules)
+        roofline_ops = op_rooflines(dev, ops)
 
     # ---- optional second contraction mode, same weights/inputs/steps (every rank takes part) ----------
     alt = None
@@ -238,7 +329,7 @@ def main():
 
         def step_alt():
             d = net_alt.predict(images, windows, with_masks=True)
-            return mdist.all_gather_detections(d.packed(), d.counts)
+            return mdist.all_gather_detections(d.packed(), d.counts, global_batch=world * args.batch)
         for _ in range(args.warmup):
             step_alt()
         mdist.barrier()
@@ -266,12 +357,15 @@ def main():
             alt["conv_ms_per_step"] = round(ms / args.roofline_steps, 3)
         del net_alt
 
-    cpu = None
+    cpu, cpu_failed = None, False
     if rank == 0 and world == 1 and args.cpu_images > 0:
         try:
             cpu = cpu_baseline(sd, cfg, args.cpu_images, seed=1000)
-        except Exception as e:  # the oracle is test infrastructure; never fail the GPU number on it
-            log(f"[bench] cpu_baseline skipped: {e!r}")
+        except Exception as e:  # keep the GPU number, but never report a silent null: the error is in the line
+            log(f"[bench] ERROR: cpu_baseline failed: {e!r}")
+            cpu = {"value": None, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": "FAILED", "error": repr(e)}
+            cpu_failed = True
 
     if rank == 0:
         line = {
@@ -294,15 +388,17 @@ def main():
                                    if (args.precision == "f32" and modules.WINOGRAD) else "direct implicit GEMM"),
                        "mean_valid_proposals": round(float(net_last_counts(net, images, windows)), 1),
                        "mean_detections": round(float(det.counts.float().mean().item()), 1)},
-            "roofline": roofline, "cpu_baseline": cpu, "alt_precision": alt,
+            "roofline": roofline, "roofline_ops": roofline_ops, "cpu_baseline": cpu, "alt_precision": alt,
         }
         print(json.dumps(line), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    if cpu_failed:
+        raise SystemExit(3)
 
 
 def net_last_counts(net, images, windows):
-    _, mid = net.predict(images[:1], windows[:1], with_masks=False, return_intermediates=True)
+    _, mid = net.predict(images, windows, with_masks=False, return_intermediates=True)
     return mid["roi_counts"].float().mean().item()
 
 

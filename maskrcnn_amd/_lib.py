@@ -88,6 +88,43 @@ def declared_symbols(header: str = HEADER) -> list[str]:
     return sorted(set(re.findall(r"\b(mrcnn_[a-z0-9_]+)\s*\(", text)) - {"mrcnn_stream_t"})
 
 
+def header_abi_version(header: str = HEADER) -> int:
+    m = re.search(r"^#define\s+MRCNN_ABI_VERSION\s+(\d+)", open(header).read(), flags=re.M)
+    if not m:
+        raise ImportError(f"{header}: MRCNN_ABI_VERSION not found")
+    return int(m.group(1))
+
+
+_CTYPE_OF = {"int": ctypes.c_int, "int32_t": c_i32, "int64_t": c_i64, "float": c_f32, "double": ctypes.c_double,
+             "size_t": ctypes.c_size_t, "mrcnn_stream_t": c_vp}
+
+
+def header_prototypes(header: str = HEADER) -> dict:
+    """name -> (restype, [argtypes]) as ctypes, parsed from the header's prototypes: pointers to anything are
+    c_void_p except the small host-side arrays the bindings pass by ctypes array (const float* const fm[4],
+    const int32_t hw[5], const float std_dev[4], const double mean[3]: POINTER(elem))."""
+    text = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
+    out = {}
+    for res, name, args in re.findall(r"^\s*([A-Za-z_][\w\s\*]*?)\s*\b(mrcnn_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text,
+                                      flags=re.M):
+        res = " ".join(res.split())
+        restype = ctypes.c_char_p if res == "const char*" else _CTYPE_OF[res]
+        argtypes = []
+        for a in [x.strip() for x in args.split(",")]:
+            if a in ("void", ""):
+                continue
+            arr = re.match(r"^(?:const\s+)?(\w+)\s*(\*?)\s*(?:const\s+)?\w+\s*\[\d*\]$", a)
+            if arr:  # host array parameter
+                base = c_vp if arr.group(2) else _CTYPE_OF[arr.group(1)]
+                argtypes.append(ctypes.POINTER(base))
+            elif "*" in a:
+                argtypes.append(c_vp)
+            else:
+                argtypes.append(_CTYPE_OF[a.replace("const ", "").split()[0]])
+        out[name] = (restype, argtypes)
+    return out
+
+
 class MaskrcnnHipError(RuntimeError):
     pass
 
@@ -105,6 +142,12 @@ def _load() -> ctypes.CDLL:
         except AttributeError as e:
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype, fn.argtypes = res, args
+    # a stale .so with the same symbol names but older argument lists would be called with mismatched ctypes
+    # arguments (memory corruption / GPU fault): MRCNN_ABI_VERSION is bumped on every signature change
+    built, want = int(lib.mrcnn_abi_version()), header_abi_version()
+    if built != want:
+        raise ImportError(f"{LIB_PATH} was built for ABI version {built}, include/maskrcnn_hip.h declares {want}: "
+                          "rebuild it (python maskrcnn_amd/build.py --force)")
     return lib
 
 

@@ -35,5 +35,16 @@ class InferenceConfig:
     def __post_init__(self):
         if self.image_height % 64 or self.image_width % 64:  # model.py:978-983
             raise ValueError("Image size must be dividable by 2 at least 6 times")
+        # kernel limits, checked here rather than deep inside the first predict(): the LDS-resident sorts of
+        # csrc/nms.hip and csrc/select.hip hold at most 4096 boxes per image (mrcnn_nms_max_boxes())
+        cap = 4096
+        if not 1 <= self.pre_nms_limit <= cap:
+            raise ValueError(f"pre_nms_limit={self.pre_nms_limit}: the NMS / top-k kernels take 1..{cap} boxes per image")
+        if not 1 <= self.proposal_count <= cap:
+            raise ValueError(f"proposal_count={self.proposal_count}: must be in 1..{cap}")
+        if not 1 <= self.detection_max_instances <= self.proposal_count:
+            raise ValueError(f"detection_max_instances={self.detection_max_instances}: must be in 1..proposal_count")
+        if self.backbone not in ("resnet50", "resnet101"):
+            raise ValueError(f"backbone={self.backbone!r}: resnet50 or resnet101 (model.py:217-219)")
         self.backbone_shapes = [(int(math.ceil(self.image_height / s)), int(math.ceil(self.image_width / s)))
                                 for s in self.backbone_strides]

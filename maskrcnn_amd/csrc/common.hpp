@@ -25,6 +25,14 @@ inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// Per-device launch state. A process may drive several GPUs (one torch device guard per call); nothing below may be
+// cached per process. Both helpers are keyed by hipGetDevice() of the calling thread.
+//   ensure_dynamic_lds: hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size) — kernels that
+//                       use more than 64 KB of dynamic LDS need it on EVERY device they are launched on;
+//   device_cu_count:    multiProcessorCount of the current device (persistent-grid sizing), 0 on failure.
+int ensure_dynamic_lds(const void* kernel, size_t lds_bytes, const char* who);
+int device_cu_count();
+
 }  // namespace mrcnn
 
 #define MRCNN_REQUIRE(cond, ...)                                              \

@@ -332,19 +332,9 @@ int launch_conv(ConvParams p, int mode, hipStream_t stream) {  // mode: 0 aligne
     const long long grid = tile_grid(p);
     if (grid > 0x7fffffffLL) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: grid too large");
     constexpr size_t lds = conv_lds_bytes<BM, BN, BK>();
-    auto set_attr = [&](const void* f, bool& done) -> int {  // once per kernel instantiation
-        if (done || lds <= 64 * 1024) return MRCNN_OK;
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(lds));
-        if (e != hipSuccess)
-            return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        done = true;
-        return MRCNN_OK;
-    };
     const int res = epilogue_variant(p, p.w_head != nullptr);
-    static bool attr_done[3][6] = {};
     auto go = [&](auto kern) -> int {
-        if (int rc = set_attr(reinterpret_cast<const void*>(kern), attr_done[mode][res])) return rc;
+        if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "conv")) return rc;
         hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
         return MRCNN_OK;
     };

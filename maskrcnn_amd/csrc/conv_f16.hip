@@ -268,13 +268,7 @@ int launch(ConvParamsH p, bool generic, hipStream_t stream) {
     constexpr size_t lds = lds_bytes<BM, BN, PRODUCTS>();
     const int res = epilogue_variant(p, false);
     auto go = [&](auto kern) -> int {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               static_cast<int>(lds));
-            if (e != hipSuccess)
-                return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv_f16: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        }
+        if (int rc2 = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "conv_f16")) return rc2;
         hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
         return MRCNN_OK;
     };

@@ -700,28 +700,15 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
     p.y_bytes = static_cast<unsigned>(4LL * px * cout);
     const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
     MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd: grid too large");
-    static bool attr_done = false;
-    if (!attr_done) {
-        for (const void* f : {reinterpret_cast<const void*>(conv3x3_wino_f32),
-                              reinterpret_cast<const void*>(conv3x3_wino8_f32)}) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(WINO_LDS));
-            if (e != hipSuccess)
-                return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        }
-        attr_done = true;
-    }
+    for (const void* f : {reinterpret_cast<const void*>(conv3x3_wino_f32), reinterpret_cast<const void*>(conv3x3_wino8_f32)})
+        if (int rc = mrcnn::ensure_dynamic_lds(f, WINO_LDS, "conv3x3_winograd")) return rc;
     static const bool four_waves = getenv("MRCNN_WINO_WAVES") && atoi(getenv("MRCNN_WINO_WAVES")) == 4;
     if (four_waves)
         hipLaunchKernelGGL(conv3x3_wino_f32, dim3(static_cast<unsigned>(grid)), dim3(256), WINO_LDS, st, p);
     else {
-        static int num_cu = 0;
-        if (num_cu == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-                return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd: cannot query the device");
-            num_cu = prop.multiProcessorCount >= 8 ? (prop.multiProcessorCount / 8) * 8 : 8;
-        }
+        const int cus = mrcnn::device_cu_count();
+        if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd: cannot query the device");
+        const int num_cu = cus >= 8 ? (cus / 8) * 8 : 8;
         static const bool persistent = !(getenv("MRCNN_WINO_PERSISTENT") && atoi(getenv("MRCNN_WINO_PERSISTENT")) == 0);
         const long long launch = (persistent && grid > num_cu) ? num_cu : grid;
         hipLaunchKernelGGL(conv3x3_wino8_f32, dim3(static_cast<unsigned>(launch)), dim3(512), WINO_LDS, st, p);

@@ -474,13 +474,7 @@ int launch(const float* dets, int32_t S, int64_t n_max, int64_t seg_stride, int6
            int64_t* keep_out, int32_t* counts_out, hipStream_t stream) {
     constexpr size_t lds = nms_lds_bytes<CAP>();
     auto kern = nms_kernel<CAP, T>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(lds));
-        if (e != hipSuccess)
-            return mrcnn::fail(MRCNN_ERR_LAUNCH, "nms: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    }
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "nms")) return rc;
     hipLaunchKernelGGL(kern, dim3(S), dim3(T), lds, stream, dets, n_max, seg_stride, row_stride,
                        col_stride, seg_counts, class_ids, thr, keep_out, counts_out);
     return mrcnn::check_launch("nms_kernel");
@@ -563,13 +557,7 @@ extern "C" int mrcnn_nms_batched_f32(const float* dets, int32_t num_segments, in
         const size_t lds_full = sizeof(u64) * ws.np * ws.nb + tail;
         if (lds_full <= 150 * 1024) {
             auto k = nms_scan_kernel<true>;
-            if (lds_full > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   static_cast<int>(lds_full));
-                if (e != hipSuccess)
-                    return mrcnn::fail(MRCNN_ERR_LAUNCH, "nms: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            }
+            if ((rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds_full, "nms"))) return rc;
             hipLaunchKernelGGL(k, dim3(num_segments), dim3(256), lds_full, s, ws, n_max, seg_counts, keep_out,
                                counts_out);
         } else {

@@ -145,19 +145,9 @@ extern "C" int mrcnn_stem_conv7x7_s2_nhwc_f32(const float* x, int32_t batch, int
     p.act = activation;
     p.x_bytes = static_cast<unsigned>(16LL * batch * height * width);
     p.y_bytes = static_cast<unsigned>(256LL * batch * p.OH * p.OW);
-    static bool attr_done = false;
-    static int num_cu = 0;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem7x7_s2_f32),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(STEM_LDS));
-        if (e != hipSuccess) return mrcnn::fail(MRCNN_ERR_LAUNCH, "stem: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            return mrcnn::fail(MRCNN_ERR_LAUNCH, "stem: cannot query the device");
-        num_cu = prop.multiProcessorCount;
-        attr_done = true;
-    }
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(stem7x7_s2_f32), STEM_LDS, "stem")) return rc;
+    const int num_cu = mrcnn::device_cu_count();
+    if (num_cu <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "stem: cannot query the device");
     const int grid = p.tiles < 2 * num_cu ? p.tiles : 2 * num_cu;  // persistent: two workgroups per CU
     hipLaunchKernelGGL(stem7x7_s2_f32, dim3(grid), dim3(256), STEM_LDS, mrcnn::as_stream(stream), p);
     return mrcnn::check_launch("stem7x7_s2_f32");

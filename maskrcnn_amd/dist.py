@@ -3,8 +3,8 @@
 One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm; "gloo" for CPU tests).
 Images are independent (BatchNorm is frozen, model.py:1009-1016,1142), so the batch shards contiguously
 across ranks with replicated weights and NO collective on the data path. The single exchange step is an
-all-gather of the fixed-shape detections block [B_local, D, 6] fp32 + int32 counts (9.6 KB per rank at
-B_local = 8, D = 50): latency-bound, one call per batch, never bucketed with anything else.
+all-gather of the fixed-shape detections block [B_local, D+1, 6] fp32 (detections + a row carrying the count;
+9.8 KB per rank at B_local = 8, D = 50): latency-bound, ONE collective per batch, never bucketed with anything else.
 """
 from __future__ import annotations
 
@@ -41,19 +41,36 @@ def shard_range(global_batch: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_detections(packed: torch.Tensor, counts: torch.Tensor):
-    """packed [B_local, D, 6] fp32, counts [B_local] int32 → ([world*B_local, D, 6], [world*B_local]),
-    rank-major (== global image order under shard_range with equal shards). Identity at world 1."""
+def all_gather_detections(packed: torch.Tensor, counts: torch.Tensor, global_batch: int | None = None):
+    """packed [B_local, D, 6] fp32, counts [B_local] int32 → ([G, D, 6], [G] int32) in global image order
+    (rank-major under shard_range). Identity at world 1.
+
+    ONE collective per step: the counts ride in the same block as an extra row ([B, D+1, 6], row D = (count, 0...);
+    exact in fp32 for counts < 2^24). `global_batch` (G) tells how the batch was sharded: ranks then own
+    shard_range(G, r, world) images, which differ by one image when G % world != 0 — all_gather_into_tensor needs
+    identical shapes, so every rank pads its block to ceil(G / world) images (count 0) and the padding is stripped
+    after the gather. Without `global_batch` every rank must hold the same B_local (G = world * B_local)."""
     if not _collectives_on():
         return packed, counts
-    world = dist.get_world_size()
-    packed = packed.contiguous()
-    counts = counts.contiguous()
-    out_p = packed.new_empty((world * packed.size(0),) + tuple(packed.shape[1:]))
-    out_c = counts.new_empty(world * counts.size(0))
-    dist.all_gather_into_tensor(out_p, packed)
-    dist.all_gather_into_tensor(out_c, counts)
-    return out_p, out_c
+    world, rank = dist.get_world_size(), dist.get_rank()
+    b, d = packed.size(0), packed.size(1)
+    if global_batch is None:
+        sizes = [b] * world
+    else:
+        sizes = [hi - lo for lo, hi in (shard_range(global_batch, r, world) for r in range(world))]
+    if sizes[rank] != b or counts.numel() != b or packed.size(2) != 6:
+        raise RuntimeError(f"all_gather_detections: rank {rank} holds {b} images (counts {counts.numel()}), "
+                           f"shard_range({global_batch}, {rank}, {world}) says {sizes[rank]}")
+    b_max = max(sizes)
+    block = packed.new_zeros(b_max, d + 1, 6)
+    block[:b, :d] = packed
+    block[:b, d, 0] = counts.to(packed.dtype)
+    out = packed.new_empty(world * b_max, d + 1, 6)
+    dist.all_gather_into_tensor(out, block)
+    if min(sizes) != b_max:  # strip the padding rows (host-side index list: no device synchronisation)
+        rows = [r * b_max + i for r in range(world) for i in range(sizes[r])]
+        out = out.index_select(0, torch.tensor(rows, dtype=torch.int64, device=out.device))
+    return out[:, :d].contiguous(), out[:, d, 0].to(torch.int32)
 
 
 def _collectives_on() -> bool:

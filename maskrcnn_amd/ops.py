@@ -14,6 +14,7 @@ GPU support", nms.h:24): this build is GPU-only by design.
 from __future__ import annotations
 
 import ctypes
+import functools
 
 import torch
 
@@ -30,6 +31,36 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _tensors(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _tensors(o)
+
+
+def _on_device(fn):
+    """Device guard for a binding: every GPU tensor argument must live on ONE device, and the call — output
+    allocation, torch.cuda.current_stream() and the kernel launch — runs with that device current, whatever the
+    caller's current device is (a launch on cuda:0's stream against cuda:1's pointers is a memory fault, or silent
+    peer traffic over xGMI)."""
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        dev = None
+        for t in _tensors(args + tuple(kwargs.values())):
+            if t.is_cuda:
+                if dev is None:
+                    dev = t.device
+                elif t.device != dev:
+                    raise RuntimeError(f"maskrcnn_amd.{fn.__name__}: tensor arguments on different devices "
+                                       f"({dev} and {t.device})")
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return guarded
+
+
 def _need_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -40,6 +71,7 @@ def _need_gpu(*tensors):
 # --------------------------------------------------------------------------------------------------
 # NMS
 # --------------------------------------------------------------------------------------------------
+@_on_device
 def nms_batched(dets: torch.Tensor, threshold: float, seg_counts: torch.Tensor | None = None,
                 class_ids: torch.Tensor | None = None, use_workspace: bool = True):
     """dets [S, N, 5] fp32 (any strides) → (keep int64 [S, N] ascending indices padded with -1,
@@ -96,6 +128,7 @@ def _check_crop_inputs(image, boxes, box_index):
         raise RuntimeError("crop: image [B,C,H,W], boxes [N,4], box_index [N] expected")
 
 
+@_on_device
 def crop(image: torch.Tensor, boxes: torch.Tensor, box_index: torch.Tensor,
          extrapolation_value: float, crop_height: int, crop_width: int) -> torch.Tensor:
     """Functional form: returns a fresh [N, C, crop_height, crop_width] tensor."""
@@ -110,6 +143,7 @@ def crop(image: torch.Tensor, boxes: torch.Tensor, box_index: torch.Tensor,
     return crops
 
 
+@_on_device
 def _crop_forward(image, boxes, box_index, extrapolation_value, crop_height, crop_width, crops):
     """Out-param form of crop.h:14-22: `crops` is resized to [N,C,h,w] and overwritten
     (crop_cpu.cpp:141-143)."""
@@ -126,6 +160,7 @@ def _crop_forward(image, boxes, box_index, extrapolation_value, crop_height, cro
                                      int(crop_height), int(crop_width), crops.data_ptr(), _stream()))
 
 
+@_on_device
 def _crop_backward(grads, boxes, box_index, grads_image):
     _need_gpu(grads, boxes, box_index, grads_image)
     if grads.dtype != torch.float32 or boxes.dtype != torch.float32 or grads_image.dtype != torch.float32:
@@ -156,6 +191,7 @@ _LIB.impl("crop", crop, "CUDA")
 _LIB.impl("crop", lambda image, *a: _need_gpu(image), "CPU")
 
 
+@_on_device
 def roi_align_pyramid(feature_maps, rois: torch.Tensor, pool: int, image_area: float,
                       rois_per_image: int | None = None, roi_batch: torch.Tensor | None = None,
                       return_levels: bool = False):
@@ -191,11 +227,12 @@ __all__ = ["nms_batched", "crop", "roi_align_pyramid", "MaskrcnnHipError"]
 # conv + BN + ReLU (+ residual), channels-last
 # --------------------------------------------------------------------------------------------------
 # When set to a list, every conv launch appends (start_event, end_event, algorithmic_flops, (M, N, K),
-# algorithmic_bytes = each operand/result tensor once) —
+# algorithmic_bytes = each operand/result tensor once, kernel tag) —
 # HIP events recorded on the launch stream; used by bench.py's roofline pass, never in the timed region.
 CONV_PROFILE: list | None = None
 
 
+@_on_device
 def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
                 shift: torch.Tensor | None, stride: int = 1, pad=(0, 0, 0, 0), relu: bool = False,
                 residual: torch.Tensor | None = None, res_div: int = 1,
@@ -246,7 +283,7 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
         e1.record()
         m, k = b * oh * ow, kh * kw * (algo_cin or cin)  # algorithmic: 2*MACs of the un-padded conv
         nbytes = 4 * (x.numel() + w.numel() + out.numel() + (residual.numel() if residual is not None else 0))
-        prof.append((e0, e1, 2.0 * m * k * cout, (m, cout, k), nbytes))
+        prof.append((e0, e1, 2.0 * m * k * cout, (m, cout, k), nbytes, "direct"))
     return out
 
 
@@ -257,6 +294,7 @@ def split_f16(w: torch.Tensor):
     return hi.contiguous(), lo.contiguous()
 
 
+@_on_device
 def conv_bn_act_f16mfma(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor | None,
                         scale: torch.Tensor | None, shift: torch.Tensor | None, stride: int = 1,
                         pad=(0, 0, 0, 0), relu: bool = False, residual: torch.Tensor | None = None,
@@ -289,7 +327,7 @@ def conv_bn_act_f16mfma(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor 
         m, k = b * oh * ow, kh * kw * (algo_cin or cin)
         nbytes = 4 * (x.numel() + out.numel() + (residual.numel() if residual is not None else 0)) + \
             2 * w_hi.numel() * (2 if products == 3 else 1)
-        prof.append((e0, e1, 2.0 * m * k * cout, (m, cout, k), nbytes))
+        prof.append((e0, e1, 2.0 * m * k * cout, (m, cout, k), nbytes, "f16"))
     return out
 
 
@@ -317,6 +355,7 @@ def same_pad(size_a: int, size_b: int, kernel: int, stride: int):
     return (b_lo, a_lo, pad_b - b_lo, pad_a - a_lo)
 
 
+@_on_device
 def maxpool(x: torch.Tensor, kernel: int, stride: int, pad=(0, 0, 0, 0)) -> torch.Tensor:
     """Zero-padded max-pool on NHWC fp32 (stem pool: kernel 3, stride 2, pad = same_pad(H, W, 3, 2);
     P6: kernel 1, stride 2)."""
@@ -332,6 +371,7 @@ def maxpool(x: torch.Tensor, kernel: int, stride: int, pad=(0, 0, 0, 0)) -> torc
     return y
 
 
+@_on_device
 def nchw_to_nhwc(x: torch.Tensor, channels_padded: int | None = None) -> torch.Tensor:
     _need_gpu(x)
     assert x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 4
@@ -342,6 +382,7 @@ def nchw_to_nhwc(x: torch.Tensor, channels_padded: int | None = None) -> torch.T
     return y
 
 
+@_on_device
 def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
     _need_gpu(x)
     assert x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 4
@@ -371,6 +412,7 @@ _LIB.impl("bottleneck_forward", lambda x, *a: _need_gpu(x), "CPU")
 __all__ += ["conv_bn_act", "conv_bn_act_f16mfma", "split_f16", "same_pad", "maxpool", "nchw_to_nhwc", "nhwc_to_nchw", "bottleneck_forward"]
 
 
+@_on_device
 def rpn_scores_deltas(heads):
     """heads: 5 contiguous fp32 NHWC tensors [B,H_l,W_l,18] (fused RPN head outputs, P2..P6) →
     (fg scores [B,A], deltas [B,A,4]) in the reference's anchor order. One launch."""
@@ -389,6 +431,7 @@ def rpn_scores_deltas(heads):
     return scores, deltas
 
 
+@_on_device
 def proposal_decode(anchors, deltas, order, top_scores, std_dev, image_height, image_width):
     """anchors [A,4], deltas [B,A,4], order int64 [B,K], top_scores [B,K] → dets [B,K,5]: refined (data.py:124),
     clipped (data.py:86) boxes + score. One launch."""
@@ -407,6 +450,7 @@ def proposal_decode(anchors, deltas, order, top_scores, std_dev, image_height, i
 __all__ += ["rpn_scores_deltas", "proposal_decode"]
 
 
+@_on_device
 def detection_decode(logits, bbox, rois, roi_counts, windows, std_dev, image_height, image_width,
                      min_confidence: float = 0.0):
     """First half of mrn_refine (model.py:1405-1443), one launch. logits [B*P,C] (row-strided view allowed),
@@ -431,6 +475,7 @@ def detection_decode(logits, bbox, rois, roi_counts, windows, std_dev, image_hei
 __all__ += ["detection_decode"]
 
 
+@_on_device
 def topk_desc(scores: torch.Tensor, k: int):
     """scores fp32 [B,N] → (top [B,k], order int64 [B,k]): descending, ties by ascending index (model.py:1345-1350)."""
     _need_gpu(scores)
@@ -445,6 +490,7 @@ def topk_desc(scores: torch.Tensor, k: int):
     return top, order
 
 
+@_on_device
 def proposal_select(dets, keep, keep_counts, proposal_count: int, image_height, image_width):
     """dets [B,K,5], NMS keep int64 [B,K] + counts int32 [B] → (rois [B,P,4] normalised, zero-padded; counts int32 [B])
     — keep[:proposal_count], gather, normalise (model.py:1366-1374) in one launch."""
@@ -460,6 +506,7 @@ def proposal_select(dets, keep, keep_counts, proposal_count: int, image_height, 
     return rois, counts
 
 
+@_on_device
 def detection_select(dets, nms_class_ids, class_ids, keep, keep_counts, max_instances: int, image_height,
                      image_width):
     """Tail of mrn_refine (model.py:1475-1487) in one launch → (class_ids int64 [B,D], scores [B,D], boxes [B,D,4]
@@ -485,6 +532,7 @@ def detection_select(dets, nms_class_ids, class_ids, keep, keep_counts, max_inst
 __all__ += ["topk_desc", "proposal_select", "detection_select"]
 
 
+@_on_device
 def deconv2x2(x: torch.Tensor, w, bias4: torch.Tensor, activation: int = 0, products: int = 0) -> torch.Tensor:
     """2x2 stride-2 transposed conv + bias + activation (Mask.forward's deconv, model.py:864,906-912) as one GEMM
     scattering into [B,2H,2W,Cout]. w: fp32 [4*Cout,1,1,Cin] (products = 0) or the (w_hi, w_lo) fp16 planes of it
@@ -513,13 +561,15 @@ def deconv2x2(x: torch.Tensor, w, bias4: torch.Tensor, activation: int = 0, prod
         e1.record()
         m = b * h * wd
         prof.append((e0, e1, 2.0 * m * cin * 4 * cout, (m, 4 * cout, cin),
-                     4 * (x.numel() + y.numel()) + (4 if products == 0 else 2 * (2 if products == 3 else 1)) * w0.numel()))
+                     4 * (x.numel() + y.numel()) + (4 if products == 0 else 2 * (2 if products == 3 else 1)) * w0.numel(),
+                     "direct" if products == 0 else "f16"))
     return y
 
 
 __all__ += ["deconv2x2"]
 
 
+@_on_device
 def rpn_level_fused(x, w_shared, b_shared, w_head32, b_head, head_n: int = 18) -> torch.Tensor:
     """RPN.forward on one level (model.py:609-649) with the shared 512-channel activation kept on chip:
     x [B,H,W,Cin] NHWC → [B,H,W,head_n] (class logits then box deltas). fp32 MFMA path."""
@@ -543,7 +593,7 @@ def rpn_level_fused(x, w_shared, b_shared, w_head32, b_head, head_n: int = 18) -
         m = b * h * wd
         flops = 2.0 * m * (9 * cin * cout + cout * head_n)  # shared 3x3 conv + both 1x1 heads
         prof.append((e0, e1, flops, (m, cout, 9 * cin),
-                     4 * (x.numel() + w_shared.numel() + cout * head_n + y.numel())))
+                     4 * (x.numel() + w_shared.numel() + cout * head_n + y.numel()), "rpn_fused"))
     return y
 
 
@@ -553,6 +603,7 @@ __all__ += ["rpn_level_fused"]
 # --------------------------------------------------------------------------------------------------
 # image pre-/post-processing (Pillow-exact 8-bit bilinear resample)
 # --------------------------------------------------------------------------------------------------
+@_on_device
 def resize_bilinear_u8(image: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
     """uint8 [H,W], [H,W,C] (C <= 4) or a batch [N,H,W] of single-channel images (rows contiguous; image and row
     strides free, so a cropped view needs no copy) → uint8 of the same rank at out_h x out_w; every image
@@ -589,6 +640,7 @@ def resize_bilinear_u8(image: torch.Tensor, out_h: int, out_w: int) -> torch.Ten
     return out
 
 
+@_on_device
 def mold_image_u8(image: torch.Tensor, new_h: int, new_w: int, top: int, left: int, out: torch.Tensor,
                   mean_pixel) -> None:
     """uint8 RGB [h,w,3] → out fp32 [3,H,W] (one slot of the batch): resize to new_h x new_w, paste at (top,left) of a
@@ -608,6 +660,7 @@ def mold_image_u8(image: torch.Tensor, new_h: int, new_w: int, top: int, left: i
                                   out.data_ptr(), _ptr(ws), nbytes, _stream()))
 
 
+@_on_device
 def paste_masks(masks: torch.Tensor, class_ids: torch.Tensor, boxes: torch.Tensor, height: int, width: int,
                 channels_last: bool, as_l8: bool = False) -> torch.Tensor:
     """datalib.full_masks (data.py:287-314) for N detections in one launch → bool [N,height,width] (as_l8: the same
@@ -636,6 +689,7 @@ def paste_masks(masks: torch.Tensor, class_ids: torch.Tensor, boxes: torch.Tenso
 # --------------------------------------------------------------------------------------------------
 # Winograd F(2x2,3x3) 3x3 stride-1 SAME conv (csrc/conv_wino.hip)
 # --------------------------------------------------------------------------------------------------
+@_on_device
 def winograd_weights(w_ohwi: torch.Tensor) -> torch.Tensor:
     """[Cout,3,3,Cin] fp32 → the transformed filter G g G^T (evaluated in double), 16*Cout*Cin floats in the
     kernel's k-blocked order [Cin/8][16][Cout][8] (returned with the logical shape [16,Cout,Cin])."""
@@ -647,6 +701,7 @@ def winograd_weights(w_ohwi: torch.Tensor) -> torch.Tensor:
     return u
 
 
+@_on_device
 def nhwc_to_kblocked(x: torch.Tensor) -> torch.Tensor:
     """[B,H,W,C] → [C/8,B,H,W,8]."""
     _need_gpu(x)
@@ -657,6 +712,7 @@ def nhwc_to_kblocked(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+@_on_device
 def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, scale, shift, relu: bool = False, algo_cin=None,
                      out: str = "nhwc"):
     """relu(conv3x3_same(x) * scale + shift) with u from winograd_weights.
@@ -696,6 +752,7 @@ def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, scale, shift, relu: bool 
     return y if out == "nhwc" else yk if out == "kblocked" else (y, yk)
 
 
+@_on_device
 def stem_conv(x: torch.Tensor, w: torch.Tensor, scale, shift, relu: bool = True, algo_cin: int | None = None):
     """The ResNet stem: conv 7x7 stride 2 pad 3 + affine + ReLU. x NHWC [B,H,W,4] (RGB + zero channel), w OHWI
     [64,7,7,4] → [B,H/2,W/2,64]."""
@@ -713,5 +770,5 @@ def stem_conv(x: torch.Tensor, w: torch.Tensor, scale, shift, relu: bool = True,
     if prof is not None:
         e1.record()
         m, k = y.numel() // 64, 49 * (algo_cin or 4)
-        prof.append((e0, e1, 2.0 * m * 64 * k, (m, 64, k), 4.0 * (x.numel() + y.numel() + w.numel())))
+        prof.append((e0, e1, 2.0 * m * 64 * k, (m, 64, k), 4.0 * (x.numel() + y.numel() + w.numel()), "stem"))
     return y

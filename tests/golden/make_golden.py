@@ -10,7 +10,7 @@ Sources of truth used here (nothing of theirs is copied into the repo — only i
     c++ext/maskrcnn/__init__.py:21-45 does (that file's legacy autograd.Function cannot run on
     torch >= 1.5).
 
-Usage:  python tests/golden/make_golden.py [nms crop roi_align anchors graph refine schema image]
+Usage:  python tests/golden/make_golden.py [nms crop roi_align anchors graph refine schema image config1]
         (no argument: rewrite every fixture; deterministic)
 """
 import contextlib
@@ -511,6 +511,35 @@ def gen_image(rconfig, rutils, rmodel, rdata):
     save("image", **out)
 
 
+def gen_config1(rconfig, rutils, rmodel):
+    """BASELINE configs[0]: `predict.py images/car58a54312d.jpg` — the geometry detect() sees for the reference's own
+    sample image (predict.py:55-60 → model.detect, model.py:1095-1110): 1200 x 1920 RGB → scale 1024/1920 → 640 x 1024
+    → zero-padded to 1024 x 1024 with window (192, 0, 832, 1024). The image file is one of the reference's data files;
+    its decoded pixels are stored as the input vector. Outputs: the resized uint8 image (Pillow BILINEAR — what
+    scipy.misc.imresize did, utils.py:73), and from the reference's own resize_image / mold_image on it: window,
+    padding, and the molded fp32 [3,1024,1024] tensor as a sha256 plus a 16-pixel-stride sample (the full tensor is
+    12.6 MB)."""
+    from PIL import Image
+    cfg = rconfig.CocoInferenceConfig()
+    a = np.array(Image.open(os.path.join(REF, "images", "car58a54312d.jpg")).convert("RGB"))
+    h, w = a.shape[:2]
+    scale = max(1, cfg.IMAGE_MIN_DIM / min(h, w))                            # utils.py:62-69, evaluated here
+    if round(max(h, w) * scale) > cfg.IMAGE_MAX_DIM:
+        scale = cfg.IMAGE_MAX_DIM / max(h, w)
+    resized = np.array(Image.fromarray(a).resize((round(w * scale), round(h * scale)), Image.BILINEAR))
+    padded, window, s1, padding = rutils.resize_image(resized, min_dim=None, max_dim=cfg.IMAGE_MAX_DIM, padding=True)
+    assert s1 == 1
+    molded = rmodel.mold_image(padded, cfg)                                   # model.py:1750-1754 (float64 mean)
+    molded = torch.from_numpy(molded.transpose(2, 0, 1)).float().contiguous()  # model.py:1108
+    save("config1", image=a, resized=resized, window=np.array(window, dtype=np.int64),
+         scale=np.array(scale, dtype=np.float64), padding=np.array(padding, dtype=np.int64),
+         mean_pixel=np.asarray(cfg.MEAN_PIXEL, dtype=np.float64),
+         min_dim=np.int64(cfg.IMAGE_MIN_DIM), max_dim=np.int64(cfg.IMAGE_MAX_DIM),
+         molded_sha256=np.array(hashlib.sha256(molded.numpy().tobytes()).hexdigest()),
+         molded_sample=molded.numpy()[:, ::16, ::16].copy(),
+         pillow_version=np.array(__import__("PIL").__version__))
+
+
 def main():
     only = set(sys.argv[1:])
     want = lambda n: not only or n in only
@@ -531,6 +560,8 @@ def main():
         gen_schema(rconfig, rmodel)
     if want("image"):
         gen_image(rconfig, rutils, rmodel, rdata)
+    if want("config1"):
+        gen_config1(rconfig, rutils, rmodel)
 
 
 if __name__ == "__main__":

@@ -19,8 +19,43 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/maskrcnn_hip.h but not exported"
     assert set(_lib._SIGS) == set(names), "ctypes table and header disagree"
-    assert _lib.lib.mrcnn_abi_version() == 1
+    assert _lib.lib.mrcnn_abi_version() == _lib.header_abi_version() >= 2
     assert _lib.lib.mrcnn_arch() == b"gfx950"
+
+
+def test_ctypes_table_matches_header_prototypes():
+    """_SIGS is a hand-kept copy of the header: argument counts and types are cross-checked against the prototypes
+    (a mismatch would pass wrong-width arguments to a kernel launch)."""
+    from maskrcnn_amd import _lib
+    protos = _lib.header_prototypes()
+    assert set(protos) == set(_lib._SIGS)
+    for name, (res, args) in _lib._SIGS.items():
+        hres, hargs = protos[name]
+        assert res == hres, f"{name}: return type {res} vs header {hres}"
+        assert len(args) == len(hargs), f"{name}: {len(args)} arguments vs {len(hargs)} in the header"
+        for i, (a, h) in enumerate(zip(args, hargs)):
+            assert a == h, f"{name}: argument {i} is {a} in _SIGS, {h} in the header"
+
+
+def test_stale_library_is_rejected(tmp_path, monkeypatch):
+    """An .so built from another revision of the header must not load (same names, other argument lists)."""
+    from maskrcnn_amd import _lib
+    fake = tmp_path / "maskrcnn_hip.h"
+    fake.write_text(open(_lib.HEADER).read().replace(f"#define MRCNN_ABI_VERSION {_lib.header_abi_version()}",
+                                                     "#define MRCNN_ABI_VERSION 9999"))
+    monkeypatch.setattr(_lib, "HEADER", str(fake))
+    monkeypatch.setattr(_lib, "header_abi_version", lambda header=str(fake): 9999)
+    with pytest.raises(ImportError, match="ABI version"):
+        _lib._load()
+
+
+def test_inference_config_validates_kernel_limits():
+    from maskrcnn_amd.config import InferenceConfig
+    InferenceConfig(pre_nms_limit=4096, proposal_count=1000)
+    for kw in (dict(pre_nms_limit=6000), dict(proposal_count=5000, pre_nms_limit=4096), dict(detection_max_instances=0),
+               dict(backbone="resnet18"), dict(image_height=1000)):
+        with pytest.raises(ValueError):
+            InferenceConfig(**kw)
 
 
 def test_dropin_surface_matches_reference():

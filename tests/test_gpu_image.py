@@ -227,3 +227,54 @@ def test_detect_end_to_end(ops, oracle):
         if scale != 1:
             h0, w0 = images[b].shape[:2]
             assert abs(masks.shape[1] - h0) <= 1 and abs(masks.shape[2] - w0) <= 1
+
+
+def test_config1_car_image_mold_and_detect(ops, oracle):
+    """BASELINE configs[0] — `predict.py images/car58a54312d.jpg`: the reference's sample image (decoded pixels in the
+    fixture) through detect(): 1200 x 1920 → 640 x 1024 → 1024^2 canvas, window (192, 0, 832, 1024) (utils.py:42-90,
+    predict.py:55-60). The molded tensor is bit-identical to the golden one (sha256 of the reference's own mold_image
+    output); detect() on it (synthetic weights: no checkpoint offline) returns boxes and masks in the ORIGINAL image's
+    frame, equal to the oracle's full_masks / decode_masks / decode_boxes composed on the pipeline's detections."""
+    import hashlib
+
+    from maskrcnn_amd import image as imagelib
+    from maskrcnn_amd import modules
+    from maskrcnn_amd.config import InferenceConfig
+    from maskrcnn_amd.pipeline import MaskRCNNInference
+    z = load_golden("config1")
+    a = z["image"]
+    cfg = InferenceConfig(image_height=1024, image_width=1024, backbone="resnet50", pre_nms_limit=500, proposal_count=500,
+                          image_min_dim=int(z["min_dim"]), image_max_dim=int(z["max_dim"]),
+                          mean_pixel=tuple(z["mean_pixel"].tolist()))
+    molded, windows, metas = imagelib.mold_inputs([a], cfg, DEV)
+    assert windows[0].tolist() == z["window"].tolist() == [192, 0, 832, 1024]
+    assert float(metas[0][0]) == float(z["scale"]) and [list(p) for p in metas[0][1]] == z["padding"].tolist()
+    m = molded[0].cpu().contiguous()
+    assert hashlib.sha256(m.numpy().tobytes()).hexdigest() == str(z["molded_sha256"])
+    assert np.array_equal(m.numpy()[:, ::16, ::16], z["molded_sample"])
+    resized = imagelib.resize_image(a, cfg.image_min_dim, cfg.image_max_dim, padding=False, device=DEV)[0]
+    assert np.array_equal(resized.cpu().numpy(), z["resized"])
+
+    sd = modules.synthetic_state_dict("resnet50", seed=0, bn_seed=1)
+    g = torch.Generator().manual_seed(5)
+    sd["classifier.linear_class.weight"] = torch.randn(81, 1024, generator=g) * 0.05
+    sd["classifier.linear_class.bias"] = torch.randn(81, generator=g) * 0.5
+    net = MaskRCNNInference(sd, cfg, DEV)
+    (ids, scores, boxes, masks), = net.detect([a])
+    det = net.predict(molded, windows)
+    n = int(det.counts[0])
+    if n == 0:
+        assert ids is None
+        return
+    scale, window = metas[0][0], tuple(windows[0].tolist())
+    assert torch.equal(ids, det.class_ids[0, :n])
+    bx = det.boxes[0, :n].cpu()
+    assert bool((bx[:, 0] >= 192).all() and (bx[:, 2] <= 832).all())          # clipped to the window (model.py:1429)
+    m28 = det.masks[0, :n].permute(0, 3, 1, 2).cpu()
+    ok = ((bx[:, 2] > bx[:, 0]) & (bx[:, 3] > bx[:, 1])).nonzero().flatten()
+    full = torch.zeros(n, 1024, 1024, dtype=torch.bool)
+    if len(ok):
+        full[ok] = oracle.full_masks(det.class_ids[0, :n].cpu()[ok], bx[ok], m28[ok], 1024, 1024)
+    assert torch.equal(masks.cpu(), oracle.decode_masks(full, scale, window))
+    assert torch.equal(boxes.cpu(), oracle.decode_boxes(bx, scale, window))
+    assert tuple(masks.shape[1:]) == (1200, 1920)                              # back at the original image's size

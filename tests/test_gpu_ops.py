@@ -392,3 +392,32 @@ def test_detection_select(dev):
             assert torch.equal(scores[i, :n].cpu(), dets[i, order, 4]) and not scores[i, n:].any()
             assert torch.equal(boxes[i, :n].cpu(), dets[i, order, :4]) and not boxes[i, n:].any()
             assert torch.equal(rois[i, :n].cpu(), dets[i, order, :4] / 1024.0) and not rois[i, n:].any()
+
+
+def test_device_guard(dev):
+    """Every binding runs with its tensors' device current and refuses tensors on different devices (a
+    launch on the current device's stream against another device's pointers is a fault or silent xGMI peer traffic)."""
+    from maskrcnn_amd import ops
+    d = torch.rand(1, 64, 5, device=dev)
+    keep, counts = ops.nms_batched(d, 0.5)
+    assert keep.device == d.device and counts.device == d.device
+    if torch.cuda.device_count() < 2:
+        # one GPU on this box: the guard's device comparison is still exercised through its error path
+        class Fake:
+            pass
+        with pytest.raises(RuntimeError, match="Not compiled with CPU support"):
+            ops.nms_batched(d.cpu(), 0.5)
+        return
+    other = torch.device("cuda:1")
+    assert torch.cuda.current_device() == 0
+    d1 = d.to(other)
+    keep1, counts1 = ops.nms_batched(d1, 0.5)          # current device is 0: the guard switches to 1 for the call
+    assert keep1.device == other and torch.equal(keep1.cpu(), keep.cpu()) and torch.equal(counts1.cpu(), counts.cpu())
+    assert torch.cuda.current_device() == 0
+    x = torch.randn(1, 16, 16, 64, device=other)
+    w = torch.randn(64, 3, 3, 64, device=other) * 0.05
+    y1 = ops.conv3x3_winograd(x, ops.winograd_weights(w), None, None)     # > 64 KB of LDS: per-device attribute
+    y0 = ops.conv3x3_winograd(x.to(dev), ops.winograd_weights(w.to(dev)), None, None)
+    assert torch.equal(y1.cpu(), y0.cpu())
+    with pytest.raises(RuntimeError, match="different devices"):
+        ops.conv_bn_act(x, w.to(dev), None, None, 1, (1, 1, 1, 1))

@@ -94,7 +94,7 @@ def _free_port():
     return p
 
 
-def _gather_worker(rank, world, port, q):
+def _gather_worker(rank, world, port, q, global_batch):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
@@ -104,35 +104,54 @@ def _gather_worker(rank, world, port, q):
     mdist = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mdist)
     r, _, w = mdist.init_from_env(backend="gloo")
-    b_local, d = 4, 50
-    lo, hi = mdist.shard_range(world * b_local, r, w)
+    d = 50
+    lo, hi = mdist.shard_range(global_batch, r, w)
+    b_local = hi - lo
     # detections whose content encodes the global image index
     packed = torch.zeros(b_local, d, 6)
     counts = torch.zeros(b_local, dtype=torch.int32)
     for i, gi in enumerate(range(lo, hi)):
         packed[i, :, 0] = gi
         packed[i, :, 1] = torch.arange(d) / d
+        packed[i, :, 2:] = gi * 10.0 + torch.arange(4)
         counts[i] = gi + 1
-    gp, gc = mdist.all_gather_detections(packed, counts)
+    calls = []
+    orig = torch.distributed.all_gather_into_tensor
+    torch.distributed.all_gather_into_tensor = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    gp, gc = mdist.all_gather_detections(packed, counts, global_batch=global_batch)
+    torch.distributed.all_gather_into_tensor = orig
+    # a shard size that disagrees with shard_range is an error, not a hang
+    bad = None
+    try:
+        mdist.all_gather_detections(torch.zeros(b_local + 1, d, 6), torch.zeros(b_local + 1, dtype=torch.int32),
+                                    global_batch=global_batch)
+    except RuntimeError as e:
+        bad = str(e)
     mdist.barrier()
     t = mdist.max_over_ranks(float(r + 1), "cpu")
-    q.put((r, gp[:, 0, 0].tolist(), gc.tolist(), t))
+    q.put((r, tuple(gp.shape), gp[:, 0, 0].tolist(), gp[:, 3, 5].tolist(), gc.tolist(), str(gc.dtype), t, len(calls),
+           bad is not None))
     torch.distributed.destroy_process_group()
 
 
-def test_all_gather_detections_gloo_world2():
+@pytest.mark.parametrize("global_batch", [8, 7, 1])   # even shards; 4 + 3; 1 + 0 (a rank with no image)
+def test_all_gather_detections_gloo_world2(global_batch):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q, global_batch)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for r, ids, counts, t in res:
-        assert ids == [float(i) for i in range(8)]      # rank-major == global image order
-        assert counts == [i + 1 for i in range(8)]
-        assert t == 2.0                                   # max over ranks
+    for r, shape, ids, last, counts, dtype, t, ncalls, bad_raised in res:
+        assert shape == (global_batch, 50, 6)
+        assert ids == [float(i) for i in range(global_batch)]      # rank-major == global image order, padding gone
+        assert last == [i * 10.0 + 3 for i in range(global_batch)]
+        assert counts == [i + 1 for i in range(global_batch)] and dtype == "torch.int32"
+        assert t == 2.0                                              # max over ranks
+        assert ncalls == 1, "one collective per step"
+        assert bad_raised

@@ -89,3 +89,22 @@ def test_coefficients_sum_to_one(oracle):
         bounds, kk = oracle.resample_coeffs(in_size, out_size)
         assert (np.abs(kk.sum(axis=1) - (1 << 22)) <= kk.shape[1]).all()
         assert (bounds[:, 0] >= 0).all() and (bounds[:, 0] + bounds[:, 1] <= in_size).all()
+
+
+def test_config1_car_image_geometry(oracle):
+    """BASELINE configs[0]: the reference's sample image images/car58a54312d.jpg through detect()'s pre-processing
+    (utils.resize_image + mold_image): 1200 x 1920 → 640 x 1024 → 1024^2 canvas, window (192, 0, 832, 1024)."""
+    import hashlib
+
+    from maskrcnn_amd import image as imagelib
+    z = load_golden("config1")
+    a = z["image"]
+    assert a.shape == (1200, 1920, 3)
+    img, window, scale, padding = oracle.resize_image(a, int(z["min_dim"]), int(z["max_dim"]), True)
+    assert tuple(window) == tuple(z["window"].tolist()) == (192, 0, 832, 1024)
+    assert float(scale) == float(z["scale"]) and np.array_equal(np.array(padding), z["padding"])
+    assert np.array_equal(img[192:832], z["resized"]) and not img[:192].any() and not img[832:].any()
+    molded = oracle.mold_image(img, z["mean_pixel"])[0].contiguous()
+    assert hashlib.sha256(molded.numpy().tobytes()).hexdigest() == str(z["molded_sha256"])
+    assert np.array_equal(molded.numpy()[:, ::16, ::16], z["molded_sample"])
+    assert imagelib.resize_plan(1200, 1920, 800, 1024, True)[:4] == (640, 1024, (192, 0, 832, 1024), float(z["scale"]))
