@@ -193,12 +193,18 @@ struct PyramidArgs {
 };
 
 __device__ __forceinline__ int roi_level(float y1, float x1, float y2, float x2, float image_area) {
-    // model.py:324-338 in fp32: 4 + log2(sqrt(h*w) / (224 / sqrt(area))), round half to even, clamp
+    // model.py:324-338 in fp32: 4 + log2(sqrt(h*w) / (224 / sqrt(area))), round half to even, clamp.
+    // Every fp32 operation of that formula is evaluated CORRECTLY ROUNDED: sqrt, the two divisions and log2 go through
+    // double and are rounded to float once (exact for sqrt and division, 53 >= 2*24 + 2; for log2 up to double's own
+    // error, ~1e-8 of the inputs). torch-CPU's log2 (MKL VML, high-accuracy mode) is correctly rounded on all but
+    // ~1e-4 of its inputs, the device's log2f on far fewer: with log2f 7-11 % of the boxes within a few ulp of a level
+    // boundary k = 2.5 / 3.5 / 4.5 landed one level off (tests/test_gpu_fullsize.py::test_level_boundaries_ulp_sweep).
     const float h = y2 - y1, w = x2 - x1;
     const float hw = h * w;
-    const float denom = 224.0f / sqrtf(image_area);
-    const float ratio = sqrtf(hw) / denom;
-    const float k = 4.0f + log2f(ratio);
+    const float denom = static_cast<float>(224.0 / static_cast<double>(static_cast<float>(sqrt(static_cast<double>(image_area)))));
+    const float ratio = static_cast<float>(static_cast<double>(static_cast<float>(sqrt(static_cast<double>(hw)))) /
+                                           static_cast<double>(denom));
+    const float k = 4.0f + static_cast<float>(log2(static_cast<double>(ratio)));
     // NaN (negative area) / -inf (zero area) → the reference's int cast is UB; it lands on level 2
     if (!(k >= 2.0f)) return 2;
     if (k >= 5.0f) return 5;

@@ -18,6 +18,7 @@ import json
 import math
 import os
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -233,9 +234,16 @@ def test_full_size_proposals(full, oracle):
                                        return_dets=True)
         got_dets = s["mid"]["rpn_dets"][b].cpu()
         assert got_dets.shape == (1000, 5)
-        assert torch.equal(got_dets[:, 4], dets[:, 4])                      # same top-1000, same order
-        d = (got_dets[:, :4] - dets[:, :4]).abs()
-        REPORT[f"config3/img{b}/proposal_boxes"] = {"max_abs_err_px": d.max().item(),
+        assert torch.equal(got_dets[:, 4], dets[:, 4])                      # same top-1000 scores, same order
+        # With 261 888 anchors some of the top-1000 fp32 scores TIE. The reference orders ties with ATen's unstable
+        # sort (unspecified), this library by lower anchor index: rows are compared within each group of equal scores
+        # as sets (sorted by their coordinates), everything else row by row.
+        def canon(t):
+            a = t.numpy()
+            return torch.from_numpy(a[np.lexsort((a[:, 3], a[:, 2], a[:, 1], a[:, 0], -a[:, 4]))])
+        ties = int(1000 - torch.unique(dets[:, 4]).numel())
+        d = (canon(got_dets)[:, :4] - canon(dets)[:, :4]).abs()
+        REPORT[f"config3/img{b}/proposal_boxes"] = {"max_abs_err_px": d.max().item(), "tied_scores": ties,
                                                     "boxes_not_bit_identical": int((d.max(1).values > 0).sum())}
         assert d.max().item() <= 1e-3                                        # pixels; exp() ulp differences only
         keep = oracle.nms(got_dets, ocfg.RPN_NMS_THRESHOLD)[:ocfg.RPN_NMS_MAX_ROIS_NUM]
