@@ -75,7 +75,7 @@ def conv_roofline(prof, args, H, W, modules):
     tag = [r[5] if len(r) > 5 else "direct" for r in prof]
     # multiply-adds the MFMA pipe really performs: Winograd F(2x2,3x3) needs 16 products per 2x2 outputs and channel
     # pair instead of 36
-    executed = [r[2] / 2.25 if t == "winograd" else r[2] for r, t in zip(prof, tag)]
+    executed = [r[6] if len(r) > 6 else (r[2] / 2.25 if t == "winograd" else r[2]) for r, t in zip(prof, tag)]
     peak = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else F16_MFMA_PEAK_TFLOPS
 
     def agg(sel):

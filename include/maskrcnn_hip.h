@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 2
+#define MRCNN_ABI_VERSION 3
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -336,6 +336,26 @@ int mrcnn_paste_masks_u8(const float* masks, int64_t stride_n, int64_t stride_y,
                          int32_t n, int32_t mask_h, int32_t mask_w, int32_t num_classes, const int64_t* class_ids,
                          const float* boxes, int32_t height, int32_t width, int32_t on_value, uint8_t* out,
                          mrcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-block fused Bottleneck — replaces the module composite  Bottleneck.forward  (model.py:190-211):
+ *   out = relu( bn3(conv3(relu(bn2(conv2_same(relu(bn1(conv1(x)))))))) + x )
+ * for the stride-1 IDENTITY blocks (no downsample branch) with planes = 64 and Cin = 4 * planes = 256 (ResNet C2 blocks
+ * after the first): ONE launch, both 64-channel intermediates stay in LDS (csrc/bottleneck.hip). BatchNorm (eval) and
+ * the conv biases are the folded fp32 (scale, shift) epilogues; conv2 runs as Winograd F(2x2,3x3) on the fp32 MFMA.
+ * The result equals the three-launch path (mrcnn_conv_bn_act_f32 → mrcnn_conv3x3_winograd_f32 → mrcnn_conv_bn_act_f32
+ * with residual) bit for bit.
+ *   x   fp32 [batch][height][width][cin] NHWC;  y  fp32 [batch][height][width][4*planes], y != x
+ *   w1  [planes][cin] (conv1, OHWI 1x1);  u2 = mrcnn_winograd_weights_f32(conv2 weights [planes][3][3][planes]);
+ *   w3  [4*planes][planes] (conv3, OHWI 1x1);  scaleN, shiftN: per output channel of conv N (NULL = 1 / 0)
+ * mrcnn_bottleneck_fused_supported() tells whether a shape is covered (planes == 64, cin == 256, height and width
+ * multiples of 16); other blocks run the per-layer entry points.
+ * ---------------------------------------------------------------------------------------------- */
+int mrcnn_bottleneck_fused_supported(int32_t height, int32_t width, int32_t cin, int32_t planes);
+int mrcnn_bottleneck_fused_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                               const float* w1, const float* scale1, const float* shift1, const float* u2,
+                               const float* scale2, const float* shift2, const float* w3, const float* scale3,
+                               const float* shift3, int32_t planes, float* y, mrcnn_stream_t stream);
 
 #ifdef __cplusplus
 }

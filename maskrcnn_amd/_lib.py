@@ -62,6 +62,9 @@ _SIGS = {
     "mrcnn_conv_bn_act_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
                                                c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32,
                                                c_vp]),
+    "mrcnn_bottleneck_fused_supported": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
+    "mrcnn_bottleneck_fused_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                    c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "mrcnn_nhwc_to_kblocked_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "mrcnn_stem_conv7x7_s2_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "mrcnn_topk_workspace_bytes": (ctypes.c_size_t, [c_i32]),

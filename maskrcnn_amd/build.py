@@ -29,6 +29,7 @@ SOURCES = {
     "conv_f16.hip": [],
     "conv_wino.hip": [],
     "stem.hip": [],
+    "bottleneck.hip": [],
     "misc.hip": ["-ffp-contract=off"],
     "select.hip": ["-ffp-contract=off"],
     "image.hip": ["-ffp-contract=off"],   # Pillow's coefficient arithmetic, operation by operation in fp64

@@ -158,6 +158,12 @@ WINOGRAD = os.environ.get("MRCNN_WINOGRAD", "1") != "0"
 # f32 mode: the 7x7 stride-2 stem runs its own kernel (same fp32 MFMA arithmetic as the generic one, 3x faster);
 # MRCNN_STEM_KERNEL=0 sends it through the generic implicit-GEMM kernel.
 STEM_KERNEL = os.environ.get("MRCNN_STEM_KERNEL", "1") != "0"
+# f32 Winograd mode: with MRCNN_FUSED_BOTTLENECK=1 the stride-1 identity Bottlenecks with planes = 64 (ResNet C2 blocks
+# 1, 2) run as ONE launch of the whole-block kernel (csrc/bottleneck.hip; bit-identical to the three-launch path, half its
+# HBM traffic). Off by default: at batch 8 x 256^2 x 256 it measures 0.735 ms per block against 0.704 ms for the three
+# launches — one workgroup per CU runs its three GEMM phases back to back, so nothing overlaps the
+# HBM-bound conv3 epilogue, while the per-layer kernels overlap five workgroups per CU there.
+FUSED_BOTTLENECK = os.environ.get("MRCNN_FUSED_BOTTLENECK", "0") == "1"
 
 
 class ConvWeight:
@@ -270,6 +276,11 @@ class FusedBottleneck:
         if self.convs is None:
             return torch.ops.maskrcnn.bottleneck_forward(x, *self.p)
         c1, c2, c3, cd = self.convs
+        if (FUSED_BOTTLENECK and WINOGRAD and self.precision == "f32" and cd is None and c1.stride == 1
+                and c2.w.u is not None and x.dim() == 4
+                and ops.bottleneck_fused_supported(x.size(1), x.size(2), x.size(3), c1.w.shape[0])):
+            return ops.bottleneck_fused(x, c1.w.w, c1.scale, c1.shift, c2.w.u, c2.scale, c2.shift,
+                                        c3.w.w, c3.scale, c3.shift)
         res = x if cd is None else cd(x)
         oh, ow = -(-x.size(1) // c1.stride), -(-x.size(2) // c1.stride)
         # conv1's output only feeds conv2: written directly in the layout the Winograd kernel reads

@@ -392,10 +392,53 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def bottleneck_fused_supported(h: int, w: int, cin: int, planes: int) -> bool:
+    """Shapes the whole-block kernel covers: stride-1 identity blocks with planes = 64, Cin = 256, H and W % 16 == 0."""
+    return bool(lib.mrcnn_bottleneck_fused_supported(int(h), int(w), int(cin), int(planes)))
+
+
+@_on_device
+def bottleneck_fused(x, w1, s1, t1, u2, s2, t2, w3, s3, t3) -> torch.Tensor:
+    """Bottleneck.forward (model.py:190-211) of a stride-1 identity block in ONE launch (csrc/bottleneck.hip): both
+    planes-channel intermediates stay in LDS. x [B,H,W,Cin] NHWC; w1 [P,1,1,Cin]; u2 = winograd_weights(conv2 weight
+    [P,3,3,P]); w3 [4P,1,1,P]; (s, t) the folded BN/bias affine of each conv. Returns [B,H,W,4P]. Equals the
+    three-launch path bit for bit."""
+    _need_gpu(x, w1, s1, t1, u2, s2, t2, w3, s3, t3)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    b, h, w, cin = x.shape
+    planes = w1.size(0)
+    assert w1.is_contiguous() and w1.numel() == planes * cin and w3.is_contiguous() and w3.numel() == 4 * planes * planes
+    assert u2.is_contiguous() and u2.numel() == 16 * planes * planes
+    for t, n in ((s1, planes), (t1, planes), (s2, planes), (t2, planes), (s3, 4 * planes), (t3, 4 * planes)):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n)
+    y = torch.empty(b, h, w, 4 * planes, dtype=torch.float32, device=x.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mrcnn_bottleneck_fused_f32(x.data_ptr(), b, h, w, cin, w1.data_ptr(), _ptr(s1), _ptr(t1), u2.data_ptr(),
+                                         _ptr(s2), _ptr(t2), w3.data_ptr(), _ptr(s3), _ptr(t3), planes, y.data_ptr(),
+                                         _stream()))
+    if prof is not None:
+        e1.record()
+        m = b * h * w
+        algo = 2.0 * m * (cin * planes + 9 * planes * planes + planes * 4 * planes)
+        # what the MFMA pipe executes: conv1 on 352 GEMM rows per 256 output pixels (halo + row-tile padding),
+        # conv2 as Winograd (1/2.25), conv3 as is
+        executed = 2.0 * m * (cin * planes * 352.0 / 256.0 + 9 * planes * planes / 2.25 + planes * 4 * planes)
+        prof.append((e0, e1, algo, (m, 4 * planes, cin + 9 * planes + planes),
+                     4.0 * (2 * x.numel() + y.numel() + w1.numel() + u2.numel() + w3.numel()), "bottleneck", executed))
+    return y
+
+
 def bottleneck_forward(x, w1, s1, t1, w2, s2, t2, w3, s3, t3, wd, sd, td, stride: int):
-    """Bottleneck.forward (model.py:190-211) on NHWC: conv1 1x1 (stride) + BN + ReLU → SamePad(3,1) +
-    conv2 3x3 + BN + ReLU → conv3 1x1 + BN, + residual (identity or 1x1-stride downsample + BN), ReLU.
-    Four (three without downsample) fused conv launches; BN/bias are (scale, shift) epilogues."""
+    """Bottleneck.forward (model.py:190-211) on NHWC: conv1 1x1 (stride) + BN + ReLU, SamePad(3,1) + conv2 3x3 + BN +
+    ReLU, conv3 1x1 + BN, + residual (identity or 1x1-stride downsample + BN), ReLU.
+    Stride-1 identity blocks with planes = 64 (the shapes of bottleneck_fused_supported) run as ONE launch of the
+    whole-block kernel; every other block as three or four fused conv launches. BN/bias are (scale, shift) epilogues."""
+    if (wd is None and int(stride) == 1 and x.is_cuda and x.dim() == 4 and tuple(w2.shape[1:3]) == (3, 3)
+            and bottleneck_fused_supported(x.size(1), x.size(2), x.size(3), w1.size(0)) and w3.size(0) == x.size(3)):
+        return bottleneck_fused(x, w1, s1, t1, winograd_weights(w2), s2, t2, w3, s3, t3)
     h = conv_bn_act(x, w1, s1, t1, stride=stride, relu=True)
     pad = same_pad(h.size(1), h.size(2), 3, 1)
     h = conv_bn_act(h, w2, s2, t2, stride=1, pad=pad, relu=True)
@@ -409,7 +452,8 @@ _LIB.define("bottleneck_forward(Tensor x, Tensor w1, Tensor s1, Tensor t1, Tenso
 _LIB.impl("bottleneck_forward", bottleneck_forward, "CUDA")
 _LIB.impl("bottleneck_forward", lambda x, *a: _need_gpu(x), "CPU")
 
-__all__ += ["conv_bn_act", "conv_bn_act_f16mfma", "split_f16", "same_pad", "maxpool", "nchw_to_nhwc", "nhwc_to_nchw", "bottleneck_forward"]
+__all__ += ["conv_bn_act", "conv_bn_act_f16mfma", "split_f16", "same_pad", "maxpool", "nchw_to_nhwc", "nhwc_to_nchw", "bottleneck_forward",
+            "bottleneck_fused", "bottleneck_fused_supported"]
 
 
 @_on_device

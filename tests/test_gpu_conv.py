@@ -379,3 +379,78 @@ def test_stem_kernel_vs_generic_and_torch(dev):
     y = ops.stem_conv(x.to(dev), wt.to(dev), None, sh.to(dev), True)
     yd = ops.conv_bn_act(x.to(dev), wt.to(dev), None, sh.to(dev), 2, (3, 3, 3, 3), True)
     assert (y - yd).abs().max().item() <= 1e-4 * max(1.0, yd.abs().max().item())
+
+
+# --------------------------------------------------------------------------------------------------
+# whole-block fused Bottleneck (csrc/bottleneck.hip): stride-1 identity blocks with planes = 64
+# --------------------------------------------------------------------------------------------------
+def _identity_block_sd(g, cin=256, planes=64):
+    sd = {}
+    for name, co, ci, k in (("conv1", planes, cin, 1), ("conv2", planes, planes, 3), ("conv3", 4 * planes, planes, 1)):
+        sd[f"{name}.weight"] = torch.randn(co, ci, k, k, generator=g) * math.sqrt(2.0 / (ci * k * k))
+        sd[f"{name}.bias"] = torch.randn(co, generator=g) * 0.1
+        bn = "bn" + name[-1]
+        sd[f"{bn}.weight"] = torch.rand(co, generator=g) + 0.5
+        sd[f"{bn}.bias"] = torch.randn(co, generator=g) * 0.1
+        sd[f"{bn}.running_mean"] = torch.randn(co, generator=g) * 0.1
+        sd[f"{bn}.running_var"] = torch.rand(co, generator=g) + 0.5
+    return sd
+
+
+def _ref_bottleneck(x, sd):
+    """Bottleneck.forward (model.py:190-211) in torch-CPU fp32, BN in eval mode (eps 1e-3)."""
+    def bn(y, n):
+        return F.batch_norm(y, sd[f"{n}.running_mean"], sd[f"{n}.running_var"], sd[f"{n}.weight"], sd[f"{n}.bias"],
+                            False, 0.0, 1e-3)
+    y = F.relu(bn(F.conv2d(x, sd["conv1.weight"], sd["conv1.bias"]), "bn1"))
+    y = F.relu(bn(F.conv2d(F.pad(y, (1, 1, 1, 1)), sd["conv2.weight"], sd["conv2.bias"]), "bn2"))
+    y = bn(F.conv2d(y, sd["conv3.weight"], sd["conv3.bias"]), "bn3")
+    return F.relu(y + x)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 16, 16), (3, 64, 16), (1, 256, 256)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+def test_bottleneck_fused_whole_block(dev, shape):
+    """One launch for conv1 → conv2 → conv3 + residual (C2 identity blocks): bit-identical to the three-launch path
+    (same summation orders and transforms), within 1e-4 abs of torch-CPU on unit-scale data, tiles on every image
+    border and in the interior, at sizes from one tile to the full C2 resolution of a 1024^2 image."""
+    from maskrcnn_amd import modules, ops
+    b, h, w = shape
+    g = torch.Generator().manual_seed(900 + h + w)
+    sd = _identity_block_sd(g)
+    x = torch.randn(b, 256, h, w, generator=g)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    assert ops.bottleneck_fused_supported(h, w, 256, 64)
+    blk = modules.FusedBottleneck.from_state_dict(sd, "", 1, dev)
+    c1, c2, c3, cd = blk.convs
+    assert cd is None
+    fused = ops.bottleneck_fused(xd, c1.w.w, c1.scale, c1.shift, c2.w.u, c2.scale, c2.shift, c3.w.w, c3.scale, c3.shift)
+    saved = modules.FUSED_BOTTLENECK
+    try:
+        modules.FUSED_BOTTLENECK = False
+        unfused = blk(xd)
+        modules.FUSED_BOTTLENECK = True
+        assert torch.equal(blk(xd), fused)                       # the module takes the fused launch
+    finally:
+        modules.FUSED_BOTTLENECK = saved
+    assert torch.equal(fused, unfused), f"max diff {(fused - unfused).abs().max().item():.3e}"
+    assert torch.equal(fused, ops.bottleneck_fused(xd, c1.w.w, c1.scale, c1.shift, c2.w.u, c2.scale, c2.shift,
+                                                   c3.w.w, c3.scale, c3.shift))          # run to run
+    want = _ref_bottleneck(x, sd)
+    err = (fused.permute(0, 3, 1, 2).cpu() - want).abs().max().item()
+    assert err <= TOL, f"max abs err {err:.3e} (|ref|max {want.abs().max().item():.2f})"
+    # the registered op with the reference-shaped argument list routes to the same launch
+    y = torch.ops.maskrcnn.bottleneck_forward(xd, c1.w.w, c1.scale, c1.shift, c2.w.w, c2.scale, c2.shift, c3.w.w,
+                                              c3.scale, c3.shift, None, None, None, 1)
+    assert torch.equal(y, fused)
+
+
+def test_bottleneck_fused_rejects_other_shapes(dev):
+    from maskrcnn_amd import ops
+    from maskrcnn_amd._lib import MaskrcnnHipError
+    assert not ops.bottleneck_fused_supported(128, 128, 512, 128)     # C3: planes 128
+    assert not ops.bottleneck_fused_supported(24, 16, 256, 64)        # H % 16 != 0
+    z = lambda *s: torch.zeros(*s, device=dev)
+    with pytest.raises(MaskrcnnHipError):
+        ops.bottleneck_fused(z(1, 24, 16, 256), z(64, 1, 1, 256), None, None, z(16, 64, 64), None, None,
+                             z(256, 1, 1, 64), None, None)
