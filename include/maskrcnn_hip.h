@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 3
+#define MRCNN_ABI_VERSION 4
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -209,6 +209,13 @@ int mrcnn_rpn_level_fused_f32(const float* x, int32_t batch, int32_t height, int
  *   reference's fp32 op order. */
 int mrcnn_rpn_scores_deltas_f32(const float* const heads[5], const int32_t level_hw[5], int32_t batch,
                                 float* scores, float* deltas, mrcnn_stream_t stream);
+/* The same with a per-level input form (level_mode[l]): 0 = NHWC [batch][H_l][W_l][18] head outputs as above;
+ * 1 = the head sums of mrcnn_conv3x3_winograd_heads_f32: [2][rows][32] fp32 in position-major pixel order (row of pixel
+ * (b,y,x) = ((b*H/2 + y/2)*W/2 + x/2)*4 + (y&1)*2 + (x&1), rows = mrcnn_conv3x3_winograd_heads_rows()), bias not yet
+ * added: logits/deltas = (sum of the two k halves) + head_bias[c]. level_h/level_w: H_l, W_l. */
+int mrcnn_rpn_scores_deltas_v2_f32(const float* const heads[5], const int32_t level_h[5], const int32_t level_w[5],
+                                   const int32_t level_mode[5], const float* head_bias, int32_t batch, float* scores,
+                                   float* deltas, mrcnn_stream_t stream);
 int mrcnn_proposal_decode_f32(const float* anchors, const float* deltas, const int64_t* order,
                               const float* top_scores, int32_t batch, int32_t num_anchors, int32_t k,
                               const float std_dev[4], float image_height, float image_width, float* dets,
@@ -336,6 +343,21 @@ int mrcnn_paste_masks_u8(const float* masks, int64_t stride_n, int64_t stride_y,
                          int32_t n, int32_t mask_h, int32_t mask_w, int32_t num_classes, const int64_t* class_ids,
                          const float* boxes, int32_t height, int32_t width, int32_t on_value, uint8_t* out,
                          mrcnn_stream_t stream);
+
+/* RPN conv_shared + both 1x1 heads in one launch on the Winograd kernel (RPN.forward, model.py:605-607,624-641):
+ * relu(conv3x3_same(x) * scale + shift) is never stored — each 64-channel output tile is transposed through LDS and
+ * multiplied by w_head32 ([32][cout]: rows 0..17 = conv_class (6) then conv_bbox (12) weights, other rows zero) while
+ * on chip; a workgroup owns whole M tiles and adds the contribution of each of its cout/64 N tiles to the M tile's sums.
+ *   x_kblocked  fp32 [cin/8][batch][H][W][8];  u = mrcnn_winograd_weights_f32 of the [cout][3][3][cin] filter
+ *   head_part   fp32 [2][rows][32], rows = mrcnn_conv3x3_winograd_heads_rows(batch, H, W): the two k halves of the sums
+ *               (without the head bias) in position-major pixel order — the input form 1 of
+ *               mrcnn_rpn_scores_deltas_v2_f32. Fully overwritten; no zero-fill needed.
+ *   H, W even; cin % 8 == 0; cout % 64 == 0. Deterministic (fixed summation order). */
+int64_t mrcnn_conv3x3_winograd_heads_rows(int32_t batch, int32_t height, int32_t width);
+int mrcnn_conv3x3_winograd_heads_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                     const float* u, int32_t cout, const float* scale, const float* shift,
+                                     int32_t activation, const float* w_head32, float* head_part,
+                                     mrcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Whole-block fused Bottleneck — replaces the module composite  Bottleneck.forward  (model.py:190-211):

@@ -46,6 +46,11 @@ struct WinoParams {
     unsigned x_plane, u_plane, yk_plane;  // bytes per 8-channel plane of x / u / the k-blocked output
     int tiles_m, tiles_n;
     unsigned x_bytes, u_bytes, y_bytes;
+    // fused 1x1 heads (conv3x3_wino8_f32<true>): w_head [32][Cout] (rows >= the real head count are zero);
+    // head_part [2 k halves][tiles_m * 256 pixel rows in position-major order][32] partial sums
+    const float* w_head;
+    float* head_part;
+    unsigned head_bytes;
 };
 
 constexpr int WT = 64;   // tile positions per workgroup
@@ -53,6 +58,7 @@ constexpr int WN = 64;   // output channels per workgroup
 constexpr int WK = 8;    // input channels per k tile
 constexpr int PLANE = WT * WK;  // floats per component plane (V and U alike: WT == WN)
 constexpr size_t WINO_LDS = sizeof(float) * 2 * 2 * 16 * PLANE;  // {V,U} x 2 buffers x 16 components = 128 KiB
+constexpr size_t WINO_HEADS_LDS = WINO_LDS + sizeof(float) * 128 * WN;  // + the transposed tile of a round: 160 KiB
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -328,6 +334,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const WinoParams p) {
 // w+4 share a SIMD, so each SIMD carries one of each. The output transform needs all 16 components of a position:
 // M.A is split into partial sums per wave (columns j = 0,1 or 2,3), exchanged through LDS in two rounds of 32
 // positions (8 waves x 2 partials x 32 x 64 floats = the 128 KB the operand buffers occupied).
+// HEADS = true (the RPN's conv_shared, model.py:605-607,624-641): the ReLU'd 64-channel output tile is not stored;
+// it is transposed through LDS and multiplied by the [32][Cout] weights of both 1x1 heads while on chip. A workgroup
+// then owns whole M tiles and walks their N tiles itself, adding each N tile's contribution to the M tile's
+// [256 pixels][32] head sums (a read-modify-write of 32 KB that stays in its XCD's L2; waves w and w + 4 split K and
+// keep separate sums). The 512-channel activation (1.43 GB written and read back per step) never reaches HBM.
+template <bool HEADS>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Vs = smem;
@@ -339,15 +351,29 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32(const WinoParams p) 
     // b + gridDim, ... of the XCD-aware virtual grid, so it stays on its XCD and the CUs of an XCD work on neighbouring
     // tiles at any time; this saves a workgroup launch (128 KB of LDS, eight waves) per tile.
     const int total_tiles = 8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-    int m0, n0;
+    for (int it = 0;; ++it) {
+    int m0, n0, nt;
     {
-        const int xcd = tile & 7, seq = tile >> 3;
+        // plain: virtual tile b, b + grid, ... in the XCD-aware (M tile, N tile) order. HEADS: M-tile units b, b + grid,
+        // ..., each walked over all its N tiles by this workgroup
+        const int tile = HEADS ? (blockIdx.x + (it / p.tiles_n) * gridDim.x) * p.tiles_n + it % p.tiles_n
+                               : blockIdx.x + it * gridDim.x;
+        if (tile >= total_tiles) break;
+        int xcd, seq;
+        if constexpr (HEADS) {
+            const int unit = tile / p.tiles_n;
+            xcd = unit & 7;
+            seq = (unit >> 3) * p.tiles_n + (tile - unit * p.tiles_n);
+        } else {
+            xcd = tile & 7;
+            seq = tile >> 3;
+        }
         const int mt_lo = (xcd * p.tiles_m) >> 3, mt_hi = ((xcd + 1) * p.tiles_m) >> 3;
         const int mt = mt_lo + seq / p.tiles_n;
         if (mt >= mt_hi) continue;  // uniform
         m0 = mt * WT;
-        n0 = (seq % p.tiles_n) * WN;
+        nt = seq % p.tiles_n;
+        n0 = nt * WN;
     }
     const int ln = lane & 31, lh = lane >> 5;
     const bool v_role = wave < 4;
@@ -522,6 +548,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32(const WinoParams p) 
     float* Z = smem;  // [wave][2 partials][8 position quads][64 channels][4 positions]
     constexpr int ZQ = 8 * WN * 4;  // floats per (wave, partial) plane
     const int jh = wave & 1;
+    // HEADS: the round's 128 pixels x 64 channels, transposed for the head MFMA; 16-byte chunks XOR-swizzled by the pixel
+    // (a 64-float pitch would put every row on the same banks), exactly the 32 KB above the operand buffers
+    float* Tt = smem + 2 * 2 * 16 * PLANE;
+    const int hrt = wave & 3, hkh = wave >> 2;  // head MFMA: pixel rows 32 hrt .. +31 of the round, channels 32 hkh .. +31
+    float4 wh[4];
+    // opaque copies of the lane coordinates: everything the heads epilogue derives from them (LDS and global offsets,
+    // the head-weight loads) stays behind the main loop — hoisted out of the tile loop those ~25 values spill inside it
+    int ln_e = ln, lh_e = lh, tid_e = tid;
+    if constexpr (HEADS) {
+        asm volatile("" : "+v"(ln_e), "+v"(lh_e), "+v"(tid_e));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            wh[j] = *reinterpret_cast<const float4*>(p.w_head + static_cast<int64_t>(ln_e) * p.Cout + n0 + hkh * 32 + j * 8 + lh_e * 4);
+    }
+    const __amdgpu_buffer_rsrc_t hp_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.head_part, 0, HEADS ? p.head_bytes : 0u, 0x00020000);
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {  // position half
         __syncthreads();  // operand buffers (or the previous round's Z) are no longer read
@@ -573,6 +614,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32(const WinoParams p) 
                 for (int a = 0; a < 2; ++a) {
                     float v = yv[a] * sc + sh;
                     if (p.act) v = v > 0.f ? v : 0.f;
+                    if constexpr (HEADS) {
+                        const int pxl = ((tid_e >> 6) * 4 + e) * 4 + a * 2 + c;  // position-major pixel of the round
+                        Tt[pxl * WN + ((tid_e & 63) ^ ((pxl & 15) << 2))] = v;
+                        continue;
+                    }
                     const unsigned px = static_cast<unsigned>((b * p.H + 2 * ty + a) * p.W + 2 * tx + c);
                     if (p.y) {
                         const unsigned o = (pv && n_ok) ? px * (static_cast<unsigned>(p.Cout) * 4u) + ncol : OOB;
@@ -584,6 +630,37 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32(const WinoParams p) 
                     }
                 }
             }
+        }
+        if constexpr (HEADS) {
+            // [128 pixels x 32 channels of this wave] x [32 channels x 32 head outputs] on top of the M tile's running
+            // sums (N tile 0 starts them): 16 MFMAs per wave and round
+            __syncthreads();
+            const int row0 = (m0 * 4 + h * 128 + hrt * 32 + 4 * lh_e);  // + (r & 3) + 8 (r >> 2)
+            const unsigned hbase = (static_cast<unsigned>(hkh) * static_cast<unsigned>(p.tiles_m) * 256u + static_cast<unsigned>(row0)) * 128u +
+                                   static_cast<unsigned>(ln_e) * 4u;
+            f32x16 hacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                hacc[r] = 0.f;
+                if (nt != 0)
+                    hacc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        hp_rsrc, static_cast<int>(hbase + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * 128u), 0, 0));
+            }
+            const int pxl = hrt * 32 + ln_e;
+            const float* trow = Tt + pxl * WN;
+            const int swz = (pxl & 15) << 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 a4 = *reinterpret_cast<const float4*>(trow + ((hkh * 32 + j * 8 + lh_e * 4) ^ swz));
+                hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, wh[j].x, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, wh[j].y, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, wh[j].z, hacc, 0, 0, 0);
+                hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, wh[j].w, hacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hacc[r]), hp_rsrc,
+                                                      static_cast<int>(hbase + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * 128u), 0, 0);
         }
     }
     __syncthreads();  // Z is read out: the next tile may overwrite the operand buffers
@@ -688,6 +765,7 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
     }
     WinoParams p;
     p.x = x8; p.u = u; p.scale = scale; p.shift = shift; p.y = y_nhwc; p.yk = y_kblocked;
+    p.w_head = nullptr; p.head_part = nullptr; p.head_bytes = 0;
     p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout;
     p.TH = height / 2; p.TW = width / 2; p.T = batch * p.TH * p.TW; p.act = activation;
     p.tiles_m = (p.T + WT - 1) / WT;
@@ -700,7 +778,7 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
     p.y_bytes = static_cast<unsigned>(4LL * px * cout);
     const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
     MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd: grid too large");
-    for (const void* f : {reinterpret_cast<const void*>(conv3x3_wino_f32), reinterpret_cast<const void*>(conv3x3_wino8_f32)})
+    for (const void* f : {reinterpret_cast<const void*>(conv3x3_wino_f32), reinterpret_cast<const void*>(conv3x3_wino8_f32<false>)})
         if (int rc = mrcnn::ensure_dynamic_lds(f, WINO_LDS, "conv3x3_winograd")) return rc;
     static const bool four_waves = getenv("MRCNN_WINO_WAVES") && atoi(getenv("MRCNN_WINO_WAVES")) == 4;
     if (four_waves)
@@ -711,9 +789,55 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
         const int num_cu = cus >= 8 ? (cus / 8) * 8 : 8;
         static const bool persistent = !(getenv("MRCNN_WINO_PERSISTENT") && atoi(getenv("MRCNN_WINO_PERSISTENT")) == 0);
         const long long launch = (persistent && grid > num_cu) ? num_cu : grid;
-        hipLaunchKernelGGL(conv3x3_wino8_f32, dim3(static_cast<unsigned>(launch)), dim3(512), WINO_LDS, st, p);
+        hipLaunchKernelGGL(conv3x3_wino8_f32<false>, dim3(static_cast<unsigned>(launch)), dim3(512), WINO_LDS, st, p);
     }
     return mrcnn::check_launch("conv3x3_wino_f32");
+}
+
+extern "C" int64_t mrcnn_conv3x3_winograd_heads_rows(int32_t batch, int32_t height, int32_t width) {
+    if (batch < 1 || height < 2 || width < 2 || height % 2 || width % 2) return 0;
+    const int64_t t = static_cast<int64_t>(batch) * (height / 2) * (width / 2);
+    return ((t + WT - 1) / WT) * 256;
+}
+
+extern "C" int mrcnn_conv3x3_winograd_heads_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width,
+                                                int32_t cin, const float* u, int32_t cout, const float* scale,
+                                                const float* shift, int32_t activation, const float* w_head32,
+                                                float* head_part, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x_kblocked && u && w_head32 && head_part, "conv3x3_winograd_heads: null pointer");
+    MRCNN_REQUIRE(batch >= 1 && height >= 2 && width >= 2 && height % 2 == 0 && width % 2 == 0,
+                  "conv3x3_winograd_heads: B=%d H=%d W=%d (even sizes required)", batch, height, width);
+    MRCNN_REQUIRE(cin >= 8 && cin % 8 == 0 && cout >= WN && cout % WN == 0,
+                  "conv3x3_winograd_heads: Cin=%d (%% 8 == 0) Cout=%d (%% 64 == 0) required", cin, cout);
+    MRCNN_REQUIRE(activation == 0 || activation == 1, "conv3x3_winograd_heads: activation must be 0 or 1");
+    const long long px = 1LL * batch * height * width;
+    const long long rows = mrcnn_conv3x3_winograd_heads_rows(batch, height, width);
+    MRCNN_REQUIRE(px * cin < (1LL << 30) && 16LL * cin * cout < (1LL << 30) && 2 * rows * 32 < (1LL << 30),
+                  "conv3x3_winograd_heads: tensor too large (32-bit buffer byte offsets)");
+    WinoParams p;
+    p.x = x_kblocked; p.u = u; p.scale = scale; p.shift = shift; p.y = nullptr; p.yk = nullptr;
+    p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout;
+    p.TH = height / 2; p.TW = width / 2; p.T = batch * p.TH * p.TW; p.act = activation;
+    p.tiles_m = (p.T + WT - 1) / WT;
+    p.tiles_n = cout / WN;
+    p.x_bytes = static_cast<unsigned>(4LL * px * cin);
+    p.u_bytes = static_cast<unsigned>(4LL * 16 * cin * cout);
+    p.x_plane = static_cast<unsigned>(4LL * px * WK);
+    p.u_plane = static_cast<unsigned>(4LL * 16 * cout * WK);
+    p.yk_plane = 0; p.y_bytes = 0;
+    p.w_head = w_head32; p.head_part = head_part;
+    p.head_bytes = static_cast<unsigned>(4LL * 2 * rows * 32);
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wino8_f32<true>), WINO_HEADS_LDS,
+                                           "conv3x3_winograd_heads"))
+        return rc;
+    const int cus = mrcnn::device_cu_count();
+    if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd_heads: cannot query the device");
+    const int num_cu = cus >= 8 ? (cus / 8) * 8 : 8;
+    const long long units = 8LL * ((p.tiles_m + 7) / 8);  // M-tile units; a workgroup walks the N tiles of its units
+    const long long launch = units < num_cu ? units : num_cu;
+    hipLaunchKernelGGL(conv3x3_wino8_f32<true>, dim3(static_cast<unsigned>(launch)), dim3(512), WINO_HEADS_LDS,
+                       mrcnn::as_stream(stream), p);
+    return mrcnn::check_launch("conv3x3_wino8_f32<heads>");
 }
 
 extern "C" int mrcnn_conv3x3_winograd_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,

@@ -161,9 +161,15 @@ extern "C" int mrcnn_nhwc_to_nchw_f32(const float* x, int32_t batch, int32_t cha
 namespace {
 
 struct RpnLevels {
-    const float* y[5];   // fused head output per level, NHWC [B][H][W][18]: 0-5 (bg,fg) logits x 3, 6-17 deltas
+    const float* y[5];   // mode 0: fused head output per level, NHWC [B][H][W][18]: 0-5 (bg,fg) logits x 3, 6-17 deltas
+                         // mode 1: the Winograd kernel's head sums [2 k halves][rows][32] in position-major pixel order
+                         //         (row = ((b*H/2 + y/2)*W/2 + x/2)*4 + (y&1)*2 + (x&1)); bias not yet added
     int hw[5];           // H*W per level
+    int w[5];            // W per level
     int first[5];        // first anchor index of the level
+    int mode[5];
+    int rows[5];         // mode 1: rows per k half
+    const float* bias;   // mode 1: [18] head bias (conv_class then conv_bbox)
 };
 
 // one thread per (image, anchor): fg = softmax(bg, fg)[1] as exp(x - max) / sum (the formula torch uses)
@@ -179,12 +185,29 @@ __global__ __launch_bounds__(256) void rpn_scores_deltas(RpnLevels lv, int B, in
         for (int i = 1; i < 5; ++i) l += (a >= lv.first[i]) ? 1 : 0;
         const int local = a - lv.first[l];
         const int pix = local / 3, r = local - pix * 3;
-        const float* p = lv.y[l] + (static_cast<int64_t>(b) * lv.hw[l] + pix) * 18;
-        const float l0 = p[2 * r], l1 = p[2 * r + 1];
+        float l0, l1;
+        float4 d;
+        if (lv.mode[l] == 0) {
+            const float* p = lv.y[l] + (static_cast<int64_t>(b) * lv.hw[l] + pix) * 18;
+            l0 = p[2 * r];
+            l1 = p[2 * r + 1];
+            d = make_float4(p[6 + 4 * r], p[7 + 4 * r], p[8 + 4 * r], p[9 + 4 * r]);
+        } else {
+            const int W = lv.w[l], H = lv.hw[l] / W;
+            const int y = pix / W, x = pix - y * W;
+            const int64_t row = ((static_cast<int64_t>(b) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * 4 + (y & 1) * 2 + (x & 1);
+            const float* p0 = lv.y[l] + row * 32;
+            const float* p1 = p0 + static_cast<int64_t>(lv.rows[l]) * 32;
+            const float* bs = lv.bias;
+            // fixed order: (k half 0 + k half 1) + bias
+            l0 = (p0[2 * r] + p1[2 * r]) + bs[2 * r];
+            l1 = (p0[2 * r + 1] + p1[2 * r + 1]) + bs[2 * r + 1];
+            d = make_float4((p0[6 + 4 * r] + p1[6 + 4 * r]) + bs[6 + 4 * r], (p0[7 + 4 * r] + p1[7 + 4 * r]) + bs[7 + 4 * r],
+                            (p0[8 + 4 * r] + p1[8 + 4 * r]) + bs[8 + 4 * r], (p0[9 + 4 * r] + p1[9 + 4 * r]) + bs[9 + 4 * r]);
+        }
         const float m = fmaxf(l0, l1);
         const float e0 = expf(l0 - m), e1 = expf(l1 - m);
         scores[e] = e1 / (e0 + e1);
-        float4 d = make_float4(p[6 + 4 * r], p[7 + 4 * r], p[8 + 4 * r], p[9 + 4 * r]);
         *reinterpret_cast<float4*>(deltas + e * 4) = d;
     }
 }
@@ -225,18 +248,31 @@ __global__ __launch_bounds__(256) void proposal_decode(const float* __restrict__
 
 }  // namespace
 
-extern "C" int mrcnn_rpn_scores_deltas_f32(const float* const heads[5], const int32_t level_hw[5],
-                                           int32_t batch, float* scores, float* deltas,
-                                           mrcnn_stream_t stream) {
-    MRCNN_REQUIRE(heads && level_hw && scores && deltas && batch >= 1, "rpn_scores_deltas: bad arguments");
+extern "C" int mrcnn_rpn_scores_deltas_v2_f32(const float* const heads[5], const int32_t level_h[5],
+                                              const int32_t level_w[5], const int32_t level_mode[5],
+                                              const float* head_bias, int32_t batch, float* scores, float* deltas,
+                                              mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(heads && level_h && level_w && level_mode && scores && deltas && batch >= 1,
+                  "rpn_scores_deltas: bad arguments");
     RpnLevels lv;
     int a = 0;
+    lv.bias = head_bias;
     for (int l = 0; l < 5; ++l) {
-        MRCNN_REQUIRE(heads[l] && level_hw[l] >= 1, "rpn_scores_deltas: bad level %d", l);
+        MRCNN_REQUIRE(heads[l] && level_h[l] >= 1 && level_w[l] >= 1, "rpn_scores_deltas: bad level %d", l);
+        MRCNN_REQUIRE(level_mode[l] == 0 || (level_mode[l] == 1 && head_bias && level_h[l] % 2 == 0 && level_w[l] % 2 == 0),
+                      "rpn_scores_deltas: level %d: mode must be 0 (NHWC heads) or 1 (position-major head sums: even H, W "
+                      "and a bias vector)", l);
         lv.y[l] = heads[l];
-        lv.hw[l] = level_hw[l];
+        lv.hw[l] = level_h[l] * level_w[l];
+        lv.w[l] = level_w[l];
+        lv.mode[l] = level_mode[l];
+        lv.rows[l] = 0;
+        if (level_mode[l] == 1) {
+            const int64_t t = static_cast<int64_t>(batch) * (level_h[l] / 2) * (level_w[l] / 2);
+            lv.rows[l] = static_cast<int>(((t + 63) / 64) * 256);  // == mrcnn_conv3x3_winograd_heads_rows()
+        }
         lv.first[l] = a;
-        a += level_hw[l] * 3;
+        a += lv.hw[l] * 3;
     }
     const int64_t total = static_cast<int64_t>(batch) * a;
     int64_t blocks = (total + 255) / 256;
@@ -244,6 +280,14 @@ extern "C" int mrcnn_rpn_scores_deltas_f32(const float* const heads[5], const in
     hipLaunchKernelGGL(rpn_scores_deltas, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
                        mrcnn::as_stream(stream), lv, batch, a, scores, deltas);
     return mrcnn::check_launch("rpn_scores_deltas");
+}
+
+extern "C" int mrcnn_rpn_scores_deltas_f32(const float* const heads[5], const int32_t level_hw[5],
+                                           int32_t batch, float* scores, float* deltas,
+                                           mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(level_hw, "rpn_scores_deltas: bad arguments");
+    const int32_t one[5] = {1, 1, 1, 1, 1}, zero[5] = {0, 0, 0, 0, 0};
+    return mrcnn_rpn_scores_deltas_v2_f32(heads, level_hw, one, zero, nullptr, batch, scores, deltas, stream);
 }
 
 extern "C" int mrcnn_proposal_decode_f32(const float* anchors, const float* deltas, const int64_t* order,

@@ -164,6 +164,14 @@ STEM_KERNEL = os.environ.get("MRCNN_STEM_KERNEL", "1") != "0"
 # launches — one workgroup per CU runs its three GEMM phases back to back, so nothing overlaps the
 # HBM-bound conv3 epilogue, while the per-layer kernels overlap five workgroups per CU there.
 FUSED_BOTTLENECK = os.environ.get("MRCNN_FUSED_BOTTLENECK", "0") == "1"
+# f32 Winograd mode: on the large pyramid levels the RPN's two 1x1 heads run inside the Winograd kernel of conv_shared
+# (ops.conv3x3_winograd_heads): the 512-channel shared activation never reaches HBM. A workgroup then owns whole M tiles
+# (64 tile positions each), so only levels with many of them qualify: at least RPN_HEADS_MIN_TILES PER IMAGE — P2 and P3
+# of a 1024^2 or 832 x 1344 input. The rule looks at the image size only, never at the batch: the two forms add the 512
+# channels up in different groupings, and image i of a batch must equal image i alone bit for bit.
+# MRCNN_RPN_FUSED_HEADS=0 keeps the separate 18-channel head conv everywhere.
+RPN_FUSED_HEADS = os.environ.get("MRCNN_RPN_FUSED_HEADS", "1") != "0"
+RPN_HEADS_MIN_TILES = 64
 
 
 class ConvWeight:
@@ -402,12 +410,21 @@ class FusedRPN:
             self.shared = FusedConv(sd, prefix + "conv_shared", None, device, relu=True, same_pad_kernel=3,
                                     precision=precision)
             self.w_head = ConvWeight(pack_weight(w, device), precision)
+            if precision == "f32" and self.shared.w.u is not None:   # heads inside the Winograd kernel (large levels)
+                w32 = torch.zeros(32, w.size(1), dtype=torch.float32)
+                w32[:w.size(0)] = w.float().view(w.size(0), -1)
+                self.w_head32 = w32.contiguous().to(device)
 
     def __call__(self, p, p_kblocked=None):
         """p: a pyramid level NHWC; p_kblocked: the same map k-blocked, when the producer wrote it (f32 Winograd mode)."""
         if self.fused_level:
             return ops.rpn_level_fused(p, self.w_shared, self.b_shared, self.w_head32, self.b_head, self.head_n)
         if p_kblocked is not None and self.shared.takes_winograd(p.size(1), p.size(2)):
+            b, h, w = p.size(0), p.size(1), p.size(2)
+            if (RPN_FUSED_HEADS and getattr(self, "w_head32", None) is not None
+                    and -(-((h // 2) * (w // 2)) // 64) >= RPN_HEADS_MIN_TILES and self.shared.w.shape[0] % 64 == 0):
+                return ops.conv3x3_winograd_heads(p_kblocked, self.shared.w.u, self.shared.scale, self.shared.shift,
+                                                  self.w_head32, True, self.shared.algo_cin)
             p = p_kblocked
         return self.w_head.conv(self.shared(p), None, self.b_head)
 

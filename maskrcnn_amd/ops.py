@@ -34,6 +34,8 @@ def _ptr(t):
 def _tensors(obj):
     if isinstance(obj, torch.Tensor):
         yield obj
+    elif hasattr(obj, "part") and isinstance(getattr(obj, "part"), torch.Tensor):   # HeadSums
+        yield obj.part
     elif isinstance(obj, (list, tuple)):
         for o in obj:
             yield from _tensors(o)
@@ -456,22 +458,73 @@ __all__ += ["conv_bn_act", "conv_bn_act_f16mfma", "split_f16", "same_pad", "maxp
             "bottleneck_fused", "bottleneck_fused_supported"]
 
 
+class HeadSums:
+    """Output of conv3x3_winograd_heads for one pyramid level: the two k halves of the 1x1-head sums (without bias) in
+    position-major pixel order, [2, rows, 32] fp32, for a [B, H, W] level. Consumed by rpn_scores_deltas."""
+
+    def __init__(self, part: torch.Tensor, batch: int, height: int, width: int):
+        self.part, self.batch, self.height, self.width = part, batch, height, width
+
+    def to_nhwc(self, bias: torch.Tensor) -> torch.Tensor:
+        """[B,H,W,18] = (half 0 + half 1) + bias, in image order (tests / debugging; the pipeline never needs it)."""
+        b, h, w = self.batch, self.height, self.width
+        t = b * (h // 2) * (w // 2)
+        v = (self.part[0, :t * 4, :18] + self.part[1, :t * 4, :18]) + bias
+        return v.view(b, h // 2, w // 2, 2, 2, 18).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, 18).contiguous()
+
+
 @_on_device
-def rpn_scores_deltas(heads):
-    """heads: 5 contiguous fp32 NHWC tensors [B,H_l,W_l,18] (fused RPN head outputs, P2..P6) →
-    (fg scores [B,A], deltas [B,A,4]) in the reference's anchor order. One launch."""
+def conv3x3_winograd_heads(x_kblocked: torch.Tensor, u: torch.Tensor, scale, shift, w_head32: torch.Tensor,
+                           relu: bool = True, algo_cin=None) -> HeadSums:
+    """RPN conv_shared + both 1x1 heads in one launch (model.py:605-607,624-641): relu(conv3x3_same(x)*scale + shift)
+    stays on chip and is multiplied by w_head32 [32, Cout] (rows 0-17: conv_class then conv_bbox weights).
+    x_kblocked [Cin/8,B,H,W,8]; u from winograd_weights. → HeadSums."""
+    _need_gpu(x_kblocked, u, scale, shift, w_head32)
+    assert x_kblocked.dim() == 5 and x_kblocked.is_contiguous() and x_kblocked.dtype == torch.float32
+    g, b, h, w, _ = x_kblocked.shape
+    cin, cout = g * 8, u.size(1)
+    assert u.is_contiguous() and u.size(2) == cin and w_head32.is_contiguous() and tuple(w_head32.shape) == (32, cout)
+    rows = int(lib.mrcnn_conv3x3_winograd_heads_rows(b, h, w))
+    part = torch.empty(2, rows, 32, dtype=torch.float32, device=x_kblocked.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mrcnn_conv3x3_winograd_heads_f32(x_kblocked.data_ptr(), b, h, w, cin, u.data_ptr(), cout, _ptr(scale),
+                                               _ptr(shift), 1 if relu else 0, w_head32.data_ptr(), part.data_ptr(),
+                                               _stream()))
+    if prof is not None:
+        e1.record()
+        m, k = b * h * w, 9 * (algo_cin or cin)
+        algo = 2.0 * m * cout * (k + 18)                      # the 3x3 conv + both 1x1 heads (18 channels)
+        executed = 2.0 * m * cout * (k / 2.25 + 32)           # Winograd multiplies + the head MFMAs on 32 padded columns
+        prof.append((e0, e1, algo, (m, cout, k), 4.0 * (m * cin + 2 * part.numel() / 2 + cout * k), "winograd", executed))
+    return HeadSums(part, b, h, w)
+
+
+@_on_device
+def rpn_scores_deltas(heads, head_bias: torch.Tensor | None = None):
+    """heads: 5 per-level entries (P2..P6), each a contiguous fp32 NHWC tensor [B,H_l,W_l,18] (fused RPN head outputs)
+    or a HeadSums (conv3x3_winograd_heads; needs head_bias [18]) → (fg scores [B,A], deltas [B,A,4]) in the
+    reference's anchor order. One launch."""
     assert len(heads) == 5
-    _need_gpu(*heads)
-    b = heads[0].size(0)
+    tens = [h.part if isinstance(h, HeadSums) else h for h in heads]
+    _need_gpu(*tens, head_bias)
+    b = heads[0].batch if isinstance(heads[0], HeadSums) else heads[0].size(0)
+    hs, ws, modes = [], [], []
     for h in heads:
-        assert h.is_contiguous() and h.dtype == torch.float32 and h.size(0) == b and h.size(3) == 18
-    hw = [h.size(1) * h.size(2) for h in heads]
-    a = 3 * sum(hw)
-    scores = torch.empty(b, a, dtype=torch.float32, device=heads[0].device)
-    deltas = torch.empty(b, a, 4, dtype=torch.float32, device=heads[0].device)
-    ptrs = (c_vp * 5)(*[h.data_ptr() for h in heads])
-    check(lib.mrcnn_rpn_scores_deltas_f32(ptrs, (c_i32 * 5)(*hw), b, scores.data_ptr(), deltas.data_ptr(),
-                                          _stream()))
+        if isinstance(h, HeadSums):
+            assert h.batch == b and h.part.is_contiguous() and head_bias is not None and head_bias.numel() == 18
+            hs.append(h.height); ws.append(h.width); modes.append(1)
+        else:
+            assert h.is_contiguous() and h.dtype == torch.float32 and h.size(0) == b and h.size(3) == 18
+            hs.append(h.size(1)); ws.append(h.size(2)); modes.append(0)
+    a = 3 * sum(hh * ww for hh, ww in zip(hs, ws))
+    scores = torch.empty(b, a, dtype=torch.float32, device=tens[0].device)
+    deltas = torch.empty(b, a, 4, dtype=torch.float32, device=tens[0].device)
+    ptrs = (c_vp * 5)(*[t.data_ptr() for t in tens])
+    check(lib.mrcnn_rpn_scores_deltas_v2_f32(ptrs, (c_i32 * 5)(*hs), (c_i32 * 5)(*ws), (c_i32 * 5)(*modes),
+                                             _ptr(head_bias), b, scores.data_ptr(), deltas.data_ptr(), _stream()))
     return scores, deltas
 
 
@@ -491,7 +544,7 @@ def proposal_decode(anchors, deltas, order, top_scores, std_dev, image_height, i
     return dets
 
 
-__all__ += ["rpn_scores_deltas", "proposal_decode"]
+__all__ += ["rpn_scores_deltas", "proposal_decode", "conv3x3_winograd_heads", "HeadSums"]
 
 
 @_on_device

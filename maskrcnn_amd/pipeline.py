@@ -62,7 +62,8 @@ class MaskRCNNInference:
     def rpn_heads(self, fms):
         """rpn_detect (model.py:1294-1304) → fg scores [B,A], deltas [B,A,4], A = 261888 at 1024^2."""
         kb = getattr(self.backbone, "kblocked", None) or [None] * len(fms)
-        return ops.rpn_scores_deltas([self.rpn(p, k) for p, k in zip(fms, kb)])   # [B,H,W,18] per level → one launch
+        # per level [B,H,W,18] head outputs, or the in-kernel head sums of the large levels → one launch
+        return ops.rpn_scores_deltas([self.rpn(p, k) for p, k in zip(fms, kb)], self.rpn.b_head)
 
     def proposals(self, scores, deltas):
         """rpn_refine (model.py:1307-1382), batched. → rois [B,P,4] normalised (zero beyond count),

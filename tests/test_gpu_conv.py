@@ -454,3 +454,43 @@ def test_bottleneck_fused_rejects_other_shapes(dev):
     with pytest.raises(MaskrcnnHipError):
         ops.bottleneck_fused(z(1, 24, 16, 256), z(64, 1, 1, 256), None, None, z(16, 64, 64), None, None,
                              z(256, 1, 1, 64), None, None)
+
+
+# --------------------------------------------------------------------------------------------------
+# RPN heads inside the Winograd kernel (conv3x3_wino8_f32<heads>)
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 16, 16, 64, 128), (2, 32, 48, 256, 512), (3, 14, 18, 32, 64), (1, 128, 128, 256, 512)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+def test_winograd_fused_rpn_heads(dev, shape):
+    """RPN.forward on one level (model.py:609-649) with the heads inside the Winograd kernel: relu(conv_shared) is
+    never stored; the head sums come back in position-major order. Against torch-CPU (1e-4 abs, unit-scale data) and
+    against the unfused path (Winograd conv + 18-channel 1x1 conv), incl. ragged last M tiles and several N tiles."""
+    from maskrcnn_amd import ops
+    b, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(300 + h + cin)
+    x = torch.randn(b, cin, h, w, generator=g)
+    ws = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin))
+    bs = torch.randn(cout, generator=g) * 0.1
+    wh = torch.randn(18, cout, 1, 1, generator=g) * math.sqrt(1.0 / cout)
+    bh = torch.randn(18, generator=g) * 0.1
+    shared = F.relu(F.conv2d(x, ws, bs, padding=1))
+    want = F.conv2d(shared, wh, bh).permute(0, 2, 3, 1)
+    xk = ops.nhwc_to_kblocked(x.permute(0, 2, 3, 1).contiguous().to(dev))
+    u = ops.winograd_weights(ws.permute(0, 2, 3, 1).contiguous().to(dev))
+    w32 = torch.zeros(32, cout)
+    w32[:18] = wh.view(18, cout)
+    sums = ops.conv3x3_winograd_heads(xk, u, None, bs.to(dev), w32.to(dev), True)
+    got = sums.to_nhwc(bh.to(dev)).cpu()
+    err = (got - want).abs().max().item()
+    assert err <= TOL, f"max abs err {err:.3e} (|ref|max {want.abs().max().item():.2f})"
+    # the unfused path on the same inputs (different summation grouping over the 512 channels: not bit-identical)
+    y = ops.conv3x3_winograd(xk, u, None, bs.to(dev), True)
+    un = ops.conv_bn_act(y, wh.permute(0, 2, 3, 1).contiguous().to(dev), None, bh.to(dev)).cpu()
+    assert (got - un).abs().max().item() <= 2e-5
+    again = ops.conv3x3_winograd_heads(xk, u, None, bs.to(dev), w32.to(dev), True)
+    assert torch.equal(again.part[:, :b * (h // 2) * (w // 2) * 4], sums.part[:, :b * (h // 2) * (w // 2) * 4])   # deterministic
+    # the consumer: scores / deltas from head sums == from NHWC heads of the same values
+    lv = [got.to(dev)] + [torch.randn(b, max(h >> i, 1), max(w >> i, 1), 18, generator=g).to(dev) for i in (1, 2, 3, 4)]
+    s0, d0 = ops.rpn_scores_deltas(lv)
+    s1, d1 = ops.rpn_scores_deltas([sums] + lv[1:], bh.to(dev))
+    assert torch.equal(s0, s1) and torch.equal(d0, d1)
