@@ -1,0 +1,25 @@
+"""Tuning aid: time the Winograd kernel on the benchmark's big layers (k-blocked input, no layout pass)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from maskrcnn_amd import ops
+dev = "cuda:0"
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+g = torch.Generator().manual_seed(0)
+out = []
+for (b, h, w, cin, cout) in ((8, 256, 256, 256, 512), (8, 256, 256, 256, 256), (8, 128, 128, 256, 512), (8, 64, 64, 256, 256), (8, 256, 256, 64, 64)):
+    x = ops.nhwc_to_kblocked(torch.randn(b, h, w, cin, generator=g).to(dev))
+    wt = (torch.randn(cout, 3, 3, cin, generator=g) * 0.02).to(dev)
+    sh = torch.zeros(cout, device=dev)
+    u = ops.winograd_weights(wt)
+    t = timeit(lambda: ops.conv3x3_winograd(x, u, None, sh, relu=True))
+    fl = 2.0 * b * h * w * cout * 9 * cin / 2.25
+    out.append(f"{cin}->{cout}@{h}: {t:.3f} ms {fl/t/1e9:.1f} TF ({fl/t/1e9/157.3:.3f})")
+print(" | ".join(out))
