@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 4
+#define MRCNN_ABI_VERSION 5
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -114,6 +114,13 @@ int mrcnn_roi_align_pyramid_nhwc_f32(const float* const fm[4], const int32_t fm_
                                      const float* rois, const int32_t* roi_batch, int32_t num_rois,
                                      int32_t rois_per_image, int32_t pool, float image_area,
                                      float* out, int32_t* levels_out, mrcnn_stream_t stream);
+/* The same with a selectable output layout: out_layout = MRCNN_LAYOUT_NHWC (as above) or MRCNN_LAYOUT_KBLOCKED
+ * ([depth/8][num_rois*pool*pool][8], depth % 8 == 0 — what mrcnn_conv3x3_winograd_f32 reads: the mask head's first
+ * conv then needs no layout pass). */
+int mrcnn_roi_align_pyramid_f32(const float* const fm[4], const int32_t fm_h[4], const int32_t fm_w[4], int32_t batch,
+                                int32_t depth, const float* rois, const int32_t* roi_batch, int32_t num_rois,
+                                int32_t rois_per_image, int32_t pool, float image_area, float* out, int32_t out_layout,
+                                int32_t* levels_out, mrcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused convolution + bias/BatchNorm affine + residual + ReLU, channels-last, fp32 MFMA implicit
@@ -180,6 +187,11 @@ int mrcnn_deconv2x2_bias_act_nhwc_f16mfma(const float* x, int32_t batch, int32_t
 int mrcnn_maxpool_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t channels,
                            int32_t kernel, int32_t stride, int32_t pad_top, int32_t pad_left,
                            int32_t pad_bottom, int32_t pad_right, float* y, mrcnn_stream_t stream);
+/* The same with a selectable output layout (MRCNN_LAYOUT_NHWC / MRCNN_LAYOUT_KBLOCKED [C/8][batch*OH*OW][8], C % 8 == 0:
+ * P6 for the RPN's Winograd conv). */
+int mrcnn_maxpool_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t channels, int32_t kernel,
+                      int32_t stride, int32_t pad_top, int32_t pad_left, int32_t pad_bottom, int32_t pad_right, float* y,
+                      int32_t y_layout, mrcnn_stream_t stream);
 
 /* One RPN level in two launches — RPN.forward (model.py:609-649) without ever writing the 512-channel shared
  * activation to HBM: SamePad + conv_shared 3x3 (cin -> cout) + bias + ReLU, then BOTH 1x1 heads (conv_class 6 +

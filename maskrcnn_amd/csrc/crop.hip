@@ -214,7 +214,7 @@ __device__ __forceinline__ int roi_level(float y1, float x1, float y2, float x2,
 __global__ __launch_bounds__(256) void roi_align_pyramid_nhwc(
     PyramidArgs a, int batch, int depth, const float* __restrict__ rois,
     const int* __restrict__ roi_batch, int rois_per_image, int pool, float image_area,
-    float* __restrict__ out, int* __restrict__ levels_out) {
+    float* __restrict__ out, int* __restrict__ levels_out, int out_kblocked, int64_t out_pixels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Sample* sy = reinterpret_cast<Sample*>(smem);
     Sample* sx = sy + pool;
@@ -255,7 +255,10 @@ __global__ __launch_bounds__(256) void roi_align_pyramid_nhwc(
                 v.z = bilerp(tl.z, tr.z, bl.z, br.z, X.lerp, Y.lerp);
                 v.w = bilerp(tl.w, tr.w, bl.w, br.w, X.lerp, Y.lerp);
             }
-            *reinterpret_cast<float4*>(o + static_cast<int64_t>(pt) * depth + c) = v;
+            if (out_kblocked)  // [depth/8][num_rois*pool*pool][8]: what the Winograd kernel (mask head conv1) reads
+                *reinterpret_cast<float4*>(out + ((c >> 3) * out_pixels + static_cast<int64_t>(r) * points + pt) * 8 + (c & 7)) = v;
+            else
+                *reinterpret_cast<float4*>(o + static_cast<int64_t>(pt) * depth + c) = v;
         }
     }
 }
@@ -317,16 +320,16 @@ extern "C" int mrcnn_crop_backward_f32(const float* grads, const float* boxes,
     return mrcnn::check_launch("crop_backward_nchw");
 }
 
-extern "C" int mrcnn_roi_align_pyramid_nhwc_f32(const float* const fm[4], const int32_t fm_h[4],
-                                                const int32_t fm_w[4], int32_t batch, int32_t depth,
-                                                const float* rois, const int32_t* roi_batch,
-                                                int32_t num_rois, int32_t rois_per_image,
-                                                int32_t pool, float image_area, float* out,
-                                                int32_t* levels_out, mrcnn_stream_t stream) {
+extern "C" int mrcnn_roi_align_pyramid_f32(const float* const fm[4], const int32_t fm_h[4], const int32_t fm_w[4],
+                                           int32_t batch, int32_t depth, const float* rois, const int32_t* roi_batch,
+                                           int32_t num_rois, int32_t rois_per_image, int32_t pool, float image_area,
+                                           float* out, int32_t out_layout, int32_t* levels_out, mrcnn_stream_t stream) {
     MRCNN_REQUIRE(fm && fm_h && fm_w && rois && out, "roi_align_pyramid: null pointer");
     MRCNN_REQUIRE(batch >= 1 && depth >= 4 && depth % 4 == 0, "roi_align_pyramid: depth=%d must be a multiple of 4", depth);
     MRCNN_REQUIRE(pool >= 1 && pool <= 1024, "roi_align_pyramid: pool=%d", pool);
     MRCNN_REQUIRE(roi_batch || rois_per_image >= 1, "roi_align_pyramid: need roi_batch or rois_per_image");
+    MRCNN_REQUIRE(out_layout == MRCNN_LAYOUT_NHWC || (out_layout == MRCNN_LAYOUT_KBLOCKED && depth % 8 == 0),
+                  "roi_align_pyramid: out_layout must be NHWC, or k-blocked with depth %% 8 == 0");
     if (num_rois <= 0) return MRCNN_OK;
     PyramidArgs a;
     for (int l = 0; l < 4; ++l) {
@@ -338,6 +341,17 @@ extern "C" int mrcnn_roi_align_pyramid_nhwc_f32(const float* const fm[4], const 
     const size_t lds = sizeof(Sample) * 2 * pool;
     hipLaunchKernelGGL(roi_align_pyramid_nhwc, dim3(num_rois), dim3(256), lds,
                        mrcnn::as_stream(stream), a, batch, depth, rois, roi_batch, rois_per_image,
-                       pool, image_area, out, levels_out);
+                       pool, image_area, out, levels_out, out_layout == MRCNN_LAYOUT_KBLOCKED ? 1 : 0,
+                       static_cast<int64_t>(num_rois) * pool * pool);
     return mrcnn::check_launch("roi_align_pyramid_nhwc");
+}
+
+extern "C" int mrcnn_roi_align_pyramid_nhwc_f32(const float* const fm[4], const int32_t fm_h[4],
+                                                const int32_t fm_w[4], int32_t batch, int32_t depth,
+                                                const float* rois, const int32_t* roi_batch,
+                                                int32_t num_rois, int32_t rois_per_image,
+                                                int32_t pool, float image_area, float* out,
+                                                int32_t* levels_out, mrcnn_stream_t stream) {
+    return mrcnn_roi_align_pyramid_f32(fm, fm_h, fm_w, batch, depth, rois, roi_batch, num_rois, rois_per_image, pool,
+                                       image_area, out, MRCNN_LAYOUT_NHWC, levels_out, stream);
 }

@@ -10,7 +10,7 @@ namespace {
 // y[b,oy,ox,c] = max over k x k window of zero-padded x. One thread = one output pixel x 4 channels.
 __global__ __launch_bounds__(256) void maxpool_nhwc(const float* __restrict__ x, int B, int H, int W,
                                                     int C, int k, int stride, int pt, int pl, int OH,
-                                                    int OW, float* __restrict__ y) {
+                                                    int OW, float* __restrict__ y, int y_kblocked) {
     const int c4 = C >> 2;
     const int64_t total = static_cast<int64_t>(B) * OH * OW * c4;
     for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
@@ -35,7 +35,11 @@ __global__ __launch_bounds__(256) void maxpool_nhwc(const float* __restrict__ x,
                 m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
-        *reinterpret_cast<float4*>(y + ((static_cast<int64_t>(b) * OH + oy) * OW + ox) * C + c) = m;
+        const int64_t opix = (static_cast<int64_t>(b) * OH + oy) * OW + ox;
+        if (y_kblocked)  // [C/8][B*OH*OW][8]
+            *reinterpret_cast<float4*>(y + ((c >> 3) * (static_cast<int64_t>(B) * OH * OW) + opix) * 8 + (c & 7)) = m;
+        else
+            *reinterpret_cast<float4*>(y + opix * C + c) = m;
     }
 }
 
@@ -98,15 +102,16 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw(const float* __restrict__ x,
 
 }  // namespace
 
-extern "C" int mrcnn_maxpool_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
-                                      int32_t channels, int32_t kernel, int32_t stride, int32_t pad_top,
-                                      int32_t pad_left, int32_t pad_bottom, int32_t pad_right, float* y,
-                                      mrcnn_stream_t stream) {
+extern "C" int mrcnn_maxpool_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t channels,
+                                 int32_t kernel, int32_t stride, int32_t pad_top, int32_t pad_left, int32_t pad_bottom,
+                                 int32_t pad_right, float* y, int32_t y_layout, mrcnn_stream_t stream) {
     MRCNN_REQUIRE(x && y, "maxpool: null pointer");
     MRCNN_REQUIRE(batch >= 1 && height >= 1 && width >= 1 && channels >= 4 && channels % 4 == 0,
                   "maxpool: bad shape (channels %% 4 == 0 required)");
     MRCNN_REQUIRE(kernel >= 1 && stride >= 1 && pad_top >= 0 && pad_left >= 0 && pad_bottom >= 0 &&
                       pad_right >= 0, "maxpool: bad kernel/stride/pad");
+    MRCNN_REQUIRE(y_layout == MRCNN_LAYOUT_NHWC || (y_layout == MRCNN_LAYOUT_KBLOCKED && channels % 8 == 0),
+                  "maxpool: y_layout must be NHWC, or k-blocked with channels %% 8 == 0");
     const int OH = (height + pad_top + pad_bottom - kernel) / stride + 1;
     const int OW = (width + pad_left + pad_right - kernel) / stride + 1;
     MRCNN_REQUIRE(OH >= 1 && OW >= 1, "maxpool: empty output");
@@ -115,8 +120,16 @@ extern "C" int mrcnn_maxpool_nhwc_f32(const float* x, int32_t batch, int32_t hei
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(maxpool_nhwc, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
                        mrcnn::as_stream(stream), x, batch, height, width, channels, kernel, stride,
-                       pad_top, pad_left, OH, OW, y);
+                       pad_top, pad_left, OH, OW, y, y_layout == MRCNN_LAYOUT_KBLOCKED ? 1 : 0);
     return mrcnn::check_launch("maxpool_nhwc");
+}
+
+extern "C" int mrcnn_maxpool_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
+                                      int32_t channels, int32_t kernel, int32_t stride, int32_t pad_top,
+                                      int32_t pad_left, int32_t pad_bottom, int32_t pad_right, float* y,
+                                      mrcnn_stream_t stream) {
+    return mrcnn_maxpool_f32(x, batch, height, width, channels, kernel, stride, pad_top, pad_left, pad_bottom, pad_right,
+                             y, MRCNN_LAYOUT_NHWC, stream);
 }
 
 extern "C" int mrcnn_nchw_to_nhwc_f32(const float* x, int32_t batch, int32_t channels, int32_t height,

@@ -384,7 +384,13 @@ class FusedBackbone:
             outs.append(y)
             self.kblocked.append(yk)
         outs.append(ops.maxpool(outs[3], 1, 2))                 # P6, model.py:109,161
-        self.kblocked.append(None)
+        # the RPN's Winograd conv reads P6 k-blocked: subsample it a second time straight into that layout (64 KB per
+        # image) rather than running a layout pass over the NHWC copy
+        p6 = outs[4]
+        p6k = None
+        if self.kblocked[3] is not None and p6.size(1) % 2 == 0 and p6.size(2) % 2 == 0 and p6.size(3) % 8 == 0:
+            p6k = ops.maxpool(outs[3], 1, 2, out_kblocked=True)
+        self.kblocked.append(p6k)
         return outs
 
 
@@ -472,9 +478,16 @@ class FusedMask:
         self.cout = cout
         self.conv5 = FusedConv(sd, prefix + "conv5", None, device, relu=2, precision=precision)  # 2 = sigmoid
 
+    def wants_kblocked(self, pool: int) -> bool:
+        """Would the four 3x3 convs run as a k-blocked Winograd chain on [R, pool, pool, 256] crops? Then RoIAlign can
+        write its output k-blocked and the first conv needs no layout pass."""
+        return self.convs[0].w.precision == "f32" and all(c.takes_winograd(pool, pool) for c in self.convs)
+
     def __call__(self, pooled):
         x = pooled
-        chain = self.convs[0].w.precision == "f32" and all(c.takes_winograd(x.size(1), x.size(2)) for c in self.convs)
+        hh, ww = (x.size(2), x.size(3)) if x.dim() == 5 else (x.size(1), x.size(2))
+        chain = self.convs[0].w.precision == "f32" and all(c.takes_winograd(hh, ww) for c in self.convs)
+        assert x.dim() == 4 or chain
         for i, c in enumerate(self.convs):
             # Winograd -> Winograd: intermediate maps stay in the k-blocked layout, no transposition passes
             x = c(x, out="kblocked" if (chain and i + 1 < len(self.convs)) else "nhwc")

@@ -196,11 +196,12 @@ _LIB.impl("crop", lambda image, *a: _need_gpu(image), "CPU")
 @_on_device
 def roi_align_pyramid(feature_maps, rois: torch.Tensor, pool: int, image_area: float,
                       rois_per_image: int | None = None, roi_batch: torch.Tensor | None = None,
-                      return_levels: bool = False):
+                      return_levels: bool = False, out_kblocked: bool = False):
     """model.py:276-393 in one launch on channels-last maps.
 
     feature_maps: [P2,P3,P4,P5], each a contiguous fp32 [B, H_l, W_l, C] (NHWC) tensor.
-    rois [R,4] normalised. Returns [R, pool, pool, C] (NHWC) in roi order (+ int32 levels)."""
+    rois [R,4] normalised. Returns [R, pool, pool, C] (NHWC) in roi order (+ int32 levels); out_kblocked=True returns
+    [C/8, R, pool, pool, 8] instead (the layout conv3x3_winograd reads: no layout pass before the mask head)."""
     assert len(feature_maps) == 4
     _need_gpu(rois, roi_batch, *feature_maps)
     rois = rois.contiguous()
@@ -208,17 +209,20 @@ def roi_align_pyramid(feature_maps, rois: torch.Tensor, pool: int, image_area: f
     for fm in feature_maps:
         assert fm.is_contiguous() and fm.dtype == torch.float32 and fm.size(0) == b and fm.size(3) == c
     r = rois.size(0)
-    out = torch.empty(r, pool, pool, c, dtype=torch.float32, device=rois.device)
+    if out_kblocked:
+        assert c % 8 == 0
+        out = torch.empty(c // 8, r, pool, pool, 8, dtype=torch.float32, device=rois.device)
+    else:
+        out = torch.empty(r, pool, pool, c, dtype=torch.float32, device=rois.device)
     levels = torch.empty(r, dtype=torch.int32, device=rois.device) if return_levels else None
     ptrs = (c_vp * 4)(*[fm.data_ptr() for fm in feature_maps])
     hs = (c_i32 * 4)(*[fm.size(1) for fm in feature_maps])
     ws = (c_i32 * 4)(*[fm.size(2) for fm in feature_maps])
     if roi_batch is not None:
         assert roi_batch.dtype == torch.int32 and roi_batch.is_contiguous()
-    check(lib.mrcnn_roi_align_pyramid_nhwc_f32(ptrs, hs, ws, b, c, rois.data_ptr(), _ptr(roi_batch), r,
-                                               int(rois_per_image or 0), int(pool),
-                                               float(image_area), out.data_ptr(), _ptr(levels),
-                                               _stream()))
+    check(lib.mrcnn_roi_align_pyramid_f32(ptrs, hs, ws, b, c, rois.data_ptr(), _ptr(roi_batch), r,
+                                          int(rois_per_image or 0), int(pool), float(image_area), out.data_ptr(),
+                                          1 if out_kblocked else 0, _ptr(levels), _stream()))
     return (out, levels) if return_levels else out
 
 
@@ -358,18 +362,22 @@ def same_pad(size_a: int, size_b: int, kernel: int, stride: int):
 
 
 @_on_device
-def maxpool(x: torch.Tensor, kernel: int, stride: int, pad=(0, 0, 0, 0)) -> torch.Tensor:
+def maxpool(x: torch.Tensor, kernel: int, stride: int, pad=(0, 0, 0, 0), out_kblocked: bool = False) -> torch.Tensor:
     """Zero-padded max-pool on NHWC fp32 (stem pool: kernel 3, stride 2, pad = same_pad(H, W, 3, 2);
-    P6: kernel 1, stride 2)."""
+    P6: kernel 1, stride 2). out_kblocked=True writes [C/8,B,OH,OW,8] (P6 for the RPN's Winograd conv)."""
     _need_gpu(x)
     assert x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 4
     b, h, w, c = x.shape
     pt, pl, pb, pr = [int(v) for v in pad]
     oh = (h + pt + pb - kernel) // stride + 1
     ow = (w + pl + pr - kernel) // stride + 1
-    y = torch.empty(b, oh, ow, c, dtype=torch.float32, device=x.device)
-    check(lib.mrcnn_maxpool_nhwc_f32(x.data_ptr(), b, h, w, c, int(kernel), int(stride), pt, pl, pb, pr,
-                                     y.data_ptr(), _stream()))
+    if out_kblocked:
+        assert c % 8 == 0
+        y = torch.empty(c // 8, b, oh, ow, 8, dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty(b, oh, ow, c, dtype=torch.float32, device=x.device)
+    check(lib.mrcnn_maxpool_f32(x.data_ptr(), b, h, w, c, int(kernel), int(stride), pt, pl, pb, pr, y.data_ptr(),
+                                1 if out_kblocked else 0, _stream()))
     return y
 
 

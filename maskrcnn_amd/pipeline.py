@@ -124,7 +124,7 @@ class MaskRCNNInference:
             # the reference divides all four coordinates by h (model.py:1188), which is only right for
             # square inputs; here (y,x) are divided by (h,w)
             mp = ops.roi_align_pyramid(fms[:4], mrois.view(-1, 4), c.mask_pool_size, self.image_area,
-                                       rois_per_image=d)
+                                       rois_per_image=d, out_kblocked=self.mask.wants_kblocked(c.mask_pool_size))
             m = self.mask(mp)
             masks = m.view(b, d, m.size(1), m.size(2), m.size(3))
         det = Detections(ids, det_scores, boxes, counts, masks)

@@ -421,3 +421,20 @@ def test_device_guard(dev):
     assert torch.equal(y1.cpu(), y0.cpu())
     with pytest.raises(RuntimeError, match="different devices"):
         ops.conv_bn_act(x, w.to(dev), None, None, 1, (1, 1, 1, 1))
+
+
+def test_kblocked_outputs_of_roialign_and_maxpool(dev):
+    """RoIAlign and max-pool can write the layout the Winograd kernel reads ([C/8][pixels][8]): bit-identical to the
+    NHWC result passed through nhwc_to_kblocked (no kblock_kernel launch in the step)."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(91)
+    fms = [torch.randn(2, 128 // s, 160 // s, 64, generator=g).to(dev) for s in (4, 8, 16, 32)]
+    rois = _rand_boxes(g, 2 * 37, 0.05, 0.7).to(dev)
+    a = ops.roi_align_pyramid(fms, rois, 14, 128.0 * 160.0, rois_per_image=37)
+    k = ops.roi_align_pyramid(fms, rois, 14, 128.0 * 160.0, rois_per_image=37, out_kblocked=True)
+    assert tuple(k.shape) == (8, 74, 14, 14, 8)
+    assert torch.equal(k, ops.nhwc_to_kblocked(a))
+    x = torch.randn(3, 10, 12, 32, generator=g).to(dev)
+    for kern, stride, pad in ((1, 2, (0, 0, 0, 0)), (3, 2, (0, 0, 1, 1))):
+        assert torch.equal(ops.maxpool(x, kern, stride, pad, out_kblocked=True),
+                           ops.nhwc_to_kblocked(ops.maxpool(x, kern, stride, pad)))
