@@ -123,7 +123,8 @@ def conv_roofline(prof, args, H, W, modules):
                     and tj.get("image") == [H, W] and tj.get("arch") == args.arch
                     and tj.get("proposals") == args.proposals and tj.get("winograd") == bool(modules.WINOGRAD)
                     and tj.get("stem_kernel") == bool(modules.STEM_KERNEL)
-                    and tj.get("fused_bottleneck") == bool(getattr(modules, "FUSED_BOTTLENECK", False)))
+                    and tj.get("fused_bottleneck") == bool(getattr(modules, "FUSED_BOTTLENECK", False))
+                    and tj.get("rpn_fused_heads") == bool(getattr(modules, "RPN_FUSED_HEADS", False)))
             k = tj.get("per_kernel", {}).get(kernel_of.get(dominant, dominant))
             if same and k and k.get("launches_per_step") == dom["launches_per_step"]:
                 traffic = k["hbm_bytes_per_step"]

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 5
+#define MRCNN_ABI_VERSION 6
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -179,6 +179,29 @@ int mrcnn_deconv2x2_bias_act_nhwc_f16mfma(const float* x, int32_t batch, int32_t
                                           int32_t cin, const void* w_hi, const void* w_lo, int32_t cout,
                                           const float* bias4, int32_t activation, int32_t products, float* y,
                                           mrcnn_stream_t stream);
+
+/* The plain-fp16 mode (products = 1) with fp16 ACTIVATIONS in HBM — BASELINE configs[4]'s "fp16 MFMA path":
+ *   x_is_f16 / y_is_f16 choose the storage type of the input and of the output (and of the residual, which has the
+ *   output's type); at least one of them is set (fp32 both ways is mrcnn_conv_bn_act_nhwc_f16mfma). fp16 tensors are
+ *   NHWC like their fp32 counterparts. w_f16 = the fp16 weight plane [cout][kh][kw][cin]. Supported combinations:
+ *     fp32 → fp16   no residual, activation 0/1 (the stem, the first conv behind RoIAlign)
+ *     fp16 → fp16   residual (res_div 1 or 2) or none, activation 0/1; cin % 32 == 0
+ *     fp16 → fp32   no residual, activation 0/1/2 (FPN smoothing, RPN heads, the FC layers, the mask sigmoid)
+ *   cout must be even for an fp16 output (channel pairs are stored as 4-byte words). A conv that reads an fp16 tensor
+ *   sees exactly the operand the fp32-storage path rounds to, so only residual adds, pooling and stores differ.
+ * mrcnn_deconv2x2_bias_act_nhwc_f16io: the 2x2 stride-2 transposed conv, fp16 in and out.
+ * mrcnn_maxpool_nhwc_f16: the zero-padded max-pool on fp16 NHWC (channels % 8 == 0). */
+int mrcnn_conv_bn_act_nhwc_f16io(const void* x, int32_t x_is_f16, int32_t batch, int32_t height, int32_t width,
+                                 int32_t cin, const void* w_f16, int32_t cout, int32_t kh, int32_t kw, int32_t stride,
+                                 int32_t pad_top, int32_t pad_left, int32_t pad_bottom, int32_t pad_right,
+                                 const float* scale, const float* shift, const void* residual, int32_t res_div,
+                                 int32_t activation, void* y, int32_t y_is_f16, mrcnn_stream_t stream);
+int mrcnn_deconv2x2_bias_act_nhwc_f16io(const void* x_f16, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                        const void* w_f16, int32_t cout, const float* bias4, int32_t activation,
+                                        void* y_f16, mrcnn_stream_t stream);
+int mrcnn_maxpool_nhwc_f16(const void* x, int32_t batch, int32_t height, int32_t width, int32_t channels,
+                           int32_t kernel, int32_t stride, int32_t pad_top, int32_t pad_left, int32_t pad_bottom,
+                           int32_t pad_right, void* y, mrcnn_stream_t stream);
 
 /* Zero-padded max-pool, NHWC fp32: [batch][H][W][C] -> [batch][OH][OW][C], OH = (H+pad_top+pad_bottom-k)/s+1.
  * Covers the stem's SamePad2d(3,2) + MaxPool2d(3,2) (model.py:227-228; pads (0,1,0,1) on even sizes — the

@@ -42,6 +42,13 @@ _SIGS = {
     "mrcnn_conv_bn_act_nhwc_f16mfma": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32,
                                                         c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp,
                                                         c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "mrcnn_conv_bn_act_nhwc_f16io": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32,
+                                                      c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32,
+                                                      c_vp, c_i32, c_vp]),
+    "mrcnn_deconv2x2_bias_act_nhwc_f16io": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32,
+                                                             c_vp, c_vp]),
+    "mrcnn_maxpool_nhwc_f16": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                                c_vp, c_vp]),
     "mrcnn_deconv2x2_bias_act_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32,
                                                            c_vp, c_vp]),
     "mrcnn_deconv2x2_bias_act_nhwc_f16mfma": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32,

@@ -43,6 +43,42 @@ __global__ __launch_bounds__(256) void maxpool_nhwc(const float* __restrict__ x,
     }
 }
 
+// The same on fp16 NHWC (the fp16-activation mode of BASELINE config 5): one thread = one output pixel x 8 channels.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void maxpool_nhwc_f16(const _Float16* __restrict__ x, int B, int H, int W, int C, int k,
+                                                        int stride, int pt, int pl, int OH, int OW,
+                                                        _Float16* __restrict__ y) {
+    const int c8 = C >> 3;
+    const int64_t total = static_cast<int64_t>(B) * OH * OW * c8;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int c = static_cast<int>(e % c8) * 8;
+        int64_t pix = e / c8;
+        const int ox = static_cast<int>(pix % OW);
+        pix /= OW;
+        const int oy = static_cast<int>(pix % OH);
+        const int b = static_cast<int>(pix / OH);
+        h16x8 m;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = static_cast<_Float16>(-INFINITY);
+        for (int ky = 0; ky < k; ++ky) {
+            const int iy = oy * stride + ky - pt;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ix = ox * stride + kx - pl;
+                h16x8 v;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = static_cast<_Float16>(0.0f);  // F.pad(..., 'constant', 0)
+                if (static_cast<unsigned>(iy) < static_cast<unsigned>(H) &&
+                    static_cast<unsigned>(ix) < static_cast<unsigned>(W))
+                    v = *reinterpret_cast<const h16x8*>(x + ((static_cast<int64_t>(b) * H + iy) * W + ix) * C + c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) m[i] = v[i] > m[i] ? v[i] : m[i];
+            }
+        }
+        *reinterpret_cast<h16x8*>(y + ((static_cast<int64_t>(b) * OH + oy) * OW + ox) * C + c) = m;
+    }
+}
+
 // [B][C][HW] -> [B][HW][Cp] (channels zero-padded to Cp), 32x32 LDS tiles.
 __global__ __launch_bounds__(256) void nchw_to_nhwc(const float* __restrict__ x, int C, int HW, int Cp,
                                                     float* __restrict__ y) {
@@ -122,6 +158,26 @@ extern "C" int mrcnn_maxpool_f32(const float* x, int32_t batch, int32_t height, 
                        mrcnn::as_stream(stream), x, batch, height, width, channels, kernel, stride,
                        pad_top, pad_left, OH, OW, y, y_layout == MRCNN_LAYOUT_KBLOCKED ? 1 : 0);
     return mrcnn::check_launch("maxpool_nhwc");
+}
+
+extern "C" int mrcnn_maxpool_nhwc_f16(const void* x, int32_t batch, int32_t height, int32_t width, int32_t channels,
+                                      int32_t kernel, int32_t stride, int32_t pad_top, int32_t pad_left,
+                                      int32_t pad_bottom, int32_t pad_right, void* y, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x && y, "maxpool_f16: null pointer");
+    MRCNN_REQUIRE(batch >= 1 && height >= 1 && width >= 1 && channels >= 8 && channels % 8 == 0,
+                  "maxpool_f16: bad shape (channels %% 8 == 0 required)");
+    MRCNN_REQUIRE(kernel >= 1 && stride >= 1 && pad_top >= 0 && pad_left >= 0 && pad_bottom >= 0 && pad_right >= 0,
+                  "maxpool_f16: bad kernel/stride/pad");
+    const int OH = (height + pad_top + pad_bottom - kernel) / stride + 1;
+    const int OW = (width + pad_left + pad_right - kernel) / stride + 1;
+    MRCNN_REQUIRE(OH >= 1 && OW >= 1, "maxpool_f16: empty output");
+    const int64_t total = static_cast<int64_t>(batch) * OH * OW * (channels / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(maxpool_nhwc_f16, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, mrcnn::as_stream(stream),
+                       static_cast<const _Float16*>(x), batch, height, width, channels, kernel, stride, pad_top, pad_left,
+                       OH, OW, static_cast<_Float16*>(y));
+    return mrcnn::check_launch("maxpool_nhwc_f16");
 }
 
 extern "C" int mrcnn_maxpool_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,

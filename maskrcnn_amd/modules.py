@@ -172,6 +172,11 @@ FUSED_BOTTLENECK = os.environ.get("MRCNN_FUSED_BOTTLENECK", "0") == "1"
 # MRCNN_RPN_FUSED_HEADS=0 keeps the separate 18-channel head conv everywhere.
 RPN_FUSED_HEADS = os.environ.get("MRCNN_RPN_FUSED_HEADS", "1") != "0"
 RPN_HEADS_MIN_TILES = 64
+# "f16" mode (BASELINE config 5's fp16 MFMA path): activations are fp16 in HBM between convs — fp32 only at the boundary,
+# at the RoIAlign inputs (the smoothed pyramid) and at the head outputs. A conv reading an fp16 tensor sees exactly the
+# operand it would have rounded an fp32 tensor to; residual adds, the stem max-pool and the stores see fp16.
+# MRCNN_F16_ACT=0 keeps every activation fp32 (round 1's form of the mode).
+F16_ACT = os.environ.get("MRCNN_F16_ACT", "1") != "0"
 
 
 class ConvWeight:
@@ -210,7 +215,7 @@ class ConvWeight:
                 and relu in (False, True, 0, 1) and h % 2 == 0 and w % 2 == 0)
 
     def conv(self, x, scale, shift, stride=1, pad=(0, 0, 0, 0), relu=False, residual=None, res_div=1,
-             algo_cin=None, out="nhwc"):
+             algo_cin=None, out="nhwc", out_f16=False):
         """out: "nhwc" (default), or for the f32 mode "kblocked" / "both" (ops.conv3x3_winograd): the layout the next
         Winograd conv reads. x may itself be k-blocked (5-d) when this conv takes the Winograd kernel."""
         if self.precision == "f32":
@@ -222,14 +227,18 @@ class ConvWeight:
                                    algo_cin, out_kblocked=(out == "kblocked"))
         assert out == "nhwc"
         return ops.conv_bn_act_f16mfma(x, self.w_hi, self.w_lo, scale, shift, stride, pad, relu, residual,
-                                       res_div, 3 if self.precision == "f16x3" else 1, algo_cin)
+                                       res_div, 3 if self.precision == "f16x3" else 1, algo_cin,
+                                       out_f16=bool(out_f16) and self.precision == "f16")
 
 
 class FusedConv:
     """conv (+BN) (+ReLU) with SAME-style explicit padding, NHWC."""
 
     def __init__(self, sd, conv, bn, device, stride=1, relu=False, same_pad_kernel: int | None = None,
-                 pad=(0, 0, 0, 0), cin_pad=None, precision="f32"):
+                 pad=(0, 0, 0, 0), cin_pad=None, precision="f32", out_f16: bool | None = None):
+        # "f16" mode: the output is stored fp16 unless the layer says otherwise (out_f16=False: tensors that RoIAlign
+        # or the caller reads)
+        self.out_f16 = (precision == "f16" and F16_ACT) if out_f16 is None else (bool(out_f16) and precision == "f16" and F16_ACT)
         self.w = ConvWeight(pack_weight(sd[conv + ".weight"], device, cin_pad), precision)
         self.scale, self.shift = fold_bn(sd, conv, bn, device)
         self.stride, self.relu, self.same_k, self.pad = stride, relu, same_pad_kernel, pad
@@ -244,7 +253,7 @@ class FusedConv:
     def __call__(self, x, residual=None, res_div=1, out="nhwc"):
         hh, ww = (x.size(2), x.size(3)) if x.dim() == 5 else (x.size(1), x.size(2))
         return self.w.conv(x, self.scale, self.shift, self.stride, self.pad_for(hh, ww), self.relu, residual, res_div,
-                           self.algo_cin, out)
+                           self.algo_cin, out, self.out_f16)
 
 
 class FusedBottleneck:
@@ -345,7 +354,7 @@ class FusedBackbone:
         self.lateral = {k: FusedConv(sd, f"{prefix}P{k}_conv1", None, device, precision=precision)
                         for k in (5, 4, 3, 2)}
         self.smooth = {k: FusedConv(sd, f"{prefix}P{k}_conv2.1", None, device, same_pad_kernel=3,
-                                    precision=precision) for k in (5, 4, 3, 2)}
+                                    precision=precision, out_f16=False) for k in (5, 4, 3, 2)}   # RoIAlign reads these
 
     def __call__(self, image_nchw):
         x = ops.nchw_to_nhwc(image_nchw.contiguous(), self.cin_pad)   # 3 → 4 (8) channels, zero-padded
@@ -432,7 +441,7 @@ class FusedRPN:
                 return ops.conv3x3_winograd_heads(p_kblocked, self.shared.w.u, self.shared.scale, self.shared.shift,
                                                   self.w_head32, True, self.shared.algo_cin)
             p = p_kblocked
-        return self.w_head.conv(self.shared(p), None, self.b_head)
+        return self.w_head.conv(self.shared(p), None, self.b_head)   # fp32 out (the shared activation may be fp16)
 
 
 class FusedClassifier:
@@ -453,7 +462,7 @@ class FusedClassifier:
 
     def __call__(self, pooled):
         r = pooled.size(0)
-        x = self.w1.conv(pooled.view(r, 1, 1, -1), self.s1, self.t1, relu=True)
+        x = self.w1.conv(pooled.view(r, 1, 1, -1), self.s1, self.t1, relu=True, out_f16=self.conv2.out_f16)
         x = self.conv2(x)
         y = self.w_fc.conv(x, None, self.b_fc).view(r, -1)
         logits = y[:, :self.num_classes]
@@ -476,7 +485,7 @@ class FusedMask:
                                precision)
         self.b_de = sd[prefix + "deconv.bias"].float().repeat(4).contiguous().to(device)
         self.cout = cout
-        self.conv5 = FusedConv(sd, prefix + "conv5", None, device, relu=2, precision=precision)  # 2 = sigmoid
+        self.conv5 = FusedConv(sd, prefix + "conv5", None, device, relu=2, precision=precision, out_f16=False)  # 2 = sigmoid
 
     def wants_kblocked(self, pool: int) -> bool:
         """Would the four 3x3 convs run as a k-blocked Winograd chain on [R, pool, pool, 256] crops? Then RoIAlign can

@@ -304,11 +304,15 @@ def split_f16(w: torch.Tensor):
 def conv_bn_act_f16mfma(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor | None,
                         scale: torch.Tensor | None, shift: torch.Tensor | None, stride: int = 1,
                         pad=(0, 0, 0, 0), relu: bool = False, residual: torch.Tensor | None = None,
-                        res_div: int = 1, products: int = 3, algo_cin: int | None = None) -> torch.Tensor:
-    """conv_bn_act on fp16-operand MFMA. x/residual/y fp32 NHWC; w_hi/w_lo fp16 OHWI planes (split_f16).
-    products = 1: plain fp16 operands; products = 3: error-compensated split (fp32-grade accuracy)."""
+                        res_div: int = 1, products: int = 3, algo_cin: int | None = None,
+                        out_f16: bool = False) -> torch.Tensor:
+    """conv_bn_act on fp16-operand MFMA. w_hi/w_lo fp16 OHWI planes (split_f16).
+    products = 3: error-compensated split (fp32-grade accuracy); x / residual / y fp32 NHWC.
+    products = 1: plain fp16 operands; x may be fp32 or fp16 NHWC, y is fp16 when out_f16 (the residual has y's type):
+    the fp16-activation form of BASELINE config 5's "fp16 MFMA path"."""
     _need_gpu(x, w_hi, w_lo, scale, shift, residual)
-    assert x.dtype == torch.float32 and w_hi.dtype == torch.float16 and x.is_contiguous() and w_hi.is_contiguous()
+    x_f16 = x.dtype == torch.float16
+    assert (x_f16 or x.dtype == torch.float32) and w_hi.dtype == torch.float16 and x.is_contiguous() and w_hi.is_contiguous()
     assert w_lo is None or (w_lo.dtype == torch.float16 and w_lo.is_contiguous() and w_lo.shape == w_hi.shape)
     b, h, wd, cin = x.shape
     cout, kh, kw, wcin = w_hi.shape
@@ -317,21 +321,31 @@ def conv_bn_act_f16mfma(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor 
     pt, pl, pb, pr = [int(v) for v in pad]
     oh = (h + pt + pb - kh) // stride + 1
     ow = (wd + pl + pr - kw) // stride + 1
-    out = torch.empty(b, oh, ow, cout, dtype=torch.float32, device=x.device)
+    io16 = x_f16 or out_f16
+    if io16 and products != 1:
+        raise RuntimeError("conv_bn_act_f16mfma: fp16 activations belong to the plain-fp16 mode (products = 1)")
+    out = torch.empty(b, oh, ow, cout, dtype=torch.float16 if out_f16 else torch.float32, device=x.device)
     if residual is not None:
         assert residual.is_contiguous() and tuple(residual.shape) == (b, oh // res_div, ow // res_div, cout)
+        assert residual.dtype == out.dtype, "the residual has the output's storage type"
     prof = CONV_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.mrcnn_conv_bn_act_nhwc_f16mfma(x.data_ptr(), b, h, wd, cin, w_hi.data_ptr(), _ptr(w_lo), cout,
-                                             kh, kw, int(stride), pt, pl, pb, pr, _ptr(scale), _ptr(shift),
-                                             _ptr(residual), int(res_div), int(relu), int(products),
-                                             out.data_ptr(), _stream()))
+    if io16:
+        check(lib.mrcnn_conv_bn_act_nhwc_f16io(x.data_ptr(), 1 if x_f16 else 0, b, h, wd, cin, w_hi.data_ptr(), cout, kh,
+                                               kw, int(stride), pt, pl, pb, pr, _ptr(scale), _ptr(shift), _ptr(residual),
+                                               int(res_div), int(relu), out.data_ptr(), 1 if out_f16 else 0, _stream()))
+    else:
+        check(lib.mrcnn_conv_bn_act_nhwc_f16mfma(x.data_ptr(), b, h, wd, cin, w_hi.data_ptr(), _ptr(w_lo), cout,
+                                                 kh, kw, int(stride), pt, pl, pb, pr, _ptr(scale), _ptr(shift),
+                                                 _ptr(residual), int(res_div), int(relu), int(products),
+                                                 out.data_ptr(), _stream()))
     if prof is not None:
         e1.record()
         m, k = b * oh * ow, kh * kw * (algo_cin or cin)
-        nbytes = 4 * (x.numel() + out.numel() + (residual.numel() if residual is not None else 0)) + \
+        nbytes = x.numel() * x.element_size() + out.numel() * out.element_size() + \
+            (residual.numel() * residual.element_size() if residual is not None else 0) + \
             2 * w_hi.numel() * (2 if products == 3 else 1)
         prof.append((e0, e1, 2.0 * m * k * cout, (m, cout, k), nbytes, "f16"))
     return out
@@ -366,11 +380,17 @@ def maxpool(x: torch.Tensor, kernel: int, stride: int, pad=(0, 0, 0, 0), out_kbl
     """Zero-padded max-pool on NHWC fp32 (stem pool: kernel 3, stride 2, pad = same_pad(H, W, 3, 2);
     P6: kernel 1, stride 2). out_kblocked=True writes [C/8,B,OH,OW,8] (P6 for the RPN's Winograd conv)."""
     _need_gpu(x)
-    assert x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 4
+    assert x.is_contiguous() and x.dtype in (torch.float32, torch.float16) and x.dim() == 4
     b, h, w, c = x.shape
     pt, pl, pb, pr = [int(v) for v in pad]
     oh = (h + pt + pb - kernel) // stride + 1
     ow = (w + pl + pr - kernel) // stride + 1
+    if x.dtype == torch.float16:
+        assert not out_kblocked
+        y = torch.empty(b, oh, ow, c, dtype=torch.float16, device=x.device)
+        check(lib.mrcnn_maxpool_nhwc_f16(x.data_ptr(), b, h, w, c, int(kernel), int(stride), pt, pl, pb, pr, y.data_ptr(),
+                                         _stream()))
+        return y
     if out_kblocked:
         assert c % 8 == 0
         y = torch.empty(c // 8, b, oh, ow, 8, dtype=torch.float32, device=x.device)
@@ -643,12 +663,12 @@ def deconv2x2(x: torch.Tensor, w, bias4: torch.Tensor, activation: int = 0, prod
     scattering into [B,2H,2W,Cout]. w: fp32 [4*Cout,1,1,Cin] (products = 0) or the (w_hi, w_lo) fp16 planes of it
     (products = 1 or 3); bias4 [4*Cout]."""
     _need_gpu(x, bias4)
-    assert x.is_contiguous() and x.dtype == torch.float32 and bias4.is_contiguous()
+    assert x.is_contiguous() and x.dtype in (torch.float32, torch.float16) and bias4.is_contiguous()
     b, h, wd, cin = x.shape
     w0 = w if products == 0 else w[0]
     cout = w0.size(0) // 4
     assert w0.size(3) == cin and bias4.numel() == 4 * cout
-    y = torch.empty(b, 2 * h, 2 * wd, cout, dtype=torch.float32, device=x.device)
+    y = torch.empty(b, 2 * h, 2 * wd, cout, dtype=x.dtype, device=x.device)
     prof = CONV_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -657,6 +677,10 @@ def deconv2x2(x: torch.Tensor, w, bias4: torch.Tensor, activation: int = 0, prod
         assert w.dtype == torch.float32 and w.is_contiguous()
         check(lib.mrcnn_deconv2x2_bias_act_nhwc_f32(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout,
                                                     bias4.data_ptr(), int(activation), y.data_ptr(), _stream()))
+    elif x.dtype == torch.float16:   # fp16 activations: plain-fp16 mode only
+        assert products == 1
+        check(lib.mrcnn_deconv2x2_bias_act_nhwc_f16io(x.data_ptr(), b, h, wd, cin, w[0].data_ptr(), cout, bias4.data_ptr(),
+                                                      int(activation), y.data_ptr(), _stream()))
     else:
         w_hi, w_lo = w
         check(lib.mrcnn_deconv2x2_bias_act_nhwc_f16mfma(x.data_ptr(), b, h, wd, cin, w_hi.data_ptr(), _ptr(w_lo),
@@ -666,7 +690,7 @@ def deconv2x2(x: torch.Tensor, w, bias4: torch.Tensor, activation: int = 0, prod
         e1.record()
         m = b * h * wd
         prof.append((e0, e1, 2.0 * m * cin * 4 * cout, (m, 4 * cout, cin),
-                     4 * (x.numel() + y.numel()) + (4 if products == 0 else 2 * (2 if products == 3 else 1)) * w0.numel(),
+                     x.element_size() * (x.numel() + y.numel()) + (4 if products == 0 else 2 * (2 if products == 3 else 1)) * w0.numel(),
                      "direct" if products == 0 else "f16"))
     return y
 

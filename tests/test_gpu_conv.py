@@ -494,3 +494,71 @@ def test_winograd_fused_rpn_heads(dev, shape):
     s0, d0 = ops.rpn_scores_deltas(lv)
     s1, d1 = ops.rpn_scores_deltas([sums] + lv[1:], bh.to(dev))
     assert torch.equal(s0, s1) and torch.equal(d0, d1)
+
+
+# --------------------------------------------------------------------------------------------------
+# fp16 ACTIVATIONS in HBM (plain-fp16 mode, BASELINE config 5's "fp16 MFMA path")
+# --------------------------------------------------------------------------------------------------
+F16IO_CASES = [
+    # (B, H, W, Cin, Cout, k, stride, relu, residual(0/1/2), x16, y16)
+    (2, 16, 16, 64, 64, 1, 1, True, 0, True, True),
+    (2, 16, 16, 64, 256, 1, 1, True, 1, True, True),      # bottleneck conv3 + fp16 residual
+    (2, 16, 16, 256, 128, 1, 2, True, 0, True, True),     # stride 2
+    (1, 16, 16, 64, 64, 3, 1, True, 0, True, True),       # 3x3
+    (2, 16, 16, 1024, 256, 1, 1, False, 2, True, True),   # FPN lateral + half-size fp16 residual
+    (1, 32, 32, 256, 256, 3, 1, False, 0, True, False),   # FPN smoothing: fp16 in, fp32 out
+    (1, 16, 16, 256, 512, 3, 1, True, 0, False, True),    # RPN shared: fp32 in, fp16 out
+    (1, 16, 16, 512, 18, 1, 1, False, 0, True, False),    # RPN heads: fp16 in, fp32 out
+    (2, 64, 64, 8, 64, 7, 2, True, 0, False, True),       # stem (generic K), fp32 in, fp16 out
+    (37, 1, 1, 12544, 1024, 1, 1, True, 0, False, True),  # classifier conv1 as GEMM
+    (3, 13, 11, 32, 48, 3, 1, True, 1, True, True),       # ragged
+]
+
+
+@pytest.mark.parametrize("case", F16IO_CASES, ids=lambda c: "x".join(str(int(v)) for v in c))
+def test_conv_f16_activations_vs_torch_cpu(dev, case):
+    """The reference computes in fp32; the fp16-storage path is held to fp16's own resolution: against an fp32 torch-CPU
+    conv of the fp16-ROUNDED operands (exact products, fp32 sums) the result may differ by the summation order plus, for
+    an fp16 output, one rounding to 11 significand bits (2^-11 relative)."""
+    from maskrcnn_amd import ops
+    b, h, w, cin, cout, k, stride, relu, res, x16, y16 = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case))
+    pad = (3, 3, 3, 3) if k == 7 else (1, 1, 1, 1) if k == 3 else (0, 0, 0, 0)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * math.sqrt(2.0 / (cin * k * k))
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    oh = (h + pad[0] + pad[2] - k) // stride + 1
+    ow = (w + pad[1] + pad[3] - k) // stride + 1
+    residual = torch.randn(b, cout, oh // max(res, 1), ow // max(res, 1), generator=g).half() if res else None
+    want = _ref_conv(x.half().float(), wt.half().float(), scale, shift, stride, pad, relu,
+                     None if residual is None else residual.float(), max(res, 1))
+    to_nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    xd = to_nhwc(x.half() if x16 else x)
+    w_hi, _ = ops.split_f16(to_nhwc(wt))
+    got = ops.conv_bn_act_f16mfma(xd, w_hi, None, scale.to(dev), shift.to(dev), stride, pad, relu,
+                                  None if residual is None else to_nhwc(residual), max(res, 1), products=1, out_f16=y16)
+    assert got.dtype == (torch.float16 if y16 else torch.float32)
+    got = got.float().permute(0, 3, 1, 2).cpu()
+    tol = 2e-4 + (2.0 ** -11) * want.abs() if y16 else torch.full_like(want, 2e-4)
+    bad = ((got - want).abs() > tol).sum().item()
+    assert bad == 0, f"{bad} elements off; max abs err {(got - want).abs().max().item():.3e}"
+
+
+def test_maxpool_and_deconv_f16(dev):
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 13, 10, 64, generator=g).half().to(dev)
+    for kern, stride, pad in ((3, 2, (0, 0, 1, 1)), (1, 2, (0, 0, 0, 0))):
+        assert torch.equal(ops.maxpool(x, kern, stride, pad), ops.maxpool(x.float(), kern, stride, pad).half())
+    # 2x2 stride-2 transposed conv, fp16 in/out, against torch-CPU on the rounded operands
+    xi = torch.randn(3, 32, 7, 7, generator=g)
+    wt = torch.randn(32, 64, 2, 2, generator=g) * 0.1      # [Cin, Cout, 2, 2]
+    bias = torch.randn(64, generator=g) * 0.1
+    want = F.relu(F.conv_transpose2d(xi.half().float(), wt.half().float(), bias, stride=2))
+    w4 = wt.permute(2, 3, 1, 0).reshape(4 * 64, 1, 1, 32).contiguous().to(dev)
+    w_hi, _ = ops.split_f16(w4)
+    y = ops.deconv2x2(xi.half().permute(0, 2, 3, 1).contiguous().to(dev), (w_hi, None), bias.repeat(4).to(dev), 1, 1)
+    assert y.dtype == torch.float16 and tuple(y.shape) == (3, 14, 14, 64)
+    err = (y.float().permute(0, 3, 1, 2).cpu() - want).abs()
+    assert bool((err <= 2e-4 + 2.0 ** -11 * want.abs()).all()), err.max().item()

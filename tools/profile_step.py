@@ -60,7 +60,8 @@ def main():
     meta = {"predict_calls": calls[0], "precision": args.precision, "batch": args.batch, "image": [H, W],
             "arch": args.arch, "proposals": args.proposals, "winograd": bool(modules.WINOGRAD),
             "stem_kernel": bool(modules.STEM_KERNEL),
-            "fused_bottleneck": bool(getattr(modules, "FUSED_BOTTLENECK", False))}
+            "fused_bottleneck": bool(getattr(modules, "FUSED_BOTTLENECK", False)),
+            "rpn_fused_heads": bool(getattr(modules, "RPN_FUSED_HEADS", False))}
     if args.meta:
         with open(args.meta, "w") as fh:
             json.dump(meta, fh)
