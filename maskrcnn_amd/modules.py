@@ -159,8 +159,8 @@ WINOGRAD = os.environ.get("MRCNN_WINOGRAD", "1") != "0"
 # MRCNN_STEM_KERNEL=0 sends it through the generic implicit-GEMM kernel.
 STEM_KERNEL = os.environ.get("MRCNN_STEM_KERNEL", "1") != "0"
 # f32 Winograd mode: with MRCNN_FUSED_BOTTLENECK=1 the stride-1 identity Bottlenecks with planes = 64 (ResNet C2 blocks
-# 1, 2) run as ONE launch of the whole-block kernel (csrc/bottleneck.hip; bit-identical to the three-launch path, half its
-# HBM traffic). Off by default: at batch 8 x 256^2 x 256 it measures 0.735 ms per block against 0.704 ms for the three
+# 1, 2) run as ONE launch of the whole-block kernel (csrc/bottleneck.hip; bit-identical to the three-launch path, 0.8x its
+# fabric traffic). Off by default: at batch 8 x 256^2 x 256 it measures 0.735 ms per block against 0.704 ms for the three
 # launches — one workgroup per CU runs its three GEMM phases back to back, so nothing overlaps the
 # HBM-bound conv3 epilogue, while the per-layer kernels overlap five workgroups per CU there.
 FUSED_BOTTLENECK = os.environ.get("MRCNN_FUSED_BOTTLENECK", "0") == "1"
