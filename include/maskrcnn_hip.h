@@ -58,7 +58,7 @@ const char* mrcnn_arch(void);
  *               NULL: one LDS-resident workgroup per segment does everything (one launch, no scratch).
  *               Given (and n_max > 128): the pair tests are spread over the whole chip (sort → 64x64 pair-mask
  *               tiles → serial scan), 3 launches, several times faster at n_max >= 500. Same results.
- * Limits: 1 <= n_max <= mrcnn_nms_max_boxes().  S >= 1.
+ * Limits: 1 <= n_max <= mrcnn_nms_max_boxes() = 16384 with a workspace, 4096 without.  S >= 1.
  * ---------------------------------------------------------------------------------------------- */
 int64_t mrcnn_nms_max_boxes(void);
 size_t mrcnn_nms_workspace_bytes(int32_t num_segments, int64_t n_max);

@@ -370,7 +370,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsWs ws, float thr) {
 }
 
 // grid = S, block = 256. LDS: mask rows (when they fit) + keep flags.
-template <bool MASK_IN_LDS>
+// NQ: 64-bit removed-set words per lane of the scanning wave (1: up to 64 chunks = 4096 boxes; 4: up to 16384)
+template <bool MASK_IN_LDS, int NQ = 1>
 __global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs ws, int64_t n_max,
                                                        const int32_t* __restrict__ seg_counts,
                                                        int64_t* __restrict__ keep_out,
@@ -398,12 +399,19 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs ws, int64_t n_max,
     __syncthreads();
     const u64* mk = MASK_IN_LDS ? lmask : gmask;
     if (wave == 0) {
-        u64 remv = 0;  // lane w: removed bits of boxes [64w, 64w+63]
+        // lane w holds the removed bits of chunks w, w + 64, w + 128, w + 192 (up to 256 chunks = 16384 boxes)
+        u64 remv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) remv[q] = 0;
         for (int c = 0; c < nchunks; ++c) {
             const int p = c * 64 + lane;
             const u64 dc = dcol[p];  // earlier boxes of this chunk that would suppress box p
-            const u32 r_lo = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(remv)), c));
-            const u32 r_hi = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(remv >> 32)), c));
+            const int cq = c >> 6, cl = c & 63;  // uniform
+            u64 rsel = remv[0];
+#pragma unroll
+            for (int q = 1; q < NQ; ++q) rsel = cq == q ? remv[q] : rsel;
+            const u32 r_lo = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(rsel)), cl));
+            const u32 r_hi = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(rsel >> 32)), cl));
             const u64 removed = (static_cast<u64>(r_hi) << 32) | r_lo;
             const u64 validm = (n - c * 64 >= 64) ? ~0ull : ((1ull << (n - c * 64)) - 1ull);
             const u64 alive = ~removed & validm;
@@ -419,22 +427,26 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs ws, int64_t n_max,
                 kept = next;
             }
             if (lane == 0) keptw[c] = kept;
-            // survivors of this chunk remove later boxes: lane w ORs word w of every surviving row
-            if (lane > c && lane < nb) {
-                u64 acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-                const u64* rowp = mk + (static_cast<int64_t>(c) * 64) * nb + lane;
+            // survivors of this chunk remove later boxes: lane w ORs words w + 64 q of every surviving row
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int word = lane + 64 * q;
+                if (word > c && word < nb) {
+                    u64 acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+                    const u64* rowp = mk + (static_cast<int64_t>(c) * 64) * nb + word;
 #pragma unroll 4
-                for (int i = 0; i < 64; i += 4) {
-                    const u64 v0 = rowp[static_cast<int64_t>(i) * nb];
-                    const u64 v1 = rowp[static_cast<int64_t>(i + 1) * nb];
-                    const u64 v2 = rowp[static_cast<int64_t>(i + 2) * nb];
-                    const u64 v3 = rowp[static_cast<int64_t>(i + 3) * nb];
-                    acc0 |= ((kept >> i) & 1ull) ? v0 : 0ull;
-                    acc1 |= ((kept >> (i + 1)) & 1ull) ? v1 : 0ull;
-                    acc2 |= ((kept >> (i + 2)) & 1ull) ? v2 : 0ull;
-                    acc3 |= ((kept >> (i + 3)) & 1ull) ? v3 : 0ull;
+                    for (int i = 0; i < 64; i += 4) {
+                        const u64 v0 = rowp[static_cast<int64_t>(i) * nb];
+                        const u64 v1 = rowp[static_cast<int64_t>(i + 1) * nb];
+                        const u64 v2 = rowp[static_cast<int64_t>(i + 2) * nb];
+                        const u64 v3 = rowp[static_cast<int64_t>(i + 3) * nb];
+                        acc0 |= ((kept >> i) & 1ull) ? v0 : 0ull;
+                        acc1 |= ((kept >> (i + 1)) & 1ull) ? v1 : 0ull;
+                        acc2 |= ((kept >> (i + 2)) & 1ull) ? v2 : 0ull;
+                        acc3 |= ((kept >> (i + 3)) & 1ull) ? v3 : 0ull;
+                    }
+                    remv[q] |= acc0 | acc1 | acc2 | acc3;
                 }
-                remv |= acc0 | acc1 | acc2 | acc3;
             }
         }
     }
@@ -484,6 +496,8 @@ template <int CAP, int T>
 int launch_sort(const float* dets, int32_t S, int64_t n_max, int64_t seg_stride, int64_t row_stride,
                 int64_t col_stride, const int32_t* seg_counts, const int32_t* class_ids, NmsWs ws,
                 hipStream_t stream) {
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(nms_sort_kernel<CAP, T>), sizeof(u64) * CAP, "nms"))
+        return rc;
     hipLaunchKernelGGL((nms_sort_kernel<CAP, T>), dim3(S), dim3(T), sizeof(u64) * CAP, stream, dets, n_max,
                        seg_stride, row_stride, col_stride, seg_counts, class_ids, ws);
     return mrcnn::check_launch("nms_sort_kernel");
@@ -513,10 +527,13 @@ size_t ws_layout(int32_t S, int64_t n_max, void* base, NmsWs* ws) {
 
 }  // namespace
 
-extern "C" int64_t mrcnn_nms_max_boxes(void) { return 4096; }
+// With a workspace: 16384 boxes per segment (the scan keeps its removed-set as one 64-bit word per lane of a 256-thread
+// workgroup: 256 x 64; the sort holds 8-byte keys in LDS: 128 KB). Without: the single-launch path, 4096.
+constexpr int64_t NMS_MAX_WS = 16384, NMS_MAX_LDS = 4096;
+extern "C" int64_t mrcnn_nms_max_boxes(void) { return NMS_MAX_WS; }
 
 extern "C" size_t mrcnn_nms_workspace_bytes(int32_t num_segments, int64_t n_max) {
-    if (num_segments < 1 || n_max < 1 || n_max > mrcnn_nms_max_boxes()) return 0;
+    if (num_segments < 1 || n_max < 1 || n_max > NMS_MAX_WS) return 0;
     return ws_layout(num_segments, n_max, nullptr, nullptr);
 }
 
@@ -527,9 +544,9 @@ extern "C" int mrcnn_nms_batched_f32(const float* dets, int32_t num_segments, in
                                      void* workspace, size_t workspace_bytes, mrcnn_stream_t stream) {
     MRCNN_REQUIRE(dets && keep_out && counts_out, "nms: null pointer");
     MRCNN_REQUIRE(num_segments >= 1, "nms: num_segments=%d must be >= 1", num_segments);
-    MRCNN_REQUIRE(n_max >= 1 && n_max <= mrcnn_nms_max_boxes(),
-                  "nms: n_max=%lld outside [1, %lld] (on-chip path)", (long long)n_max,
-                  (long long)mrcnn_nms_max_boxes());
+    MRCNN_REQUIRE(n_max >= 1 && n_max <= ((workspace && n_max > 128) ? NMS_MAX_WS : NMS_MAX_LDS),
+                  "nms: n_max=%lld outside [1, %lld] (%lld with a workspace)", (long long)n_max, (long long)NMS_MAX_LDS,
+                  (long long)NMS_MAX_WS);
     hipStream_t s = mrcnn::as_stream(stream);
     if (workspace && n_max > 128) {
         // ---- path 2: sort → pair mask over the whole chip → serial scan ------------------------------
@@ -546,9 +563,15 @@ extern "C" int mrcnn_nms_batched_f32(const float* dets, int32_t num_segments, in
         else if (n_max <= 2048)
             rc = launch_sort<2048, 1024>(dets, num_segments, n_max, seg_stride, row_stride, col_stride,
                                          seg_counts, class_ids, ws, s);
-        else
+        else if (n_max <= 4096)
             rc = launch_sort<4096, 1024>(dets, num_segments, n_max, seg_stride, row_stride, col_stride,
                                          seg_counts, class_ids, ws, s);
+        else if (n_max <= 8192)
+            rc = launch_sort<8192, 1024>(dets, num_segments, n_max, seg_stride, row_stride, col_stride,
+                                         seg_counts, class_ids, ws, s);
+        else
+            rc = launch_sort<16384, 1024>(dets, num_segments, n_max, seg_stride, row_stride, col_stride,
+                                          seg_counts, class_ids, ws, s);
         if (rc) return rc;
         hipLaunchKernelGGL(nms_mask_kernel, dim3(ws.nb * (ws.nb + 1) / 2, num_segments), dim3(64), 0, s, ws,
                            threshold);
@@ -560,9 +583,13 @@ extern "C" int mrcnn_nms_batched_f32(const float* dets, int32_t num_segments, in
             if ((rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds_full, "nms"))) return rc;
             hipLaunchKernelGGL(k, dim3(num_segments), dim3(256), lds_full, s, ws, n_max, seg_counts, keep_out,
                                counts_out);
-        } else {
+        } else if (ws.nb <= 64) {
             hipLaunchKernelGGL(nms_scan_kernel<false>, dim3(num_segments), dim3(256), tail, s, ws, n_max,
                                seg_counts, keep_out, counts_out);
+        } else {
+            auto k4 = nms_scan_kernel<false, 4>;
+            if ((rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(k4), tail, "nms"))) return rc;
+            hipLaunchKernelGGL(k4, dim3(num_segments), dim3(256), tail, s, ws, n_max, seg_counts, keep_out, counts_out);
         }
         return mrcnn::check_launch("nms_scan_kernel");
     }

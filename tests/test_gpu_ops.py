@@ -58,18 +58,20 @@ def test_nms_random_vs_oracle(dev, oracle):
     import maskrcnn
     from maskrcnn_amd import ops
     g = torch.Generator().manual_seed(7)
-    for n in (1, 5, 64, 65, 255, 256, 257, 777, 1000, 1024, 1025, 2048, 3000, 4096):
+    for n in (1, 5, 64, 65, 255, 256, 257, 777, 1000, 1024, 1025, 2048, 3000, 4096, 6000, 16384):
         for thr in (0.3, 0.7):
             d = _rand_dets(g, n)
             want = oracle.nms(d, thr)
             got = maskrcnn.nms(d.to(dev), thr).cpu()
             assert torch.equal(got, want), (n, thr)
-            # both device paths: chip-wide pair mask (workspace) and the single-launch LDS kernel
-            for ws in (True, False):
+            # both device paths: chip-wide pair mask (workspace, up to 16384 boxes) and the single-launch LDS kernel (4096)
+            for ws in ((True, False) if n <= 4096 else (True,)):
                 keep, cnt = ops.nms_batched(d.to(dev).unsqueeze(0), thr, use_workspace=ws)
                 assert torch.equal(keep[0, :int(cnt[0])].cpu(), want), (n, thr, ws)
     with pytest.raises(RuntimeError):
-        maskrcnn.nms(_rand_dets(g, 5000).to(dev), 0.5)  # beyond the on-chip path: loud, not wrong
+        maskrcnn.nms(_rand_dets(g, 16385).to(dev), 0.5)  # beyond the workspace path: loud, not wrong
+    with pytest.raises(RuntimeError):
+        ops.nms_batched(_rand_dets(g, 5000).to(dev).unsqueeze(0), 0.5, use_workspace=False)
 
 
 def test_nms_ties_and_specials(dev, oracle):
