@@ -667,6 +667,267 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32(const WinoParams p) 
     }  // tiles
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Spatial-tile variant (round 2): the same 64 positions x 64 channels x 16 components per workgroup, eight waves, two
+// components per wave — but the 64 positions are an 8 x 8 block of ONE image (16 x 16 output pixels), and the
+// transformed input V is never staged: two thirds of the linear-tile kernel's patch loads fetch pixels that neighbouring
+// positions fetch again (64 x 16 patch pixels for an 18 x 18 = 324-pixel footprint).
+//   staging     per k tile of 8 channels the RAW 18 x 18 x 8 input region (10 KB: at most two 16-byte loads per thread)
+//               and the 32 KB block of U (four per thread) go through registers into LDS, double-buffered: 6 loads per
+//               thread and k tile instead of 16 (V role) / 8 (U role).
+//   transform   an MFMA A-operand register is one position x one channel per lane, so every lane transforms its OWN
+//               position out of the raw region: its wave's two components need 2 rows x 3 columns of the 4 x 4 patch —
+//               six 16-byte LDS reads (the lane half picks the channel quad) and 10 packed adds per 16 MFMAs. The pixel
+//               pitch is 12 floats: the reads are 2-way bank-conflicted at best (positions sit on even pixels).
+//   pipeline    order pinned as in the kernels above; see the slot table at the main loop.
+//   everything else (U layout, MFMA order, accumulators, A^T M A rounds, stores) is the linear kernel's, so the result is
+//   bit-identical to it.
+constexpr int RPIX = 12;                       // floats per raw pixel in LDS (8 channels + pad)
+constexpr int RROW = 18 * RPIX;                // floats per raw row
+constexpr int RAW_FLOATS = 18 * RROW + 8;      // one buffer (3896 floats, 16-byte multiple)
+constexpr size_t WINOS_LDS = WINO_LDS;         // the epilogue's Z exchange (128 KiB) is the high-water mark
+
+struct WinoSParams : WinoParams {
+    int tyb, txb;  // 8 x 8-position blocks per image along y / x
+};
+
+__global__ __launch_bounds__(512, 1) void conv3x3_wino8s_f32(const WinoSParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Rs = smem;                         // [2][RAW_FLOATS]
+    float* Us = smem + 2 * RAW_FLOATS;        // [2][16][2 quads][64][4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+    const int nk = (p.Cin + WK - 1) / WK;
+    const int total_tiles = 8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        int mt, n0;
+        {
+            const int xcd = tile & 7, seq = tile >> 3;
+            const int mt_lo = (xcd * p.tiles_m) >> 3, mt_hi = ((xcd + 1) * p.tiles_m) >> 3;
+            mt = mt_lo + seq / p.tiles_n;
+            if (mt >= mt_hi) continue;  // uniform
+            n0 = (seq % p.tiles_n) * WN;
+        }
+        const int per_img = p.tyb * p.txb;
+        const int b = mt / per_img, trem = mt - b * per_img;
+        const int tyb = trem / p.txb, txb = trem - tyb * p.txb;
+        const int ty0 = tyb * 8, tx0 = txb * 8;          // first tile position of the block
+        const int iy0 = 2 * ty0 - 1, ix0 = 2 * tx0 - 1;  // first raw input pixel (may be -1: zero padding)
+
+        // ---- staging offsets: raw float4 ids tid and tid + 512 (648 in all: 324 pixels x 2 channel quads), U slots
+        unsigned r_off[2], u_off[4];
+        int r_lds[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 512 * i, px = id >> 1, q = id & 1;
+            const int hy = (px * 57) >> 10, hx = px - hy * 18;  // px / 18 for px < 512
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = id < 648 && static_cast<unsigned>(iy) < static_cast<unsigned>(p.H) &&
+                            static_cast<unsigned>(ix) < static_cast<unsigned>(p.W);
+            r_off[i] = ok ? static_cast<unsigned>(((b * p.H + iy) * p.W + ix) * WK + q * 4) * 4u : OOB;
+            r_lds[i] = hy * RROW + hx * RPIX + q * 4;
+        }
+        const bool r1 = tid + 512 < 648;  // wave-uniform for waves 0 and 1, false for waves 3-7; wave 2 mixed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + 512 * i;
+            const int xi = id >> 7, r = id & 127, q = r >> 6, ch = r & 63;
+            const int n = n0 + ch;
+            u_off[i] = n < p.Cout ? static_cast<unsigned>((xi * p.Cout + n) * WK + q * 4) * 4u : OOB;
+        }
+        auto plane_of = [&](int kt) { return static_cast<unsigned>(kt < nk ? kt : nk - 1); };
+        u32x4 rr[2], ru[4];
+        // pieces of a k tile: 0,1 = raw region, 2..5 = U
+        auto load_piece = [&](int pc, int kt) {
+            const unsigned pl = plane_of(kt);
+            if (pc < 2) rr[pc] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(r_off[pc]), static_cast<int>(pl * p.x_plane), 0);
+            else ru[pc - 2] = __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, static_cast<int>(u_off[pc - 2]), static_cast<int>(pl * p.u_plane), 0);
+        };
+        auto store_piece = [&](int pc, int buf) {
+            if (pc == 0) *reinterpret_cast<u32x4*>(Rs + buf * RAW_FLOATS + r_lds[0]) = rr[0];
+            else if (pc == 1) { if (r1) *reinterpret_cast<u32x4*>(Rs + buf * RAW_FLOATS + r_lds[1]) = rr[1]; }
+            else *reinterpret_cast<u32x4*>(Us + buf * 16 * PLANE + (tid + 512 * (pc - 2)) * 4) = ru[pc - 2];
+        };
+
+        // wave = (i, jh): components xi = 4 i + 2 jh + {0, 1}; transform row i combines patch rows (ra, rb) as ra + rs rb
+        const int wi = wave >> 1, jh = wave & 1;
+        const int row_a = wi == 0 ? 0 : wi == 2 ? 2 : 1;
+        const int row_b = wi == 0 ? 2 : wi == 1 ? 2 : wi == 2 ? 1 : 3;
+        const float rs = wi == 1 ? 1.0f : -1.0f;
+        int pbase[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int pos = a * 32 + ln, py = pos >> 3, px = pos & 7;
+            pbase[a] = 2 * py * RROW + (2 * px + jh) * RPIX + 4 * lh;  // columns jh, jh+1, jh+2 of the patch
+        }
+        const int offA = row_a * RROW, offB = row_b * RROW;
+        const float* Bw = Us + (wave * 2) * PLANE + lh * (WN * 4) + ln * 4;
+
+        f32x16 acc[2][2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[j][a][c][r] = 0.f;
+
+        // patch pieces of position half a: d[0..2] = row A columns 0..2, d[3..5] = row B
+        float4 d[6], av[2][2], fb[2][2];
+        auto patch_read = [&](int i, int buf, int a) {
+            d[i] = *reinterpret_cast<const float4*>(Rs + buf * RAW_FLOATS + pbase[a] + (i < 3 ? offA : offB) + (i % 3) * RPIX);
+        };
+        auto row_pass = [&](int cc) {  // l[cc] = dA + rs * dB, in place of d[cc]
+            d[cc] = make_float4(fmaf(d[3 + cc].x, rs, d[cc].x), fmaf(d[3 + cc].y, rs, d[cc].y),
+                                fmaf(d[3 + cc].z, rs, d[cc].z), fmaf(d[3 + cc].w, rs, d[cc].w));
+        };
+        auto col_pass = [&](int a) {
+            if (jh == 0) {  // columns 0,1,2: components j = 0: t0 - t2, j = 1: t1 + t2
+                av[0][a] = make_float4(d[0].x - d[2].x, d[0].y - d[2].y, d[0].z - d[2].z, d[0].w - d[2].w);
+                av[1][a] = make_float4(d[1].x + d[2].x, d[1].y + d[2].y, d[1].z + d[2].z, d[1].w + d[2].w);
+            } else {        // columns 1,2,3: components j = 2: t2 - t1, j = 3: t1 - t3
+                av[0][a] = make_float4(d[1].x - d[0].x, d[1].y - d[0].y, d[1].z - d[0].z, d[1].w - d[0].w);
+                av[1][a] = make_float4(d[0].x - d[2].x, d[0].y - d[2].y, d[0].z - d[2].z, d[0].w - d[2].w);
+            }
+        };
+        auto fb_read = [&](int j, int buf) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                fb[j][c] = *reinterpret_cast<const float4*>(Bw + buf * 16 * PLANE + j * PLANE + c * 32 * 4);
+        };
+
+        // prologue: k tile 0 in buffer 0, k tile 1 in flight, the first operands (position half 0, component pair j = 0)
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) load_piece(pc, 0);
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) store_piece(pc, 0);
+#pragma unroll
+        for (int pc = 0; pc < 6; ++pc) load_piece(pc, 1);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) patch_read(i, 0, 0);
+        fb_read(0, 0);
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) row_pass(cc);
+        col_pass(0);
+        // ---- main loop, order pinned (sched_barrier after every MFMA); 32 MFMAs per k tile and wave:
+        //   slots  0-15  position half 0 (j = 0: 0-7, j = 1: 8-15): fb[1] of this k tile, the six patch reads of half 1
+        //                (one per slot), their transform (slots 8-11), the six LDS writes of k tile kt+1 (10-15)
+        //   slots 16-31  position half 1: the six global loads of k tile kt+2 (16-21); the barrier sits after slot 23, then
+        //                fb[0] and the patch reads of half 0 of k tile kt+1 (24-29) and their transform (30-31) — the
+        //                next k tile starts with its operands in registers.
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int stp = 0; stp < 4; ++stp)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const float4 fav = av[j][a], fbv = fb[j][c];
+                            const float avv = stp == 0 ? fav.x : stp == 1 ? fav.y : stp == 2 ? fav.z : fav.w;
+                            const float bvv = stp == 0 ? fbv.x : stp == 1 ? fbv.y : stp == 2 ? fbv.z : fbv.w;
+                            acc[j][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv, bvv, acc[j][a][c], 0, 0, 0);
+                            const int m = a * 16 + j * 8 + stp * 2 + c;  // slot 0..31
+                            if (m == 0) fb_read(1, buf);
+                            if (m < 6) patch_read(m, buf, 1);
+                            if (m >= 8 && m < 11) row_pass(m - 8);
+                            if (m == 11) col_pass(1);
+                            if (m >= 10 && m < 16) store_piece(m - 10, buf ^ 1);
+                            if (m >= 16 && m < 22) load_piece(m - 16, kt + 2);
+                            if (m == 23) {
+                                __syncthreads();  // k tile kt+1 is complete in buf^1; nobody reads buf any more
+                                fb_read(0, buf ^ 1);
+                            }
+                            if (m >= 24 && m < 30) patch_read(m - 24, buf ^ 1, 0);
+                            if (m == 30) { row_pass(0); row_pass(1); row_pass(2); }
+                            if (m == 31) col_pass(0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+        }
+        __syncthreads();  // the behind-the-barrier operand reads of a k tile that does not exist are done
+
+        // ---- epilogue: as the linear kernel's, positions decoded from the 8 x 8 block
+        const int n = n0 + (tid & 63);
+        const bool n_ok = n < p.Cout;
+        const float sc = (n_ok && p.scale) ? p.scale[n] : 1.0f, sh = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yk_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.yk, 0, p.y_bytes, 0x00020000);
+        const unsigned ncol = n_ok ? static_cast<unsigned>(n) * 4u : OOB;
+        const unsigned kcol = static_cast<unsigned>(n >> 3) * p.yk_plane + static_cast<unsigned>(n & 7) * 4u;
+        float* Z = smem;  // [wave][2 partials][8 position quads][64 channels][4 positions]
+        constexpr int ZQ = 8 * WN * 4;
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            if (h) __syncthreads();  // (h = 0: the barrier behind the main loop)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int pq = 2 * rq + lh, ch = c * 32 + ln;
+                    float4 zp, zq;
+                    float* zpp = &zp.x;
+                    float* zqp = &zq.x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = rq * 4 + e;
+                        const float ma = h == 0 ? acc[0][0][c][r] : acc[0][1][c][r];
+                        const float mb = h == 0 ? acc[1][0][c][r] : acc[1][1][c][r];
+                        zpp[e] = jh == 0 ? ma + mb : ma;
+                        zqp[e] = jh == 0 ? mb : -ma - mb;
+                    }
+                    *reinterpret_cast<float4*>(Z + (wave * 2 + 0) * ZQ + (pq * WN + ch) * 4) = zp;
+                    *reinterpret_cast<float4*>(Z + (wave * 2 + 1) * ZQ + (pq * WN + ch) * 4) = zq;
+                }
+            __syncthreads();
+            const int pq = tid >> 6, ch = tid & 63;
+            float4 y0[4], y1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 p0 = *reinterpret_cast<const float4*>(Z + ((2 * i) * 2 + 0) * ZQ + (pq * WN + ch) * 4);
+                const float4 p1 = *reinterpret_cast<const float4*>(Z + ((2 * i + 1) * 2 + 0) * ZQ + (pq * WN + ch) * 4);
+                const float4 q0 = *reinterpret_cast<const float4*>(Z + ((2 * i) * 2 + 1) * ZQ + (pq * WN + ch) * 4);
+                const float4 q1 = *reinterpret_cast<const float4*>(Z + ((2 * i + 1) * 2 + 1) * ZQ + (pq * WN + ch) * 4);
+                y0[i] = make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
+                y1[i] = make_float4(q0.x + q1.x, q0.y + q1.y, q0.z + q1.z, q0.w + q1.w);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pos = h * 32 + pq * 4 + e;  // uniform per wave
+                const int ty = ty0 + (pos >> 3), tx = tx0 + (pos & 7);
+                const bool pv = ty < p.TH && tx < p.TW;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float z0 = c == 0 ? (&y0[0].x)[e] : (&y1[0].x)[e], z1 = c == 0 ? (&y0[1].x)[e] : (&y1[1].x)[e];
+                    const float z2 = c == 0 ? (&y0[2].x)[e] : (&y1[2].x)[e], z3 = c == 0 ? (&y0[3].x)[e] : (&y1[3].x)[e];
+                    const float yv[2] = {z0 + z1 + z2, z1 - z2 - z3};
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        float v = yv[a] * sc + sh;
+                        if (p.act) v = v > 0.f ? v : 0.f;
+                        const unsigned px = static_cast<unsigned>((b * p.H + 2 * ty + a) * p.W + 2 * tx + c);
+                        if (p.y) {
+                            const unsigned o = (pv && n_ok) ? px * (static_cast<unsigned>(p.Cout) * 4u) + ncol : OOB;
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(o), 0, 0);
+                        }
+                        if (p.yk) {
+                            const unsigned o = (pv && n_ok) ? kcol + px * 32u : OOB;
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yk_rsrc, static_cast<int>(o), 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // Z is read out: the next tile may overwrite the staging buffers
+    }
+}
+
 // U_xi[n][c] = (G g G^T)[i][j], xi = 4i + j, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; evaluated in double; stored
 // k-blocked [Cin/8][16][Cout][8] so that a k tile's 16 x 64 x 8 block is sixteen contiguous 2 KB runs.
 __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, int cout, int cin,
@@ -780,6 +1041,25 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
     MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd: grid too large");
     for (const void* f : {reinterpret_cast<const void*>(conv3x3_wino_f32), reinterpret_cast<const void*>(conv3x3_wino8_f32<false>)})
         if (int rc = mrcnn::ensure_dynamic_lds(f, WINO_LDS, "conv3x3_winograd")) return rc;
+    // spatial-tile kernel (8 x 8 position blocks of one image): MRCNN_WINO_SPATIAL=1, for maps of at least 8 x 8 positions
+    static const bool spatial_on = getenv("MRCNN_WINO_SPATIAL") && atoi(getenv("MRCNN_WINO_SPATIAL")) == 1;
+    if (spatial_on && p.TH >= 8 && p.TW >= 8) {
+        WinoSParams q;
+        static_cast<WinoParams&>(q) = p;
+        q.tyb = (p.TH + 7) / 8;
+        q.txb = (p.TW + 7) / 8;
+        q.tiles_m = batch * q.tyb * q.txb;
+        const long long sgrid = 8LL * ((q.tiles_m + 7) / 8) * q.tiles_n;
+        MRCNN_REQUIRE(sgrid <= 0x7fffffffLL, "conv3x3_winograd: grid too large");
+        if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wino8s_f32), WINOS_LDS, "conv3x3_winograd"))
+            return rc;
+        const int cus = mrcnn::device_cu_count();
+        if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd: cannot query the device");
+        const int ncu = cus >= 8 ? (cus / 8) * 8 : 8;
+        const long long launch = sgrid > ncu ? ncu : sgrid;
+        hipLaunchKernelGGL(conv3x3_wino8s_f32, dim3(static_cast<unsigned>(launch)), dim3(512), WINOS_LDS, st, q);
+        return mrcnn::check_launch("conv3x3_wino8s_f32");
+    }
     static const bool four_waves = getenv("MRCNN_WINO_WAVES") && atoi(getenv("MRCNN_WINO_WAVES")) == 4;
     if (four_waves)
         hipLaunchKernelGGL(conv3x3_wino_f32, dim3(static_cast<unsigned>(grid)), dim3(256), WINO_LDS, st, p);

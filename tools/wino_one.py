@@ -1,15 +1,15 @@
-"""Profiling aid: run the Winograd kernel on one P2-level layer (8 x 256 x 256, 256 -> 256) a few times."""
+"""Tuning aid: run the Winograd kernel a few times on the P2 RPN layer (for rocprofv3 --pmc passes)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from maskrcnn_amd import ops
 dev = "cuda:0"
 g = torch.Generator().manual_seed(0)
-x = torch.randn(8, 256, 256, 256, generator=g).to(dev)
-wt = (torch.randn(256, 3, 3, 256, generator=g) * 0.02).to(dev)
+b, h, w, cin, cout = 8, 256, 256, 256, 512
+x = ops.nhwc_to_kblocked(torch.randn(b, h, w, cin, generator=g).to(dev))
+wt = (torch.randn(cout, 3, 3, cin, generator=g) * 0.02).to(dev)
 u = ops.winograd_weights(wt)
-sh = torch.zeros(256, device=dev)
-for _ in range(3):
-    y = ops.conv3x3_winograd(x, u, None, sh, relu=True)
+sh = torch.zeros(cout, device=dev)
+for _ in range(4):
+    ops.conv3x3_winograd(x, u, None, sh, relu=True)
 torch.cuda.synchronize()
-print(float(y.abs().mean()))
