@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 6
+#define MRCNN_ABI_VERSION 7
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -289,6 +289,11 @@ int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int32_t batch, 
                                int32_t cin, const float* u, int32_t cout, const float* scale, const float* shift,
                                int32_t activation, float* y_nhwc, float* y_kblocked, void* workspace,
                                size_t workspace_bytes, mrcnn_stream_t stream);
+/* Tile shape of mrcnn_conv3x3_winograd_f32 on maps of at least 8 x 8 tile positions: 1 (default) = 8 x 8 position blocks of
+ * one image with the input transform done per lane out of a raw LDS region (conv3x3_wino8s_f32), 0 = 64 consecutive
+ * positions with a staged transform (conv3x3_wino8_f32), -1 = back to the default / MRCNN_WINO_SPATIAL. Same results bit
+ * for bit; a process-wide tuning switch, not per stream. */
+int mrcnn_winograd_set_spatial(int32_t on);
 int mrcnn_conv_bn_act_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin, const float* w,
                           int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad_top, int32_t pad_left,
                           int32_t pad_bottom, int32_t pad_right, const float* scale, const float* shift,

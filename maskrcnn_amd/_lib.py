@@ -70,6 +70,7 @@ _SIGS = {
     "mrcnn_detection_decode_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
                                                     ctypes.POINTER(c_f32), c_f32, c_f32, c_f32, c_vp, c_vp, c_vp,
                                                     c_vp]),
+    "mrcnn_winograd_set_spatial": (ctypes.c_int, [c_i32]),
     "mrcnn_winograd_weights_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "mrcnn_conv3x3_winograd_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32]),
     "mrcnn_conv3x3_winograd_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32,

@@ -984,6 +984,13 @@ __global__ __launch_bounds__(256) void kblock_kernel(const float* __restrict__ x
 
 }  // namespace
 
+static int g_spatial = -1;  // -1: not decided yet (environment), 0 / 1: linear / spatial tiles for large maps
+
+extern "C" int mrcnn_winograd_set_spatial(int32_t on) {
+    g_spatial = on < 0 ? -1 : (on ? 1 : 0);
+    return MRCNN_OK;
+}
+
 extern "C" int mrcnn_winograd_weights_f32(const float* w, int32_t cout, int32_t cin, float* u, mrcnn_stream_t stream) {
     MRCNN_REQUIRE(w && u, "winograd_weights: null pointer");
     MRCNN_REQUIRE(cout >= 1 && cin >= 1 && 16LL * cout * cin < (1LL << 30), "winograd_weights: cout=%d cin=%d", cout, cin);
@@ -1041,9 +1048,10 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
     MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd: grid too large");
     for (const void* f : {reinterpret_cast<const void*>(conv3x3_wino_f32), reinterpret_cast<const void*>(conv3x3_wino8_f32<false>)})
         if (int rc = mrcnn::ensure_dynamic_lds(f, WINO_LDS, "conv3x3_winograd")) return rc;
-    // spatial-tile kernel (8 x 8 position blocks of one image): MRCNN_WINO_SPATIAL=1, for maps of at least 8 x 8 positions
-    static const bool spatial_on = getenv("MRCNN_WINO_SPATIAL") && atoi(getenv("MRCNN_WINO_SPATIAL")) == 1;
-    if (spatial_on && p.TH >= 8 && p.TW >= 8) {
+    // spatial-tile kernel (8 x 8 position blocks of one image) for maps of at least 8 x 8 positions — the default;
+    // MRCNN_WINO_SPATIAL=0 (or mrcnn_winograd_set_spatial(0)) keeps the linear-tile kernel everywhere. Same results bit for bit.
+    if (g_spatial < 0) g_spatial = (getenv("MRCNN_WINO_SPATIAL") && atoi(getenv("MRCNN_WINO_SPATIAL")) == 0) ? 0 : 1;
+    if (g_spatial == 1 && p.TH >= 8 && p.TW >= 8) {
         WinoSParams q;
         static_cast<WinoParams&>(q) = p;
         q.tyb = (p.TH + 7) / 8;

@@ -818,6 +818,12 @@ def paste_masks(masks: torch.Tensor, class_ids: torch.Tensor, boxes: torch.Tenso
 # --------------------------------------------------------------------------------------------------
 # Winograd F(2x2,3x3) 3x3 stride-1 SAME conv (csrc/conv_wino.hip)
 # --------------------------------------------------------------------------------------------------
+def winograd_set_spatial(on: int) -> None:
+    """Process-wide tuning switch: 1 = spatial-tile Winograd kernel on large maps (default), 0 = linear-tile kernel
+    everywhere, -1 = default / MRCNN_WINO_SPATIAL. Results are bit-identical either way."""
+    check(lib.mrcnn_winograd_set_spatial(int(on)))
+
+
 @_on_device
 def winograd_weights(w_ohwi: torch.Tensor) -> torch.Tensor:
     """[Cout,3,3,Cin] fp32 → the transformed filter G g G^T (evaluated in double), 16*Cout*Cin floats in the

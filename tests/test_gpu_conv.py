@@ -283,6 +283,34 @@ def test_conv3x3_winograd_matches_direct_kernel_full_size(dev):
         assert torch.equal(y, ops.conv3x3_winograd(x, u, None, sh, True))
 
 
+def test_winograd_spatial_and_linear_tiles_are_bit_identical(dev):
+    """The two Winograd kernels (8 x 8 position blocks with a per-lane transform out of a raw LDS region; 64 consecutive
+    positions with a staged transform) use the same transforms, MFMA order and epilogue: equal bit for bit, on full and
+    ragged maps (positions not a multiple of 8), NHWC and k-blocked inputs and outputs."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(404)
+    try:
+        for (b, h, w, cin, cout) in ((2, 32, 48, 64, 64), (1, 128, 128, 256, 256), (3, 20, 36, 24, 72), (1, 16, 16, 512, 128)):
+            x = torch.randn(b, h, w, cin, generator=g).to(dev)
+            wt = (torch.randn(cout, 3, 3, cin, generator=g) * math.sqrt(2.0 / (9 * cin))).to(dev)
+            sc, sh = (torch.rand(cout, generator=g) + 0.5).to(dev), (torch.randn(cout, generator=g) * 0.1).to(dev)
+            u = ops.winograd_weights(wt)
+            xk = ops.nhwc_to_kblocked(x)
+            outs = []
+            for mode in (1, 0):
+                ops.winograd_set_spatial(mode)
+                y = ops.conv3x3_winograd(x, u, sc, sh, True)
+                outs.append((y, ops.conv3x3_winograd(xk, u, sc, sh, True, out="both" if cout % 8 == 0 else "nhwc")))
+            (ys, ks), (yl, kl) = outs
+            assert torch.equal(ys, yl), (b, h, w, cin, cout)
+            if cout % 8 == 0:
+                assert torch.equal(ks[0], kl[0]) and torch.equal(ks[1], kl[1]) and torch.equal(ks[0], ys)
+            else:
+                assert torch.equal(ks, kl)
+    finally:
+        ops.winograd_set_spatial(-1)
+
+
 def test_conv3x3_winograd_bad_arguments(dev):
     from maskrcnn_amd import ops
     from maskrcnn_amd._lib import MaskrcnnHipError
