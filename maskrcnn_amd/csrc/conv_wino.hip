@@ -781,17 +781,26 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8s_f32(const WinoSParams p
         auto patch_read = [&](int i, int buf, int a) {
             d[i] = *reinterpret_cast<const float4*>(Rs + buf * RAW_FLOATS + pbase[a] + (i < 3 ? offA : offB) + (i % 3) * RPIX);
         };
+        // packed arithmetic: one VALU issue per channel pair (VALU does not co-execute with this MFMA: every issue counts)
+        const f32x2 rs2 = {rs, rs};
+        auto lo2 = [](const float4& v) { return f32x2{v.x, v.y}; };
+        auto hi2 = [](const float4& v) { return f32x2{v.z, v.w}; };
+        auto pk_fma = [](f32x2 a, f32x2 b, f32x2 c) {
+            f32x2 r;
+            asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+            return r;
+        };
+        auto join = [](f32x2 lo, f32x2 hi) { return make_float4(lo.x, lo.y, hi.x, hi.y); };
         auto row_pass = [&](int cc) {  // l[cc] = dA + rs * dB, in place of d[cc]
-            d[cc] = make_float4(fmaf(d[3 + cc].x, rs, d[cc].x), fmaf(d[3 + cc].y, rs, d[cc].y),
-                                fmaf(d[3 + cc].z, rs, d[cc].z), fmaf(d[3 + cc].w, rs, d[cc].w));
+            d[cc] = join(pk_fma(lo2(d[3 + cc]), rs2, lo2(d[cc])), pk_fma(hi2(d[3 + cc]), rs2, hi2(d[cc])));
         };
         auto col_pass = [&](int a) {
             if (jh == 0) {  // columns 0,1,2: components j = 0: t0 - t2, j = 1: t1 + t2
-                av[0][a] = make_float4(d[0].x - d[2].x, d[0].y - d[2].y, d[0].z - d[2].z, d[0].w - d[2].w);
-                av[1][a] = make_float4(d[1].x + d[2].x, d[1].y + d[2].y, d[1].z + d[2].z, d[1].w + d[2].w);
+                av[0][a] = join(pk_sub(lo2(d[0]), lo2(d[2])), pk_sub(hi2(d[0]), hi2(d[2])));
+                av[1][a] = join(pk_add(lo2(d[1]), lo2(d[2])), pk_add(hi2(d[1]), hi2(d[2])));
             } else {        // columns 1,2,3: components j = 2: t2 - t1, j = 3: t1 - t3
-                av[0][a] = make_float4(d[1].x - d[0].x, d[1].y - d[0].y, d[1].z - d[0].z, d[1].w - d[0].w);
-                av[1][a] = make_float4(d[0].x - d[2].x, d[0].y - d[2].y, d[0].z - d[2].z, d[0].w - d[2].w);
+                av[0][a] = join(pk_sub(lo2(d[1]), lo2(d[0])), pk_sub(hi2(d[1]), hi2(d[0])));
+                av[1][a] = join(pk_sub(lo2(d[0]), lo2(d[2])), pk_sub(hi2(d[0]), hi2(d[2])));
             }
         };
         auto fb_read = [&](int j, int buf) {
