@@ -829,8 +829,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8s_f32(const WinoSParams p
         //   slots 16-31  position half 1: the six global loads of k tile kt+2 (16-21); the barrier sits after slot 23, then
         //                fb[0] and the patch reads of half 0 of k tile kt+1 (24-29) and their transform (30-31) — the
         //                next k tile starts with its operands in registers.
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
+        // the k loop is unrolled by two so that the buffer index is a compile-time constant: every LDS address is then a
+        // per-thread base plus an instruction-immediate offset (no address VALU in the loop)
+        auto ktile = [&](auto bufc, int kt) {
+            constexpr int buf = decltype(bufc)::value;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -859,7 +861,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8s_f32(const WinoSParams p
                             if (m == 31) col_pass(0);
                             __builtin_amdgcn_sched_barrier(0);
                         }
+        };
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            ktile(std::integral_constant<int, 0>{}, kt);
+            ktile(std::integral_constant<int, 1>{}, kt + 1);
         }
+        if (kt < nk) ktile(std::integral_constant<int, 0>{}, kt);  // odd number of k tiles
         __syncthreads();  // the behind-the-barrier operand reads of a k tile that does not exist are done
 
         // ---- epilogue: as the linear kernel's, positions decoded from the 8 x 8 block
