@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 7
+#define MRCNN_ABI_VERSION 8
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -245,9 +245,8 @@ int mrcnn_rpn_level_fused_f32(const float* x, int32_t batch, int32_t height, int
 int mrcnn_rpn_scores_deltas_f32(const float* const heads[5], const int32_t level_hw[5], int32_t batch,
                                 float* scores, float* deltas, mrcnn_stream_t stream);
 /* The same with a per-level input form (level_mode[l]): 0 = NHWC [batch][H_l][W_l][18] head outputs as above;
- * 1 = the head sums of mrcnn_conv3x3_winograd_heads_f32: [2][rows][32] fp32 in position-major pixel order (row of pixel
- * (b,y,x) = ((b*H/2 + y/2)*W/2 + x/2)*4 + (y&1)*2 + (x&1), rows = mrcnn_conv3x3_winograd_heads_rows()), bias not yet
- * added: logits/deltas = (sum of the two k halves) + head_bias[c]. level_h/level_w: H_l, W_l. */
+ * 1 / 2 = the head sums of mrcnn_conv3x3_winograd_heads_f32 in tile mode 1 / 2: [2][rows][32] fp32 in that function's row
+ * order, bias not yet added: logits/deltas = (sum of the two k halves) + head_bias[c]. level_h/level_w: H_l, W_l. */
 int mrcnn_rpn_scores_deltas_v2_f32(const float* const heads[5], const int32_t level_h[5], const int32_t level_w[5],
                                    const int32_t level_mode[5], const float* head_bias, int32_t batch, float* scores,
                                    float* deltas, mrcnn_stream_t stream);
@@ -389,14 +388,20 @@ int mrcnn_paste_masks_u8(const float* masks, int64_t stride_n, int64_t stride_y,
  * multiplied by w_head32 ([32][cout]: rows 0..17 = conv_class (6) then conv_bbox (12) weights, other rows zero) while
  * on chip; a workgroup owns whole M tiles and adds the contribution of each of its cout/64 N tiles to the M tile's sums.
  *   x_kblocked  fp32 [cin/8][batch][H][W][8];  u = mrcnn_winograd_weights_f32 of the [cout][3][3][cin] filter
- *   head_part   fp32 [2][rows][32], rows = mrcnn_conv3x3_winograd_heads_rows(batch, H, W): the two k halves of the sums
- *               (without the head bias) in position-major pixel order — the input form 1 of
- *               mrcnn_rpn_scores_deltas_v2_f32. Fully overwritten; no zero-fill needed.
+ *   tile_mode   1: an M tile is 64 consecutive tile positions; 2: an 8 x 8 block of positions of one image (the faster
+ *               kernel; maps of at least 8 x 8 positions). mrcnn_conv3x3_winograd_heads_tile_mode(H, W) returns the
+ *               recommended one (follows mrcnn_winograd_set_spatial).
+ *   head_part   fp32 [2][rows][32], rows = mrcnn_conv3x3_winograd_heads_rows(batch, H, W, tile_mode): the two k halves of
+ *               the sums (without the head bias); row of pixel (b,y,x): mode 1 = ((b*H/2 + y/2)*W/2 + x/2)*4 + (y&1)*2 +
+ *               (x&1); mode 2 = mt*256 + ((y/2 & 7)*8 + (x/2 & 7))*4 + (y&1)*2 + (x&1) with mt the block index
+ *               (b*ceil(H/16) + y/16)*ceil(W/16) + x/16 — the input forms 1 / 2 of mrcnn_rpn_scores_deltas_v2_f32.
+ *               Fully overwritten; no zero-fill needed.
  *   H, W even; cin % 8 == 0; cout % 64 == 0. Deterministic (fixed summation order). */
-int64_t mrcnn_conv3x3_winograd_heads_rows(int32_t batch, int32_t height, int32_t width);
+int64_t mrcnn_conv3x3_winograd_heads_rows(int32_t batch, int32_t height, int32_t width, int32_t tile_mode);
+int32_t mrcnn_conv3x3_winograd_heads_tile_mode(int32_t height, int32_t width);
 int mrcnn_conv3x3_winograd_heads_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width, int32_t cin,
                                      const float* u, int32_t cout, const float* scale, const float* shift,
-                                     int32_t activation, const float* w_head32, float* head_part,
+                                     int32_t activation, const float* w_head32, int32_t tile_mode, float* head_part,
                                      mrcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

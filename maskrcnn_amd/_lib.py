@@ -62,9 +62,10 @@ _SIGS = {
                                                      c_vp, c_vp]),
     "mrcnn_rpn_scores_deltas_v2_f32": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                                         ctypes.POINTER(c_i32), c_vp, c_i32, c_vp, c_vp, c_vp]),
-    "mrcnn_conv3x3_winograd_heads_rows": (c_i64, [c_i32, c_i32, c_i32]),
+    "mrcnn_conv3x3_winograd_heads_rows": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "mrcnn_conv3x3_winograd_heads_tile_mode": (c_i32, [c_i32, c_i32]),
     "mrcnn_conv3x3_winograd_heads_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32,
-                                                          c_vp, c_vp, c_vp]),
+                                                          c_vp, c_i32, c_vp, c_vp]),
     "mrcnn_proposal_decode_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
                                                    ctypes.POINTER(c_f32), c_f32, c_f32, c_vp, c_vp]),
     "mrcnn_detection_decode_f32": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,

@@ -691,6 +691,9 @@ struct WinoSParams : WinoParams {
     int tyb, txb;  // 8 x 8-position blocks per image along y / x
 };
 
+// HEADS as in conv3x3_wino8_f32<true>: the output tile feeds the 1x1 heads on chip; a workgroup owns whole M tiles (8 x 8
+// position blocks) and walks their N tiles; head sums in M-tile-major rows: row = mt * 256 + (py * 8 + px) * 4 + a * 2 + c.
+template <bool HEADS>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino8s_f32(const WinoSParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Rs = smem;                         // [2][RAW_FLOATS]
@@ -702,14 +705,28 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8s_f32(const WinoSParams p
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
     const int nk = (p.Cin + WK - 1) / WK;
     const int total_tiles = 8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
-    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        int mt, n0;
+    for (int it = 0;; ++it) {
+        int mt, n0, nt;
         {
-            const int xcd = tile & 7, seq = tile >> 3;
+            // plain: virtual tile b, b + grid, ... in the XCD-aware (M tile, N tile) order. HEADS: M-tile units b, b + grid,
+            // ..., each walked over all its N tiles by this workgroup
+            const int tile = HEADS ? (blockIdx.x + (it / p.tiles_n) * gridDim.x) * p.tiles_n + it % p.tiles_n
+                                   : blockIdx.x + it * gridDim.x;
+            if (tile >= total_tiles) break;
+            int xcd, seq;
+            if constexpr (HEADS) {
+                const int unit = tile / p.tiles_n;
+                xcd = unit & 7;
+                seq = (unit >> 3) * p.tiles_n + (tile - unit * p.tiles_n);
+            } else {
+                xcd = tile & 7;
+                seq = tile >> 3;
+            }
             const int mt_lo = (xcd * p.tiles_m) >> 3, mt_hi = ((xcd + 1) * p.tiles_m) >> 3;
             mt = mt_lo + seq / p.tiles_n;
             if (mt >= mt_hi) continue;  // uniform
-            n0 = (seq % p.tiles_n) * WN;
+            nt = seq % p.tiles_n;
+            n0 = nt * WN;
         }
         const int per_img = p.tyb * p.txb;
         const int b = mt / per_img, trem = mt - b * per_img;
@@ -880,6 +897,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8s_f32(const WinoSParams p
         const unsigned kcol = static_cast<unsigned>(n >> 3) * p.yk_plane + static_cast<unsigned>(n & 7) * 4u;
         float* Z = smem;  // [wave][2 partials][8 position quads][64 channels][4 positions]
         constexpr int ZQ = 8 * WN * 4;
+        // HEADS (see conv3x3_wino8_f32<true>): the round's 128 pixels x 64 channels transposed above the Z exchange
+        float* Tt = smem + 2 * 2 * 16 * PLANE;
+        const int hrt = wave & 3, hkh = wave >> 2;
+        float4 wh[4];
+        int ln_e = ln, lh_e = lh, tid_e = tid;  // opaque copies: keep the heads epilogue's address arithmetic behind the loop
+        if constexpr (HEADS) {
+            asm volatile("" : "+v"(ln_e), "+v"(lh_e), "+v"(tid_e));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wh[j] = *reinterpret_cast<const float4*>(p.w_head + static_cast<int64_t>(ln_e) * p.Cout + n0 + hkh * 32 + j * 8 + lh_e * 4);
+        }
+        const __amdgpu_buffer_rsrc_t hp_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.head_part, 0, HEADS ? p.head_bytes : 0u, 0x00020000);
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
             if (h) __syncthreads();  // (h = 0: the barrier behind the main loop)
@@ -928,6 +957,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8s_f32(const WinoSParams p
                     for (int a = 0; a < 2; ++a) {
                         float v = yv[a] * sc + sh;
                         if (p.act) v = v > 0.f ? v : 0.f;
+                        if constexpr (HEADS) {
+                            const int pxl = ((tid_e >> 6) * 4 + e) * 4 + a * 2 + c;  // position-major pixel of the round
+                            Tt[pxl * WN + ((tid_e & 63) ^ ((pxl & 15) << 2))] = v;
+                            continue;
+                        }
                         const unsigned px = static_cast<unsigned>((b * p.H + 2 * ty + a) * p.W + 2 * tx + c);
                         if (p.y) {
                             const unsigned o = (pv && n_ok) ? px * (static_cast<unsigned>(p.Cout) * 4u) + ncol : OOB;
@@ -939,6 +973,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8s_f32(const WinoSParams p
                         }
                     }
                 }
+            }
+            if constexpr (HEADS) {
+                __syncthreads();
+                const int row0 = mt * 256 + h * 128 + hrt * 32 + 4 * lh_e;  // + (r & 3) + 8 (r >> 2)
+                const unsigned hbase = (static_cast<unsigned>(hkh) * static_cast<unsigned>(p.tiles_m) * 256u + static_cast<unsigned>(row0)) * 128u +
+                                       static_cast<unsigned>(ln_e) * 4u;
+                f32x16 hacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    hacc[r] = 0.f;
+                    if (nt != 0)
+                        hacc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            hp_rsrc, static_cast<int>(hbase + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * 128u), 0, 0));
+                }
+                const int pxl = hrt * 32 + ln_e;
+                const float* trow = Tt + pxl * WN;
+                const int swz = (pxl & 15) << 2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(trow + ((hkh * 32 + j * 8 + lh_e * 4) ^ swz));
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, wh[j].x, hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, wh[j].y, hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, wh[j].z, hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, wh[j].w, hacc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hacc[r]), hp_rsrc,
+                                                          static_cast<int>(hbase + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * 128u), 0, 0);
             }
         }
         __syncthreads();  // Z is read out: the next tile may overwrite the staging buffers
@@ -1076,13 +1139,13 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
         q.tiles_m = batch * q.tyb * q.txb;
         const long long sgrid = 8LL * ((q.tiles_m + 7) / 8) * q.tiles_n;
         MRCNN_REQUIRE(sgrid <= 0x7fffffffLL, "conv3x3_winograd: grid too large");
-        if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wino8s_f32), WINOS_LDS, "conv3x3_winograd"))
+        if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wino8s_f32<false>), WINOS_LDS, "conv3x3_winograd"))
             return rc;
         const int cus = mrcnn::device_cu_count();
         if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd: cannot query the device");
         const int ncu = cus >= 8 ? (cus / 8) * 8 : 8;
         const long long launch = sgrid > ncu ? ncu : sgrid;
-        hipLaunchKernelGGL(conv3x3_wino8s_f32, dim3(static_cast<unsigned>(launch)), dim3(512), WINOS_LDS, st, q);
+        hipLaunchKernelGGL(conv3x3_wino8s_f32<false>, dim3(static_cast<unsigned>(launch)), dim3(512), WINOS_LDS, st, q);
         return mrcnn::check_launch("conv3x3_wino8s_f32");
     }
     static const bool four_waves = getenv("MRCNN_WINO_WAVES") && atoi(getenv("MRCNN_WINO_WAVES")) == 4;
@@ -1099,31 +1162,42 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
     return mrcnn::check_launch("conv3x3_wino_f32");
 }
 
-extern "C" int64_t mrcnn_conv3x3_winograd_heads_rows(int32_t batch, int32_t height, int32_t width) {
+// tile_mode: 1 = 64 consecutive positions per M tile (rows in position-major order), 2 = 8 x 8 position blocks
+extern "C" int64_t mrcnn_conv3x3_winograd_heads_rows(int32_t batch, int32_t height, int32_t width, int32_t tile_mode) {
     if (batch < 1 || height < 2 || width < 2 || height % 2 || width % 2) return 0;
-    const int64_t t = static_cast<int64_t>(batch) * (height / 2) * (width / 2);
-    return ((t + WT - 1) / WT) * 256;
+    const int64_t th = height / 2, tw = width / 2;
+    if (tile_mode == 2) return static_cast<int64_t>(batch) * ((th + 7) / 8) * ((tw + 7) / 8) * 256;
+    if (tile_mode != 1) return 0;
+    return ((static_cast<int64_t>(batch) * th * tw + WT - 1) / WT) * 256;
+}
+
+extern "C" int32_t mrcnn_conv3x3_winograd_heads_tile_mode(int32_t height, int32_t width) {
+    if (g_spatial < 0) g_spatial = (getenv("MRCNN_WINO_SPATIAL") && atoi(getenv("MRCNN_WINO_SPATIAL")) == 0) ? 0 : 1;
+    return (g_spatial == 1 && height / 2 >= 8 && width / 2 >= 8) ? 2 : 1;
 }
 
 extern "C" int mrcnn_conv3x3_winograd_heads_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width,
                                                 int32_t cin, const float* u, int32_t cout, const float* scale,
                                                 const float* shift, int32_t activation, const float* w_head32,
-                                                float* head_part, mrcnn_stream_t stream) {
+                                                int32_t tile_mode, float* head_part, mrcnn_stream_t stream) {
     MRCNN_REQUIRE(x_kblocked && u && w_head32 && head_part, "conv3x3_winograd_heads: null pointer");
     MRCNN_REQUIRE(batch >= 1 && height >= 2 && width >= 2 && height % 2 == 0 && width % 2 == 0,
                   "conv3x3_winograd_heads: B=%d H=%d W=%d (even sizes required)", batch, height, width);
     MRCNN_REQUIRE(cin >= 8 && cin % 8 == 0 && cout >= WN && cout % WN == 0,
                   "conv3x3_winograd_heads: Cin=%d (%% 8 == 0) Cout=%d (%% 64 == 0) required", cin, cout);
     MRCNN_REQUIRE(activation == 0 || activation == 1, "conv3x3_winograd_heads: activation must be 0 or 1");
+    MRCNN_REQUIRE(tile_mode == 1 || (tile_mode == 2 && height / 2 >= 8 && width / 2 >= 8),
+                  "conv3x3_winograd_heads: tile_mode must be 1, or 2 on maps of at least 8 x 8 tile positions");
     const long long px = 1LL * batch * height * width;
-    const long long rows = mrcnn_conv3x3_winograd_heads_rows(batch, height, width);
+    const long long rows = mrcnn_conv3x3_winograd_heads_rows(batch, height, width, tile_mode);
     MRCNN_REQUIRE(px * cin < (1LL << 30) && 16LL * cin * cout < (1LL << 30) && 2 * rows * 32 < (1LL << 30),
                   "conv3x3_winograd_heads: tensor too large (32-bit buffer byte offsets)");
-    WinoParams p;
+    WinoSParams p;
     p.x = x_kblocked; p.u = u; p.scale = scale; p.shift = shift; p.y = nullptr; p.yk = nullptr;
     p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout;
     p.TH = height / 2; p.TW = width / 2; p.T = batch * p.TH * p.TW; p.act = activation;
-    p.tiles_m = (p.T + WT - 1) / WT;
+    p.tyb = (p.TH + 7) / 8; p.txb = (p.TW + 7) / 8;
+    p.tiles_m = tile_mode == 2 ? batch * p.tyb * p.txb : (p.T + WT - 1) / WT;
     p.tiles_n = cout / WN;
     p.x_bytes = static_cast<unsigned>(4LL * px * cin);
     p.u_bytes = static_cast<unsigned>(4LL * 16 * cin * cout);
@@ -1132,16 +1206,20 @@ extern "C" int mrcnn_conv3x3_winograd_heads_f32(const float* x_kblocked, int32_t
     p.yk_plane = 0; p.y_bytes = 0;
     p.w_head = w_head32; p.head_part = head_part;
     p.head_bytes = static_cast<unsigned>(4LL * 2 * rows * 32);
-    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wino8_f32<true>), WINO_HEADS_LDS,
-                                           "conv3x3_winograd_heads"))
-        return rc;
+    const void* kern = tile_mode == 2 ? reinterpret_cast<const void*>(conv3x3_wino8s_f32<true>)
+                                      : reinterpret_cast<const void*>(conv3x3_wino8_f32<true>);
+    if (int rc = mrcnn::ensure_dynamic_lds(kern, WINO_HEADS_LDS, "conv3x3_winograd_heads")) return rc;
     const int cus = mrcnn::device_cu_count();
     if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd_heads: cannot query the device");
     const int num_cu = cus >= 8 ? (cus / 8) * 8 : 8;
     const long long units = 8LL * ((p.tiles_m + 7) / 8);  // M-tile units; a workgroup walks the N tiles of its units
     const long long launch = units < num_cu ? units : num_cu;
-    hipLaunchKernelGGL(conv3x3_wino8_f32<true>, dim3(static_cast<unsigned>(launch)), dim3(512), WINO_HEADS_LDS,
-                       mrcnn::as_stream(stream), p);
+    if (tile_mode == 2)
+        hipLaunchKernelGGL(conv3x3_wino8s_f32<true>, dim3(static_cast<unsigned>(launch)), dim3(512), WINO_HEADS_LDS,
+                           mrcnn::as_stream(stream), p);
+    else
+        hipLaunchKernelGGL(conv3x3_wino8_f32<true>, dim3(static_cast<unsigned>(launch)), dim3(512), WINO_HEADS_LDS,
+                           mrcnn::as_stream(stream), static_cast<const WinoParams&>(p));
     return mrcnn::check_launch("conv3x3_wino8_f32<heads>");
 }
 

@@ -264,7 +264,14 @@ __global__ __launch_bounds__(256) void rpn_scores_deltas(RpnLevels lv, int B, in
         } else {
             const int W = lv.w[l], H = lv.hw[l] / W;
             const int y = pix / W, x = pix - y * W;
-            const int64_t row = ((static_cast<int64_t>(b) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * 4 + (y & 1) * 2 + (x & 1);
+            int64_t row;
+            if (lv.mode[l] == 1) {  // 64 consecutive positions per M tile: plain position-major order
+                row = ((static_cast<int64_t>(b) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * 4 + (y & 1) * 2 + (x & 1);
+            } else {                // 8 x 8 position blocks: M-tile-major
+                const int ty = y >> 1, tx = x >> 1, tyb = ((H >> 1) + 7) >> 3, txb = ((W >> 1) + 7) >> 3;
+                const int64_t mt = (static_cast<int64_t>(b) * tyb + (ty >> 3)) * txb + (tx >> 3);
+                row = mt * 256 + (((ty & 7) << 3) + (tx & 7)) * 4 + (y & 1) * 2 + (x & 1);
+            }
             const float* p0 = lv.y[l] + row * 32;
             const float* p1 = p0 + static_cast<int64_t>(lv.rows[l]) * 32;
             const float* bs = lv.bias;
@@ -328,9 +335,10 @@ extern "C" int mrcnn_rpn_scores_deltas_v2_f32(const float* const heads[5], const
     lv.bias = head_bias;
     for (int l = 0; l < 5; ++l) {
         MRCNN_REQUIRE(heads[l] && level_h[l] >= 1 && level_w[l] >= 1, "rpn_scores_deltas: bad level %d", l);
-        MRCNN_REQUIRE(level_mode[l] == 0 || (level_mode[l] == 1 && head_bias && level_h[l] % 2 == 0 && level_w[l] % 2 == 0),
-                      "rpn_scores_deltas: level %d: mode must be 0 (NHWC heads) or 1 (position-major head sums: even H, W "
-                      "and a bias vector)", l);
+        MRCNN_REQUIRE(level_mode[l] == 0 || ((level_mode[l] == 1 || level_mode[l] == 2) && head_bias &&
+                                               level_h[l] % 2 == 0 && level_w[l] % 2 == 0),
+                      "rpn_scores_deltas: level %d: mode must be 0 (NHWC heads), 1 or 2 (head sums of "
+                      "mrcnn_conv3x3_winograd_heads_f32 in tile mode 1 / 2: even H, W and a bias vector)", l);
         lv.y[l] = heads[l];
         lv.hw[l] = level_h[l] * level_w[l];
         lv.w[l] = level_w[l];
@@ -338,7 +346,9 @@ extern "C" int mrcnn_rpn_scores_deltas_v2_f32(const float* const heads[5], const
         lv.rows[l] = 0;
         if (level_mode[l] == 1) {
             const int64_t t = static_cast<int64_t>(batch) * (level_h[l] / 2) * (level_w[l] / 2);
-            lv.rows[l] = static_cast<int>(((t + 63) / 64) * 256);  // == mrcnn_conv3x3_winograd_heads_rows()
+            lv.rows[l] = static_cast<int>(((t + 63) / 64) * 256);  // == mrcnn_conv3x3_winograd_heads_rows(.., 1)
+        } else if (level_mode[l] == 2) {
+            lv.rows[l] = batch * ((level_h[l] / 2 + 7) / 8) * ((level_w[l] / 2 + 7) / 8) * 256;
         }
         lv.first[l] = a;
         a += lv.hw[l] * 3;

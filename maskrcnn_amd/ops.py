@@ -490,20 +490,26 @@ class HeadSums:
     """Output of conv3x3_winograd_heads for one pyramid level: the two k halves of the 1x1-head sums (without bias) in
     position-major pixel order, [2, rows, 32] fp32, for a [B, H, W] level. Consumed by rpn_scores_deltas."""
 
-    def __init__(self, part: torch.Tensor, batch: int, height: int, width: int):
-        self.part, self.batch, self.height, self.width = part, batch, height, width
+    def __init__(self, part: torch.Tensor, batch: int, height: int, width: int, tile_mode: int = 1):
+        self.part, self.batch, self.height, self.width, self.tile_mode = part, batch, height, width, tile_mode
 
     def to_nhwc(self, bias: torch.Tensor) -> torch.Tensor:
         """[B,H,W,18] = (half 0 + half 1) + bias, in image order (tests / debugging; the pipeline never needs it)."""
         b, h, w = self.batch, self.height, self.width
-        t = b * (h // 2) * (w // 2)
-        v = (self.part[0, :t * 4, :18] + self.part[1, :t * 4, :18]) + bias
-        return v.view(b, h // 2, w // 2, 2, 2, 18).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, 18).contiguous()
+        th, tw = h // 2, w // 2
+        if self.tile_mode == 1:
+            t = b * th * tw
+            v = (self.part[0, :t * 4, :18] + self.part[1, :t * 4, :18]) + bias
+            return v.view(b, th, tw, 2, 2, 18).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, 18).contiguous()
+        tyb, txb = -(-th // 8), -(-tw // 8)
+        v = (self.part[0, :, :18] + self.part[1, :, :18]) + bias          # rows: (b, tyb, txb, py, px, a, c)
+        v = v.view(b, tyb, txb, 8, 8, 2, 2, 18).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(b, tyb * 16, txb * 16, 18)
+        return v[:, :h, :w].contiguous()
 
 
 @_on_device
 def conv3x3_winograd_heads(x_kblocked: torch.Tensor, u: torch.Tensor, scale, shift, w_head32: torch.Tensor,
-                           relu: bool = True, algo_cin=None) -> HeadSums:
+                           relu: bool = True, algo_cin=None, tile_mode: int | None = None) -> HeadSums:
     """RPN conv_shared + both 1x1 heads in one launch (model.py:605-607,624-641): relu(conv3x3_same(x)*scale + shift)
     stays on chip and is multiplied by w_head32 [32, Cout] (rows 0-17: conv_class then conv_bbox weights).
     x_kblocked [Cin/8,B,H,W,8]; u from winograd_weights. → HeadSums."""
@@ -512,14 +518,15 @@ def conv3x3_winograd_heads(x_kblocked: torch.Tensor, u: torch.Tensor, scale, shi
     g, b, h, w, _ = x_kblocked.shape
     cin, cout = g * 8, u.size(1)
     assert u.is_contiguous() and u.size(2) == cin and w_head32.is_contiguous() and tuple(w_head32.shape) == (32, cout)
-    rows = int(lib.mrcnn_conv3x3_winograd_heads_rows(b, h, w))
+    mode = int(lib.mrcnn_conv3x3_winograd_heads_tile_mode(h, w)) if tile_mode is None else int(tile_mode)
+    rows = int(lib.mrcnn_conv3x3_winograd_heads_rows(b, h, w, mode))
     part = torch.empty(2, rows, 32, dtype=torch.float32, device=x_kblocked.device)
     prof = CONV_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     check(lib.mrcnn_conv3x3_winograd_heads_f32(x_kblocked.data_ptr(), b, h, w, cin, u.data_ptr(), cout, _ptr(scale),
-                                               _ptr(shift), 1 if relu else 0, w_head32.data_ptr(), part.data_ptr(),
+                                               _ptr(shift), 1 if relu else 0, w_head32.data_ptr(), mode, part.data_ptr(),
                                                _stream()))
     if prof is not None:
         e1.record()
@@ -527,7 +534,7 @@ def conv3x3_winograd_heads(x_kblocked: torch.Tensor, u: torch.Tensor, scale, shi
         algo = 2.0 * m * cout * (k + 18)                      # the 3x3 conv + both 1x1 heads (18 channels)
         executed = 2.0 * m * cout * (k / 2.25 + 32)           # Winograd multiplies + the head MFMAs on 32 padded columns
         prof.append((e0, e1, algo, (m, cout, k), 4.0 * (m * cin + 2 * part.numel() / 2 + cout * k), "winograd", executed))
-    return HeadSums(part, b, h, w)
+    return HeadSums(part, b, h, w, mode)
 
 
 @_on_device
@@ -543,7 +550,7 @@ def rpn_scores_deltas(heads, head_bias: torch.Tensor | None = None):
     for h in heads:
         if isinstance(h, HeadSums):
             assert h.batch == b and h.part.is_contiguous() and head_bias is not None and head_bias.numel() == 18
-            hs.append(h.height); ws.append(h.width); modes.append(1)
+            hs.append(h.height); ws.append(h.width); modes.append(h.tile_mode)
         else:
             assert h.is_contiguous() and h.dtype == torch.float32 and h.size(0) == b and h.size(3) == 18
             hs.append(h.size(1)); ws.append(h.size(2)); modes.append(0)

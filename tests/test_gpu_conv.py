@@ -508,6 +508,7 @@ def test_winograd_fused_rpn_heads(dev, shape):
     w32 = torch.zeros(32, cout)
     w32[:18] = wh.view(18, cout)
     sums = ops.conv3x3_winograd_heads(xk, u, None, bs.to(dev), w32.to(dev), True)
+    assert sums.tile_mode == (2 if min(h, w) >= 16 else 1)
     got = sums.to_nhwc(bh.to(dev)).cpu()
     err = (got - want).abs().max().item()
     assert err <= TOL, f"max abs err {err:.3e} (|ref|max {want.abs().max().item():.2f})"
@@ -516,7 +517,10 @@ def test_winograd_fused_rpn_heads(dev, shape):
     un = ops.conv_bn_act(y, wh.permute(0, 2, 3, 1).contiguous().to(dev), None, bh.to(dev)).cpu()
     assert (got - un).abs().max().item() <= 2e-5
     again = ops.conv3x3_winograd_heads(xk, u, None, bs.to(dev), w32.to(dev), True)
-    assert torch.equal(again.part[:, :b * (h // 2) * (w // 2) * 4], sums.part[:, :b * (h // 2) * (w // 2) * 4])   # deterministic
+    assert torch.equal(again.to_nhwc(bh.to(dev)).cpu(), got)                          # deterministic
+    # both tile shapes give the same sums bit for bit (same transforms, MFMA order and head accumulation order)
+    lin = ops.conv3x3_winograd_heads(xk, u, None, bs.to(dev), w32.to(dev), True, tile_mode=1)
+    assert torch.equal(lin.to_nhwc(bh.to(dev)).cpu(), got)
     # the consumer: scores / deltas from head sums == from NHWC heads of the same values
     lv = [got.to(dev)] + [torch.randn(b, max(h >> i, 1), max(w >> i, 1), 18, generator=g).to(dev) for i in (1, 2, 3, 4)]
     s0, d0 = ops.rpn_scores_deltas(lv)

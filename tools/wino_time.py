@@ -23,3 +23,15 @@ for (b, h, w, cin, cout) in ((8, 256, 256, 256, 512), (8, 256, 256, 256, 256), (
     fl = 2.0 * b * h * w * cout * 9 * cin / 2.25
     out.append(f"{cin}->{cout}@{h}: {t:.3f} ms {fl/t/1e9:.1f} TF ({fl/t/1e9/157.3:.3f})")
 print(" | ".join(out))
+# the RPN layer with its two 1x1 heads fused, both tile shapes
+out = []
+for (b, h, w) in ((8, 256, 256), (8, 128, 128), (8, 64, 64)):
+    x = ops.nhwc_to_kblocked(torch.randn(b, h, w, 256, generator=g).to(dev))
+    u = ops.winograd_weights((torch.randn(512, 3, 3, 256, generator=g) * 0.02).to(dev))
+    sh = torch.zeros(512, device=dev)
+    w32 = torch.zeros(32, 512, device=dev); w32[:18] = torch.randn(18, 512, generator=g).to(dev) * 0.02
+    for mode in (1, 2):
+        t = timeit(lambda: ops.conv3x3_winograd_heads(x, u, None, sh, w32, True, tile_mode=mode))
+        fl = 2.0 * b * h * w * 512 * 9 * 256 / 2.25
+        out.append(f"heads@{h} mode{mode}: {t:.3f} ms ({fl/t/1e9/157.3:.3f})")
+print(" | ".join(out))
