@@ -533,7 +533,8 @@ def conv3x3_winograd_heads(x_kblocked: torch.Tensor, u: torch.Tensor, scale, shi
         m, k = b * h * w, 9 * (algo_cin or cin)
         algo = 2.0 * m * cout * (k + 18)                      # the 3x3 conv + both 1x1 heads (18 channels)
         executed = 2.0 * m * cout * (k / 2.25 + 32)           # Winograd multiplies + the head MFMAs on 32 padded columns
-        prof.append((e0, e1, algo, (m, cout, k), 4.0 * (m * cin + 2 * part.numel() / 2 + cout * k), "winograd", executed))
+        prof.append((e0, e1, algo, (m, cout, k), 4.0 * (m * cin + 2 * part.numel() / 2 + cout * k),
+                     "winograd_spatial" if mode == 2 else "winograd", executed))
     return HeadSums(part, b, h, w, mode)
 
 
@@ -890,7 +891,8 @@ def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, scale, shift, relu: bool 
         # FLOPs are the algorithmic ones of the convolution (2*M*N*K), as for the direct kernel — not the reduced
         # multiply count Winograd actually executes
         prof.append((e0, e1, 2.0 * m * cout * k, (m, cout, k),
-                     4.0 * (m * cin + m * cout * (2 if out == "both" else 1) + cout * k), "winograd"))
+                     4.0 * (m * cin + m * cout * (2 if out == "both" else 1) + cout * k),
+                     "winograd_spatial" if int(lib.mrcnn_conv3x3_winograd_heads_tile_mode(h, w)) == 2 else "winograd"))
     return y if out == "nhwc" else yk if out == "kblocked" else (y, yk)
 
 
