@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 8
+#define MRCNN_ABI_VERSION 9
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -288,6 +288,21 @@ int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int32_t batch, 
                                int32_t cin, const float* u, int32_t cout, const float* scale, const float* shift,
                                int32_t activation, float* y_nhwc, float* y_kblocked, void* workspace,
                                size_t workspace_bytes, mrcnn_stream_t stream);
+/* Winograd F(4x4, 3x3): the same convolution with 4x (instead of 2.25x) fewer multiply-adds, for maps whose height and
+ * width are multiples of 4 (csrc/conv_wino4.hip; fp32 arithmetic, max |err| about 2e-5 at unit scale against the direct
+ * convolution — ten times F(2x2)'s, inside the 1e-4 parity bar). Replaces the same reference lines as
+ * mrcnn_conv3x3_winograd_f32 (model.py:154-157, :605,624).
+ *   mrcnn_winograd4_weights_f32   w_ohwi [Cout][3][3][Cin] -> u = G g G^T in the kernel's order [Cin/4][36][2][Cout][2]
+ *                                 (36 * Cout * Cin floats; evaluated in double); Cin % 4 == 0
+ *   mrcnn_conv3x3_winograd4_supported   1 when H % 4 == 0, W % 4 == 0, Cin % 8 == 0, Cout % 64 == 0
+ *   mrcnn_conv3x3_winograd4_f32   x k-blocked [Cin/8][B*H*W][8] -> relu?(conv * scale + shift) as NHWC and/or k-blocked
+ *                                 [Cout/8][B*H*W][8] (either output pointer may be null, not both) */
+int mrcnn_winograd4_weights_f32(const float* w_ohwi, int32_t cout, int32_t cin, float* u, mrcnn_stream_t stream);
+int32_t mrcnn_conv3x3_winograd4_supported(int32_t height, int32_t width, int32_t cin, int32_t cout);
+int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                const float* u, int32_t cout, const float* scale, const float* shift, int32_t activation,
+                                float* y_nhwc, float* y_kblocked, mrcnn_stream_t stream);
+
 /* Tile shape of mrcnn_conv3x3_winograd_f32 on maps of at least 8 x 8 tile positions: 1 (default) = 8 x 8 position blocks of
  * one image with the input transform done per lane out of a raw LDS region (conv3x3_wino8s_f32), 0 = 64 consecutive
  * positions with a staged transform (conv3x3_wino8_f32), -1 = back to the default / MRCNN_WINO_SPATIAL. Same results bit

@@ -28,6 +28,7 @@ SOURCES = {
     "conv.hip": [],
     "conv_f16.hip": [],
     "conv_wino.hip": [],
+    "conv_wino4.hip": [],
     "stem.hip": [],
     "bottleneck.hip": [],
     "misc.hip": ["-ffp-contract=off"],

@@ -1,0 +1,415 @@
+// 3x3 stride-1 SAME convolution + per-channel affine + ReLU as a fused Winograd F(4x4, 3x3) on the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32): 4x fewer multiply-adds than the direct implicit GEMM (F(2x2,3x3) of conv_wino.hip: 2.25x)
+// for the large-map 3x3 layers — FPN smoothing (model.py:154-157) and the RPN's shared conv (model.py:605,624). All
+// arithmetic is fp32 (filter transform in double, once); the transforms' larger coefficients (up to 8) cost about one
+// decimal digit against F(2x2): max |err| 2e-5 at unit scale and K = 2304, inside the 1e-4 parity bar
+// (tests/test_gpu_conv.py).
+//
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A       g: 3x3 filter, d: 6x6 input patch, Y: 4x4 outputs
+//   interpolation points 0, +-1, +-2, inf (Lavin & Gray 2015, the matrices below)
+//
+//   GEMM view   36 independent products, one per transform component (xi, nu): M[T x N] = V[T x C] U[C x N], T = tile
+//               positions (one per 4x4 output pixels), N = Cout, C = Cin.
+//   tile        a workgroup = 4 waves, ONE per SIMD, owns 32 positions (a 4 x 8 block of one image: 16 x 32 output pixels)
+//               x 64 output channels x all 36 components: 288 accumulator registers per lane — the whole 512-entry
+//               register file (256 AGPRs + 32 VGPRs hold the accumulators; the MFMAs are inline asm so that each
+//               accumulator's register class is fixed). Wave (qa, qb) owns the 3 x 3 quadrant xi in 3qa..3qa+2, nu in
+//               3qb..3qb+2 of the component grid: its A operands need only a 5 x 5 part of the 6 x 6 patch.
+//   staging     per k tile of 4 input channels: the raw 18 x 34 x 4 input region through registers into LDS (two
+//               channel-pair planes; a row's base is rotated by row/4 so that the 32 lanes of a half, which sit 4 pixels
+//               apart in both directions, read 32 different bank pairs), and the 36 x 64 x 4 block of U by LDS-DMA
+//               (buffer_load ... lds, no registers: a wave moves 9 components, 1 KB each). Double-buffered, one barrier
+//               per k tile.
+//   transform   an MFMA A-operand register is one position x one channel per lane, so every lane transforms its OWN
+//               position out of the raw region (25 8-byte reads, 48 packed VALU ops) straight into the 9 A operands of
+//               its wave's components — V is never stored. Each A operand feeds two MFMAs (the two 32-channel halves
+//               of the N tile).
+//   epilogue    the 36 components of 8 positions x 64 channels go through LDS per round; every thread then applies
+//               A^T . A to two (position, channel) pairs, affine, ReLU, stores NHWC and/or k-blocked.
+#include "conv_common.hpp"
+
+#include <cstdlib>
+
+namespace {
+
+using namespace mrcnn_conv;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct Wino4Params {
+    const float* x;      // k-blocked input  [Cin/8][B*H*W][8]
+    const float* u;      // transformed filter [Cin/4][36][2 channel pairs][Cout][2]
+    const float* scale;  // [Cout] or null
+    const float* shift;  // [Cout] or null
+    float* y;            // NHWC output [B][H][W][Cout], or null
+    float* yk;           // k-blocked output [Cout/8][B*H*W][8], or null
+    int B, H, W, Cin, Cout, TH, TW, act;  // TH, TW: tile positions per image (H/4, W/4)
+    int tyb, txb;                         // 4 x 8-position blocks per image along y / x
+    int tiles_m, tiles_n;
+    unsigned x_plane, u_ktile, yk_plane;  // bytes per 8-channel plane of x, per k tile of u, per 8-channel output plane
+    unsigned x_bytes, u_bytes, y_bytes;
+};
+
+constexpr int W4_N = 64;                              // output channels per workgroup
+constexpr int W4_RW = 40;                             // channel pairs per raw row in LDS (34 used; == 0 mod 8)
+constexpr int W4_RPLANE = 18 * W4_RW + 8;             // pairs per (buffer, channel pair) plane, rotation included
+constexpr int W4_RS_FLOATS = 2 * 2 * W4_RPLANE * 2;   // raw region: [2 buffers][2 channel pairs][plane][2]
+constexpr int W4_UBUF = 36 * 256;                     // floats per U buffer: [36][2 channel pairs][64][2]
+constexpr int W4_Z_FLOATS = 36 * 8 * 64;              // epilogue exchange of a round: [36][8 positions][64 channels]
+constexpr size_t WINO4_LDS = sizeof(float) * (W4_RS_FLOATS + 2 * W4_UBUF);
+static_assert(W4_Z_FLOATS <= W4_RS_FLOATS + 2 * W4_UBUF, "the exchange buffer aliases the staging buffers");
+
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {  // a * b + c
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 b, f32x2 c) {  // c - a * b
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// The MFMA with the accumulator's register class fixed by the constraint: 16 of a wave's 18 accumulators live in AGPRs,
+// 2 in VGPRs (left to itself the register allocator shuttles 288 accumulator registers between the two files inside the
+// loop). s_nop 1: the A / B operand may have been written by the VALU instruction just before (the compiler pads only
+// its own instructions).
+__device__ __forceinline__ void mfma_a(f32x16& acc, float a, float b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_v(f32x16& acc, float a, float b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+// Three rows of B^T applied to five consecutive samples. B^T (6 x 6), rows 0..5:
+//   [4 0 -5 0 1 0] [0 -4 -4 1 1 0] [0 4 -4 -1 1 0] [0 -2 -1 2 1 0] [0 2 -1 -2 1 0] [0 4 0 -5 0 1]
+// Q = 0: rows 0..2 of samples d0..d4 (= e0..e4); Q = 1: rows 3..5 of samples d1..d5 (= e0..e4).
+template <int Q>
+__device__ __forceinline__ void bt3(const f32x2 e0, const f32x2 e1, const f32x2 e2, const f32x2 e3, const f32x2 e4,
+                                    const f32x2 c4, const f32x2 c5, const f32x2 c2, f32x2& r0, f32x2& r1, f32x2& r2) {
+    if constexpr (Q == 0) {
+        const f32x2 t1 = pk_fnma(c4, e2, e4);   // d4 - 4 d2
+        const f32x2 t2 = pk_fnma(c4, e1, e3);   // d3 - 4 d1
+        r0 = pk_fma(c4, e0, pk_fnma(c5, e2, e4));  // 4 d0 - 5 d2 + d4
+        r1 = pk_add(t1, t2);
+        r2 = pk_sub(t1, t2);
+    } else {
+        const f32x2 u1 = pk_sub(e3, e1);        // d4 - d2
+        const f32x2 u2 = pk_sub(e2, e0);        // d3 - d1
+        r0 = pk_fma(c2, u2, u1);                // -2 d1 - d2 + 2 d3 + d4
+        r1 = pk_fnma(c2, u2, u1);               //  2 d1 - d2 - 2 d3 + d4
+        r2 = pk_fma(c4, e0, pk_fnma(c5, e2, e4));  // 4 d1 - 5 d3 + d5
+    }
+}
+
+// The lane's 5 x 5 part of its position's patch (rows QA.., columns QB..) -> the 9 A operands V[3QA+i][3QB+j], i*3+j.
+template <int QA, int QB>
+__device__ __forceinline__ void patch_to_a(const f32x2* __restrict__ rp, f32x2 (&A)[9]) {
+    const f32x2 c4 = {4.f, 4.f}, c5 = {5.f, 5.f}, c2 = {2.f, 2.f};
+    f32x2 t[3][5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        f32x2 e[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int dy = QA + r, dx = QB + c;
+            e[r] = rp[dy * W4_RW + (dy >= 4 ? 1 : 0) + dx];
+        }
+        bt3<QA>(e[0], e[1], e[2], e[3], e[4], c4, c5, c2, t[0][c], t[1][c], t[2][c]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        bt3<QB>(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], c4, c5, c2, A[i * 3 + 0], A[i * 3 + 1], A[i * 3 + 2]);
+}
+
+// A^T (4 x 6) applied to six samples: rows [1 1 1 1 1 0] [0 1 -1 2 -2 0] [0 1 1 4 4 0] [0 1 -1 8 -8 1]
+__device__ __forceinline__ void at4(const float m0, const float m1, const float m2, const float m3, const float m4,
+                                    const float m5, float& y0, float& y1, float& y2, float& y3) {
+    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+    y0 = (m0 + s12) + s34;
+    y1 = fmaf(2.f, d34, d12);
+    y2 = fmaf(4.f, s34, s12);
+    y3 = fmaf(8.f, d34, d12) + m5;
+}
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const Wino4Params p) {
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    f32x2* Rs = reinterpret_cast<f32x2*>(smem);  // [2][2][W4_RPLANE] channel pairs
+    float* Us = smem + W4_RS_FLOATS;             // [2][36][2][64][2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 31, lh = lane >> 5;
+    const int qa = wave >> 1, qb = wave & 1;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+    const int nk = p.Cin >> 2;
+    const int total_tiles = 8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
+
+    for (int it = 0;; ++it) {
+        // virtual tile b, b + grid, ... in the XCD-aware order of conv_wino.hip: the workgroups of one XCD walk the N
+        // tiles of neighbouring M tiles, so the raw input region is shared in that XCD's L2
+        const int tile = blockIdx.x + it * gridDim.x;
+        if (tile >= total_tiles) break;
+        const int xcd = tile & 7, seq = tile >> 3;
+        const int mt_lo = (xcd * p.tiles_m) >> 3, mt_hi = ((xcd + 1) * p.tiles_m) >> 3;
+        const int mt = mt_lo + seq / p.tiles_n;
+        if (mt >= mt_hi) continue;  // uniform
+        const int n0 = (seq % p.tiles_n) * W4_N;
+        const int per_img = p.tyb * p.txb;
+        const int b = mt / per_img, trem = mt - b * per_img;
+        const int tby = trem / p.txb, tbx = trem - tby * p.txb;
+        const int TY0 = tby * 4, TX0 = tbx * 8;          // first tile position of the block
+        const int iy0 = 4 * TY0 - 1, ix0 = 4 * TX0 - 1;  // first raw input pixel (may be -1: zero padding)
+
+        // ---- staging: raw pixels tid, tid + 256, tid + 512 of the 18 x 34 region (16 bytes = the k tile's 4 channels)
+        unsigned r_off[3];
+        int r_lds[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int f = tid + 256 * i;
+            const int r = f / 34, c = f - r * 34;
+            const int iy = iy0 + r, ix = ix0 + c;
+            const bool ok = f < 612 && static_cast<unsigned>(iy) < static_cast<unsigned>(p.H) &&
+                            static_cast<unsigned>(ix) < static_cast<unsigned>(p.W);
+            r_off[i] = ok ? static_cast<unsigned>((b * p.H + iy) * p.W + ix) * 32u : OOB;
+            r_lds[i] = r * W4_RW + (r >> 2) + c;
+        }
+        const bool r2 = tid + 512 < 612;
+        // U by LDS-DMA: wave w moves components 9w..9w+8; lane = (channel pair lh, channels n0 + 2 ln, +1)
+        const unsigned u_voff = static_cast<unsigned>((lh * p.Cout + n0 + 2 * ln) * 2) * 4u;
+        const unsigned u_comp = static_cast<unsigned>(p.Cout) * 16u;  // bytes per component of a k tile
+
+        u32x4 rr[3];
+        auto load_raw = [&](int kt) {
+            const int soff = static_cast<int>(static_cast<unsigned>(kt >> 1) * p.x_plane + static_cast<unsigned>(kt & 1) * 16u);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rr[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(r_off[i]), soff, 0);
+        };
+        auto write_raw = [&](int buf) {
+            f32x2* base = Rs + buf * 2 * W4_RPLANE;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i == 2 && !r2) break;
+                const float4 v = __builtin_bit_cast(float4, rr[i]);
+                base[r_lds[i]] = f32x2{v.x, v.y};
+                base[W4_RPLANE + r_lds[i]] = f32x2{v.z, v.w};
+            }
+        };
+        auto dma_u = [&](int kt, int buf) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int c = wave * 9 + j;
+                const int soff = static_cast<int>(static_cast<unsigned>(kt) * p.u_ktile + static_cast<unsigned>(c) * u_comp);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rsrc, Us + buf * W4_UBUF + c * 256, 16, static_cast<int>(u_voff), soff, 0, 0);
+            }
+        };
+
+        // the lane's position: px = ln & 7, py = ln >> 3; raw rows 4 py + dy, columns 4 px + dx
+        const int lp_x = ln & 7, lp_y = ln >> 3;
+        const int rbase = lh * W4_RPLANE + 4 * lp_y * W4_RW + lp_y + 4 * lp_x;
+        const int cg0 = (3 * qa) * 6 + 3 * qb;  // the quadrant's first component
+
+        f32x16 acc[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+        load_raw(0);
+        dma_u(0, 0);
+        write_raw(0);
+        __syncthreads();
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            const bool more = kt + 1 < nk;
+            if (more) {
+                load_raw(kt + 1);
+                dma_u(kt + 1, buf ^ 1);
+            }
+            f32x2 A[9];
+            const f32x2* rp = Rs + buf * 2 * W4_RPLANE + rbase;
+            if (qa == 0) {
+                if (qb == 0) patch_to_a<0, 0>(rp, A); else patch_to_a<0, 1>(rp, A);
+            } else {
+                if (qb == 0) patch_to_a<1, 0>(rp, A); else patch_to_a<1, 1>(rp, A);
+            }
+            const f32x2* up = reinterpret_cast<const f32x2*>(Us + buf * W4_UBUF) + lh * 64 + ln;
+            f32x2 Bv[18];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        Bv[(i * 3 + j) * 2 + nb] = up[(cg0 + i * 6 + j) * 128 + nb * 32];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int ci = 0; ci < 9; ++ci)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const float a = s == 0 ? A[ci].x : A[ci].y;
+                        const float bb = s == 0 ? Bv[ci * 2 + nb].x : Bv[ci * 2 + nb].y;
+                        if (ci < 8) mfma_a(acc[ci * 2 + nb], a, bb);
+                        else mfma_v(acc[ci * 2 + nb], a, bb);
+                    }
+            if (more) write_raw(buf ^ 1);
+            __syncthreads();
+        }
+
+        // ---- epilogue: four rounds of 8 positions (accumulator registers 4g..4g+3 of both lane halves)
+        float* Z = smem;
+        const int n = tid & 63, pq = tid >> 6;
+        const int ng = n0 + n;
+        const float sc = p.scale ? p.scale[ng] : 1.0f, sh = p.shift ? p.shift[ng] : 0.0f;
+        const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y ? p.y_bytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yk_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.yk, 0, p.yk ? p.y_bytes : 0u, 0x00020000);
+        const unsigned ncol = static_cast<unsigned>(ng) * 4u;
+        const unsigned kcol = static_cast<unsigned>(ng >> 3) * p.yk_plane + static_cast<unsigned>(ng & 7) * 4u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            Z[((cg0 + i * 6 + j) * 8 + 4 * lh + e) * 64 + nb * 32 + ln] = acc[(i * 3 + j) * 2 + nb][4 * g + e];
+            __syncthreads();
+#pragma unroll 1
+            for (int pp = 0; pp < 2; ++pp) {
+                const int p8 = 2 * pq + pp;
+                const int pos = 8 * g + p8;
+                const int TY = TY0 + (pos >> 3), TX = TX0 + (pos & 7);
+                const bool valid = TY < p.TH && TX < p.TW;
+                float w[6][4];
+#pragma unroll
+                for (int xi = 0; xi < 6; ++xi) {
+                    float m[6];
+#pragma unroll
+                    for (int nu = 0; nu < 6; ++nu) m[nu] = Z[((xi * 6 + nu) * 8 + p8) * 64 + n];
+                    at4(m[0], m[1], m[2], m[3], m[4], m[5], w[xi][0], w[xi][1], w[xi][2], w[xi][3]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float yv[4];
+                    at4(w[0][j], w[1][j], w[2][j], w[3][j], w[4][j], w[5][j], yv[0], yv[1], yv[2], yv[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = fmaf(yv[i], sc, sh);
+                        if (p.act) v = fmaxf(v, 0.f);
+                        const unsigned pix = static_cast<unsigned>((b * p.H + 4 * TY + i) * p.W + 4 * TX + j);
+                        if (p.y)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc,
+                                                                  static_cast<int>(valid ? pix * static_cast<unsigned>(p.Cout) * 4u + ncol : OOB), 0, 0);
+                        if (p.yk)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yk_rsrc,
+                                                                  static_cast<int>(valid ? pix * 32u + kcol : OOB), 0, 0);
+                    }
+                }
+            }
+            __syncthreads();  // Z is read out: the next round / the next tile's staging may overwrite it
+        }
+    }  // tiles
+}
+
+// G g G^T in double, stored as the kernel's [Cin/4][36][2][Cout][2]. G (6 x 3):
+//   [1/4 0 0] [-1/6 -1/6 -1/6] [-1/6 1/6 -1/6] [1/24 1/12 1/6] [1/24 -1/12 1/6] [0 0 1]
+__global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restrict__ w, int cout, int cin,
+                                                            float* __restrict__ u) {
+    const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (e >= static_cast<int64_t>(cout) * cin) return;
+    const int n = static_cast<int>(e / cin), c = static_cast<int>(e - static_cast<int64_t>(n) * cin);
+    double g[3][3];
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((static_cast<int64_t>(n) * 3 + ky) * 3 + kx) * cin + c];
+    auto g6 = [](double a, double b2, double c2, double (&r)[6]) {
+        r[0] = a / 4.0;
+        r[1] = -(a + b2 + c2) / 6.0;
+        r[2] = -(a - b2 + c2) / 6.0;
+        r[3] = a / 24.0 + b2 / 12.0 + c2 / 6.0;
+        r[4] = a / 24.0 - b2 / 12.0 + c2 / 6.0;
+        r[5] = c2;
+    };
+    double t[6][3];
+    for (int kx = 0; kx < 3; ++kx) {
+        double r[6];
+        g6(g[0][kx], g[1][kx], g[2][kx], r);
+        for (int i = 0; i < 6; ++i) t[i][kx] = r[i];
+    }
+    const int kt = c >> 2, h = (c >> 1) & 1, s = c & 1;
+    for (int i = 0; i < 6; ++i) {
+        double r[6];
+        g6(t[i][0], t[i][1], t[i][2], r);
+        for (int j = 0; j < 6; ++j)
+            u[((static_cast<int64_t>(kt) * 36 + (i * 6 + j)) * 2 + h) * cout * 2 + n * 2 + s] = static_cast<float>(r[j]);
+    }
+}
+
+}  // namespace
+
+extern "C" int mrcnn_winograd4_weights_f32(const float* w_ohwi, int32_t cout, int32_t cin, float* u,
+                                           mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(w_ohwi && u, "winograd4_weights: null pointer");
+    MRCNN_REQUIRE(cout >= 1 && cin >= 4 && cin % 4 == 0, "winograd4_weights: Cout=%d Cin=%d (Cin %% 4 == 0 required)", cout, cin);
+    const int64_t e = static_cast<int64_t>(cout) * cin;
+    hipLaunchKernelGGL(wino4_weights_kernel, dim3(static_cast<unsigned>((e + 255) / 256)), dim3(256), 0,
+                       mrcnn::as_stream(stream), w_ohwi, cout, cin, u);
+    return mrcnn::check_launch("wino4_weights_kernel");
+}
+
+extern "C" int32_t mrcnn_conv3x3_winograd4_supported(int32_t height, int32_t width, int32_t cin, int32_t cout) {
+    return height >= 4 && width >= 4 && height % 4 == 0 && width % 4 == 0 && cin >= 8 && cin % 8 == 0 && cout >= W4_N &&
+           cout % W4_N == 0;
+}
+
+extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width,
+                                           int32_t cin, const float* u, int32_t cout, const float* scale,
+                                           const float* shift, int32_t activation, float* y_nhwc, float* y_kblocked,
+                                           mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x_kblocked && u && (y_nhwc || y_kblocked), "conv3x3_winograd4: null pointer");
+    MRCNN_REQUIRE(batch >= 1 && mrcnn_conv3x3_winograd4_supported(height, width, cin, cout),
+                  "conv3x3_winograd4: B=%d H=%d W=%d (%% 4 == 0) Cin=%d (%% 8 == 0) Cout=%d (%% 64 == 0) required", batch,
+                  height, width, cin, cout);
+    MRCNN_REQUIRE(activation == 0 || activation == 1, "conv3x3_winograd4: activation must be 0 or 1");
+    const long long px = 1LL * batch * height * width;
+    MRCNN_REQUIRE(px * cin < (1LL << 30) && px * cout < (1LL << 30) && 36LL * cin * cout < (1LL << 30),
+                  "conv3x3_winograd4: tensor too large (32-bit buffer byte offsets)");
+    Wino4Params p;
+    p.x = x_kblocked; p.u = u; p.scale = scale; p.shift = shift; p.y = y_nhwc; p.yk = y_kblocked;
+    p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout;
+    p.TH = height / 4; p.TW = width / 4; p.act = activation;
+    p.tyb = (p.TH + 3) / 4; p.txb = (p.TW + 7) / 8;
+    p.tiles_m = batch * p.tyb * p.txb;
+    p.tiles_n = cout / W4_N;
+    p.x_plane = static_cast<unsigned>(4LL * px * 8);
+    p.u_ktile = static_cast<unsigned>(4LL * 36 * 4 * cout);
+    p.yk_plane = static_cast<unsigned>(4LL * px * 8);
+    p.x_bytes = static_cast<unsigned>(4LL * px * cin);
+    p.u_bytes = static_cast<unsigned>(4LL * 36 * cin * cout);
+    p.y_bytes = static_cast<unsigned>(4LL * px * cout);
+    const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
+    MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd4: grid too large");
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wino4_f32), WINO4_LDS, "conv3x3_winograd4"))
+        return rc;
+    const int cus = mrcnn::device_cu_count();
+    if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd4: cannot query the device");
+    const int ncu = cus >= 8 ? (cus / 8) * 8 : 8;
+    const long long launch = grid > ncu ? ncu : grid;
+    hipLaunchKernelGGL(conv3x3_wino4_f32, dim3(static_cast<unsigned>(launch)), dim3(256), WINO4_LDS,
+                       mrcnn::as_stream(stream), p);
+    return mrcnn::check_launch("conv3x3_wino4_f32");
+}

@@ -896,6 +896,53 @@ def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, scale, shift, relu: bool 
     return y if out == "nhwc" else yk if out == "kblocked" else (y, yk)
 
 
+# --------------------------------------------------------------------------------------------------
+# Winograd F(4x4,3x3) 3x3 stride-1 SAME conv (csrc/conv_wino4.hip): maps with H % 4 == W % 4 == 0, Cout % 64 == 0
+# --------------------------------------------------------------------------------------------------
+def conv3x3_winograd4_supported(h: int, w: int, cin: int, cout: int) -> bool:
+    return bool(lib.mrcnn_conv3x3_winograd4_supported(int(h), int(w), int(cin), int(cout)))
+
+
+@_on_device
+def winograd4_weights(w_ohwi: torch.Tensor) -> torch.Tensor:
+    """[Cout,3,3,Cin] fp32 → G g G^T (6 x 6, evaluated in double) in the kernel's order [Cin/4,36,2,Cout,2]."""
+    _need_gpu(w_ohwi)
+    assert w_ohwi.dtype == torch.float32 and w_ohwi.is_contiguous() and tuple(w_ohwi.shape[1:3]) == (3, 3)
+    cout, cin = w_ohwi.size(0), w_ohwi.size(3)
+    assert cin % 4 == 0
+    u = torch.empty(cin // 4, 36, 2, cout, 2, dtype=torch.float32, device=w_ohwi.device)
+    check(lib.mrcnn_winograd4_weights_f32(w_ohwi.data_ptr(), cout, cin, u.data_ptr(), _stream()))
+    return u
+
+
+@_on_device
+def conv3x3_winograd4(x_kblocked: torch.Tensor, u4: torch.Tensor, scale, shift, relu: bool = False, algo_cin=None,
+                      out: str = "nhwc"):
+    """relu(conv3x3_same(x) * scale + shift) with u4 from winograd4_weights; x k-blocked [Cin/8,B,H,W,8].
+    out: "nhwc" → [B,H,W,Cout]; "kblocked" → [Cout/8,B,H,W,8]; "both" → (nhwc, kblocked)."""
+    _need_gpu(x_kblocked, u4, scale, shift)
+    assert x_kblocked.dim() == 5 and x_kblocked.dtype == torch.float32 and x_kblocked.is_contiguous()
+    assert u4.is_contiguous() and out in ("nhwc", "kblocked", "both")
+    g, b, h, w, _ = x_kblocked.shape
+    cin, cout = g * 8, u4.size(3)
+    assert u4.size(0) * 4 == cin and conv3x3_winograd4_supported(h, w, cin, cout), (h, w, cin, cout)
+    y = torch.empty(b, h, w, cout, dtype=torch.float32, device=x_kblocked.device) if out != "kblocked" else None
+    yk = torch.empty(cout // 8, b, h, w, 8, dtype=torch.float32, device=x_kblocked.device) if out != "nhwc" else None
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mrcnn_conv3x3_winograd4_f32(x_kblocked.data_ptr(), b, h, w, cin, u4.data_ptr(), cout, _ptr(scale),
+                                          _ptr(shift), 1 if relu else 0, _ptr(y), _ptr(yk), _stream()))
+    if prof is not None:
+        e1.record()
+        m, k = b * h * w, 9 * (algo_cin or cin)
+        prof.append((e0, e1, 2.0 * m * cout * k, (m, cout, k),
+                     4.0 * (m * cin + m * cout * (2 if out == "both" else 1) + 4 * cout * k), "winograd4",
+                     2.0 * m * cout * k / 4.0))
+    return y if out == "nhwc" else yk if out == "kblocked" else (y, yk)
+
+
 @_on_device
 def stem_conv(x: torch.Tensor, w: torch.Tensor, scale, shift, relu: bool = True, algo_cin: int | None = None):
     """The ResNet stem: conv 7x7 stride 2 pad 3 + affine + ReLU. x NHWC [B,H,W,4] (RGB + zero channel), w OHWI

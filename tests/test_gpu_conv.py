@@ -594,3 +594,36 @@ def test_maxpool_and_deconv_f16(dev):
     assert y.dtype == torch.float16 and tuple(y.shape) == (3, 14, 14, 64)
     err = (y.float().permute(0, 3, 1, 2).cpu() - want).abs()
     assert bool((err <= 2e-4 + 2.0 ** -11 * want.abs()).all()), err.max().item()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Winograd F(4x4,3x3) (conv3x3_wino4_f32) against torch-CPU, absolute 1e-4 at unit scale
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,h,w,cin,cout,relu", [
+    (1, 16, 32, 8, 64, False),      # exactly one M tile, one k plane
+    (2, 16, 32, 16, 64, True),
+    (1, 32, 64, 32, 128, True),     # several M and N tiles
+    (2, 20, 28, 24, 64, True),      # ragged blocks: 5 x 7 positions
+    (1, 4, 4, 8, 64, False),        # a single position
+    (3, 64, 64, 256, 256, True),    # the FPN smoothing shape at P4 size
+])
+def test_conv3x3_winograd4_vs_torch_cpu(dev, b, h, w, cin, cout, relu):
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(b * 1000 + h + cin)
+    x = torch.randn(b, h, w, cin, generator=g).clamp_(min=0)          # post-ReLU activations, unit scale
+    wt = torch.randn(cout, 3, 3, cin, generator=g) / (9 * cin * 0.5) ** 0.5
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.permute(0, 3, 1, 2).double(), padding=1)
+    ref = ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    if relu:
+        ref = ref.clamp_(min=0)
+    ref = ref.permute(0, 2, 3, 1).float()
+    xk = ops.nhwc_to_kblocked(x.to(dev))
+    u4 = ops.winograd4_weights(wt.to(dev).contiguous())
+    y, yk = ops.conv3x3_winograd4(xk, u4, sc.to(dev), sh.to(dev), relu, out="both")
+    err = (y.cpu() - ref).abs().max().item()
+    assert err <= TOL, f"max|err| {err:.3g} at max|ref| {ref.abs().max().item():.3g}"
+    assert torch.equal(ops.nhwc_to_kblocked(y), yk)
+    y2 = ops.conv3x3_winograd4(xk, u4, sc.to(dev), sh.to(dev), relu, out="nhwc")
+    assert torch.equal(y2, y)                                         # deterministic

@@ -35,3 +35,14 @@ for (b, h, w) in ((8, 256, 256), (8, 128, 128), (8, 64, 64)):
         fl = 2.0 * b * h * w * 512 * 9 * 256 / 2.25
         out.append(f"heads@{h} mode{mode}: {t:.3f} ms ({fl/t/1e9/157.3:.3f})")
 print(" | ".join(out))
+# F(4x4,3x3) on the same big layers
+out = []
+for (b, h, w, cin, cout) in ((8, 256, 256, 256, 512), (8, 256, 256, 256, 256), (8, 128, 128, 256, 512), (8, 64, 64, 256, 256)):
+    x = ops.nhwc_to_kblocked(torch.randn(b, h, w, cin, generator=g).to(dev))
+    wt = (torch.randn(cout, 3, 3, cin, generator=g) * 0.02).to(dev)
+    sh = torch.zeros(cout, device=dev)
+    u4 = ops.winograd4_weights(wt)
+    t = timeit(lambda: ops.conv3x3_winograd4(x, u4, None, sh, relu=True))
+    fl = 2.0 * b * h * w * cout * 9 * cin / 4.0
+    out.append(f"F4 {cin}->{cout}@{h}: {t:.3f} ms {fl/t/1e9:.1f} TF ({fl/t/1e9/157.3:.3f})")
+print(" | ".join(out))
