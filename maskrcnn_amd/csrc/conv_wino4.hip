@@ -29,6 +29,7 @@
 #include "conv_common.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -91,6 +92,15 @@ __device__ __forceinline__ void mfma_v(f32x16& acc, float a, float b) {
     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
+// One ds_read_b64, as asm: left to the compiler, pairs of these reads become ds_read2_b64 (half rate, banked mod 32 — the
+// raw region's layout is conflict-free for ds_read_b64 only), and a volatile access becomes a flat load with a full wait.
+// The compiler does not count an asm load: every consumer sits behind an explicit s_waitcnt lgkmcnt.
+__device__ __forceinline__ f32x2 lds_read_b64(unsigned addr, int offset) {
+    f32x2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(offset));
+    return v;
+}
+
 // Three rows of B^T applied to five consecutive samples. B^T (6 x 6), rows 0..5:
 //   [4 0 -5 0 1 0] [0 -4 -4 1 1 0] [0 4 -4 -1 1 0] [0 -2 -1 2 1 0] [0 2 -1 -2 1 0] [0 4 0 -5 0 1]
 // Q = 0: rows 0..2 of samples d0..d4 (= e0..e4); Q = 1: rows 3..5 of samples d1..d5 (= e0..e4).
@@ -112,26 +122,6 @@ __device__ __forceinline__ void bt3(const f32x2 e0, const f32x2 e1, const f32x2 
     }
 }
 
-// The lane's 5 x 5 part of its position's patch (rows QA.., columns QB..) -> the 9 A operands V[3QA+i][3QB+j], i*3+j.
-template <int QA, int QB>
-__device__ __forceinline__ void patch_to_a(const f32x2* __restrict__ rp, f32x2 (&A)[9]) {
-    const f32x2 c4 = {4.f, 4.f}, c5 = {5.f, 5.f}, c2 = {2.f, 2.f};
-    f32x2 t[3][5];
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-        f32x2 e[5];
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const int dy = QA + r, dx = QB + c;
-            e[r] = rp[dy * W4_RW + (dy >= 4 ? 1 : 0) + dx];
-        }
-        bt3<QA>(e[0], e[1], e[2], e[3], e[4], c4, c5, c2, t[0][c], t[1][c], t[2][c]);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-        bt3<QB>(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], c4, c5, c2, A[i * 3 + 0], A[i * 3 + 1], A[i * 3 + 2]);
-}
-
 // A^T (4 x 6) applied to six samples: rows [1 1 1 1 1 0] [0 1 -1 2 -2 0] [0 1 1 4 4 0] [0 1 -1 8 -8 1]
 __device__ __forceinline__ void at4(const float m0, const float m1, const float m2, const float m3, const float m4,
                                     const float m5, float& y0, float& y1, float& y2, float& y3) {
@@ -142,18 +132,20 @@ __device__ __forceinline__ void at4(const float m0, const float m1, const float 
     y3 = fmaf(8.f, d34, d12) + m5;
 }
 
-__global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const Wino4Params p) {
-    extern __shared__ __attribute__((aligned(1024))) float smem[];
+// One wave's share of the kernel; QA, QB = its quadrant of the component grid (compile-time: the transform's operations
+// differ per quadrant; the four waves of a workgroup run four instances of this code and meet at the same barriers).
+template <int QA, int QB>
+__device__ __forceinline__ void wino4_wave(const Wino4Params& p, float* smem) {
     f32x2* Rs = reinterpret_cast<f32x2*>(smem);  // [2][2][W4_RPLANE] channel pairs
     float* Us = smem + W4_RS_FLOATS;             // [2][36][2][64][2]
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int wave = QA * 2 + QB;
     const int ln = lane & 31, lh = lane >> 5;
-    const int qa = wave >> 1, qb = wave & 1;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
     const int nk = p.Cin >> 2;
     const int total_tiles = 8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
+    const f32x2 c4 = {4.f, 4.f}, c5 = {5.f, 5.f}, c2 = {2.f, 2.f};
 
     for (int it = 0;; ++it) {
         // virtual tile b, b + grid, ... in the XCD-aware order of conv_wino.hip: the workgroups of one XCD walk the N
@@ -182,42 +174,41 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const Wino4Params p)
             const bool ok = f < 612 && static_cast<unsigned>(iy) < static_cast<unsigned>(p.H) &&
                             static_cast<unsigned>(ix) < static_cast<unsigned>(p.W);
             r_off[i] = ok ? static_cast<unsigned>((b * p.H + iy) * p.W + ix) * 32u : OOB;
-            r_lds[i] = r * W4_RW + (r >> 2) + c;
+            r_lds[i] = f < 612 ? r * W4_RW + (r >> 2) + c : W4_RPLANE - 1;  // the plane's last pair is never read
         }
-        const bool r2 = tid + 512 < 612;
         // U by LDS-DMA: wave w moves components 9w..9w+8; lane = (channel pair lh, channels n0 + 2 ln, +1)
         const unsigned u_voff = static_cast<unsigned>((lh * p.Cout + n0 + 2 * ln) * 2) * 4u;
         const unsigned u_comp = static_cast<unsigned>(p.Cout) * 16u;  // bytes per component of a k tile
 
         u32x4 rr[3];
-        auto load_raw = [&](int kt) {
-            const int soff = static_cast<int>(static_cast<unsigned>(kt >> 1) * p.x_plane + static_cast<unsigned>(kt & 1) * 16u);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) rr[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(r_off[i]), soff, 0);
+        auto kclamp = [&](int kt) { return kt < nk ? kt : nk - 1; };  // past the end: reload the last k tile, never used
+        auto load_raw1 = [&](int kt, int i) {
+            const int k = kclamp(kt);
+            const int soff = static_cast<int>(static_cast<unsigned>(k >> 1) * p.x_plane + static_cast<unsigned>(k & 1) * 16u);
+            rr[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(r_off[i]), soff, 0);
         };
-        auto write_raw = [&](int buf) {
+        auto write_raw1 = [&](int buf, int i) {
             f32x2* base = Rs + buf * 2 * W4_RPLANE;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (i == 2 && !r2) break;
-                const float4 v = __builtin_bit_cast(float4, rr[i]);
-                base[r_lds[i]] = f32x2{v.x, v.y};
-                base[W4_RPLANE + r_lds[i]] = f32x2{v.z, v.w};
-            }
+            const float4 v = __builtin_bit_cast(float4, rr[i]);
+            base[r_lds[i]] = f32x2{v.x, v.y};
+            base[W4_RPLANE + r_lds[i]] = f32x2{v.z, v.w};
         };
-        auto dma_u = [&](int kt, int buf) {
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const int c = wave * 9 + j;
-                const int soff = static_cast<int>(static_cast<unsigned>(kt) * p.u_ktile + static_cast<unsigned>(c) * u_comp);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rsrc, Us + buf * W4_UBUF + c * 256, 16, static_cast<int>(u_voff), soff, 0, 0);
-            }
+        auto dma_u1 = [&](int kt, int buf, int j) {
+            const int c = wave * 9 + j;
+            const int soff = static_cast<int>(static_cast<unsigned>(kclamp(kt)) * p.u_ktile + static_cast<unsigned>(c) * u_comp);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rsrc, Us + buf * W4_UBUF + c * 256, 16, static_cast<int>(u_voff), soff, 0, 0);
         };
 
         // the lane's position: px = ln & 7, py = ln >> 3; raw rows 4 py + dy, columns 4 px + dx
         const int lp_x = ln & 7, lp_y = ln >> 3;
         const int rbase = lh * W4_RPLANE + 4 * lp_y * W4_RW + lp_y + 4 * lp_x;
-        const int cg0 = (3 * qa) * 6 + 3 * qb;  // the quadrant's first component
+        constexpr int cg0 = (3 * QA) * 6 + 3 * QB;  // the quadrant's first component
+        // LDS byte addresses of the lane's patch origin / B column in both buffers (the reads are asm: see lds_read_b64)
+        const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)smem));
+        const unsigned rp_addr[2] = {lds0 + static_cast<unsigned>(rbase) * 8u,
+                                     lds0 + static_cast<unsigned>(2 * W4_RPLANE + rbase) * 8u};
+        const unsigned up_addr[2] = {lds0 + static_cast<unsigned>(W4_RS_FLOATS * 4 + (lh * 64 + ln) * 8),
+                                     lds0 + static_cast<unsigned>((W4_RS_FLOATS + W4_UBUF) * 4 + (lh * 64 + ln) * 8)};
 
         f32x16 acc[18];
 #pragma unroll
@@ -225,48 +216,105 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const Wino4Params p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-        load_raw(0);
-        dma_u(0, 0);
-        write_raw(0);
-        __syncthreads();
+        // A: operand sets of the k tile in flight and the next one. B: ONE set, refreshed in place — the MFMAs run
+        // component-major, so Bv[q] is dead after slot 2q+1 and the next k tile's value is read into it at slot 2q+2;
+        // only the last one (q = 17, dead after the last slot) has a second register pair.
+        f32x2 A[2][9], Bv[17], Bl[2];
+        f32x2 e[2][5], t[3][5];
+        auto read_col = [&](int buf, int c) {  // column QB + c of the patch, rows QA..QA+4
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int dy = QA + r, dx = QB + c;
+                e[c & 1][r] = lds_read_b64(rp_addr[buf], (dy * W4_RW + (dy >= 4 ? 1 : 0) + dx) * 8);
+            }
+        };
+        auto row_stage = [&](int c) {  // waits for the column's reads (and whatever LDS operation is older)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[c & 1][0]), "+v"(e[c & 1][1]), "+v"(e[c & 1][2]), "+v"(e[c & 1][3]), "+v"(e[c & 1][4]));
+            bt3<QA>(e[c & 1][0], e[c & 1][1], e[c & 1][2], e[c & 1][3], e[c & 1][4], c4, c5, c2, t[0][c], t[1][c], t[2][c]);
+        };
+        auto col_stage = [&](int set, int i) {
+            bt3<QB>(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], c4, c5, c2, A[set][i * 3 + 0], A[set][i * 3 + 1], A[set][i * 3 + 2]);
+        };
+        auto read_b = [&](int set, int buf, int q) {  // q = component * 2 + channel half of the N tile
+            const int ci = q >> 1, nb = q & 1;
+            const int off = (cg0 + (ci / 3) * 6 + ci % 3) * 128 + nb * 32;
+            if (q < 17) Bv[q] = lds_read_b64(up_addr[buf], off * 8);
+            else Bl[set] = lds_read_b64(up_addr[buf], off * 8);
+        };
+        auto mfma = [&](int set, int m) {  // m = (ci * 2 + nb) * 2 + s
+            const int s = m & 1, q = m >> 1;
+            const f32x2 bq = q < 17 ? Bv[q] : Bl[set];
+            const float a = s == 0 ? A[set][q >> 1].x : A[set][q >> 1].y;
+            const float bb = s == 0 ? bq.x : bq.y;
+            if (q < 16) mfma_a(acc[q], a, bb);
+            else mfma_v(acc[q], a, bb);
+        };
 
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            const bool more = kt + 1 < nk;
-            if (more) {
-                load_raw(kt + 1);
-                dma_u(kt + 1, buf ^ 1);
-            }
-            f32x2 A[9];
-            const f32x2* rp = Rs + buf * 2 * W4_RPLANE + rbase;
-            if (qa == 0) {
-                if (qb == 0) patch_to_a<0, 0>(rp, A); else patch_to_a<0, 1>(rp, A);
-            } else {
-                if (qb == 0) patch_to_a<1, 0>(rp, A); else patch_to_a<1, 1>(rp, A);
-            }
-            const f32x2* up = reinterpret_cast<const f32x2*>(Us + buf * W4_UBUF) + lh * 64 + ln;
-            f32x2 Bv[18];
+        auto tie_b = [&](int set) {  // the asm reads of B have landed (lgkmcnt(0) just before): order their consumers behind
+            asm volatile("" : "+v"(Bv[0]), "+v"(Bv[1]), "+v"(Bv[2]), "+v"(Bv[3]), "+v"(Bv[4]), "+v"(Bv[5]), "+v"(Bv[6]), "+v"(Bv[7]), "+v"(Bv[8]));
+            asm volatile("" : "+v"(Bv[9]), "+v"(Bv[10]), "+v"(Bv[11]), "+v"(Bv[12]), "+v"(Bv[13]), "+v"(Bv[14]), "+v"(Bv[15]), "+v"(Bv[16]), "+v"(Bl[set]));
+        };
+
+        // ---- prologue: k tiles 0 and 1 staged, operands of k tile 0 in registers, raw k tile 2 in flight
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i) load_raw1(0, i);
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 9; ++j) dma_u1(0, 0, j);
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-                        Bv[(i * 3 + j) * 2 + nb] = up[(cg0 + i * 6 + j) * 128 + nb * 32];
+        for (int i = 0; i < 3; ++i) write_raw1(0, i);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+        for (int i = 0; i < 3; ++i) load_raw1(1, i);
 #pragma unroll
-                for (int ci = 0; ci < 9; ++ci)
+        for (int j = 0; j < 9; ++j) dma_u1(1, 1, j);
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) {
-                        const float a = s == 0 ? A[ci].x : A[ci].y;
-                        const float bb = s == 0 ? Bv[ci * 2 + nb].x : Bv[ci * 2 + nb].y;
-                        if (ci < 8) mfma_a(acc[ci * 2 + nb], a, bb);
-                        else mfma_v(acc[ci * 2 + nb], a, bb);
-                    }
-            if (more) write_raw(buf ^ 1);
-            __syncthreads();
+        for (int i = 0; i < 3; ++i) write_raw1(1, i);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) load_raw1(2, i);
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            read_col(0, c);
+            row_stage(c);
         }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) col_stage(0, i);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) read_b(0, 0, q);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tie_b(0);
+
+        // ---- one k tile. 36 MFMA slots, the order pinned (sched_barrier after every slot); beside the MFMAs of k tile kt:
+        //   slots 0-8    LDS-DMA of U(kt+2) into the buffer U(kt) has left (its B reads completed before the last barrier)
+        //   slots 0-4    the lane's patch of k tile kt+1, one column per slot;  slots 1-5 its row transform
+        //   slots 6-8    the column transform -> A(kt+1)
+        //   slots 2,4..  B(kt+1)[q] into the register B(kt)[q] has just left (slot 2q+2)
+        //   slots 27-29  raw k tile kt+2: registers -> LDS (the buffer of kt, last read a k tile ago); reload with kt+3
+        // then vmcnt(3) (the three raw loads may stay in flight, every DMA has landed), lgkmcnt(0), barrier.
+        auto ktile = [&](auto par, int kt) {
+            constexpr int CUR = decltype(par)::value, NXT = CUR ^ 1;
+#pragma unroll
+            for (int slot = 0; slot < 36; ++slot) {
+                mfma(CUR, slot);
+                if (slot < 9) dma_u1(kt + 2, CUR, slot);
+                if (slot >= 1 && slot <= 5) row_stage(slot - 1);
+                if (slot < 5) read_col(NXT, slot);
+                if (slot >= 6 && slot <= 8) col_stage(NXT, slot - 6);
+                if (slot >= 2 && (slot & 1) == 0) read_b(NXT, NXT, (slot - 2) >> 1);   // q = 0..16
+                if (slot == 35) read_b(NXT, NXT, 17);
+                if (slot >= 27 && slot < 30) {
+                    write_raw1(CUR, slot - 27);
+                    load_raw1(kt + 3, slot - 27);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            tie_b(NXT);
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            ktile(std::integral_constant<int, 0>{}, kt);
+            ktile(std::integral_constant<int, 1>{}, kt + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         // ---- epilogue: four rounds of 8 positions (accumulator registers 4g..4g+3 of both lane halves)
         float* Z = smem;
@@ -324,6 +372,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const Wino4Params p)
             __syncthreads();  // Z is read out: the next round / the next tile's staging may overwrite it
         }
     }  // tiles
+}
+
+__global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const Wino4Params p) {
+    extern __shared__ __attribute__((aligned(1024))) float smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0) wino4_wave<0, 0>(p, smem);
+    else if (wave == 1) wino4_wave<0, 1>(p, smem);
+    else if (wave == 2) wino4_wave<1, 0>(p, smem);
+    else wino4_wave<1, 1>(p, smem);
 }
 
 // G g G^T in double, stored as the kernel's [Cin/4][36][2][Cout][2]. G (6 x 3):
