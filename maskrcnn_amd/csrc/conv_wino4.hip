@@ -36,6 +36,10 @@ namespace {
 using namespace mrcnn_conv;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// LDS pointers stay in their address space: arithmetic on generic pointers costs a null check per conversion (and the
+// LDS-DMA destination / asm read addresses are 32-bit LDS offsets anyway)
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
 
 struct Wino4Params {
     const float* x;      // k-blocked input  [Cin/8][B*H*W][8]
@@ -49,6 +53,7 @@ struct Wino4Params {
     int tiles_m, tiles_n;
     unsigned x_plane, u_ktile, yk_plane;  // bytes per 8-channel plane of x, per k tile of u, per 8-channel output plane
     unsigned x_bytes, u_bytes, y_bytes;
+    int debug;  // MRCNN_W4_DEBUG: timing ablations (wrong results): 1 no DMA, 2 no transform, 4 no patch reads, 8 no B reads, 16 no raw staging
 };
 
 constexpr int W4_N = 64;                              // output channels per workgroup
@@ -56,7 +61,8 @@ constexpr int W4_RW = 40;                             // channel pairs per raw r
 constexpr int W4_RPLANE = 18 * W4_RW + 8;             // pairs per (buffer, channel pair) plane, rotation included
 constexpr int W4_RS_FLOATS = 2 * 2 * W4_RPLANE * 2;   // raw region: [2 buffers][2 channel pairs][plane][2]
 constexpr int W4_UBUF = 36 * 256;                     // floats per U buffer: [36][2 channel pairs][64][2]
-constexpr int W4_Z_FLOATS = 36 * 8 * 64;              // epilogue exchange of a round: [36][8 positions][64 channels]
+constexpr int W4_ZP = 10;                             // floats per (component, channel) row of the exchange buffer
+constexpr int W4_Z_FLOATS = 36 * 64 * W4_ZP;          // epilogue exchange of a round: [36][64 channels][8 positions, padded]
 constexpr size_t WINO4_LDS = sizeof(float) * (W4_RS_FLOATS + 2 * W4_UBUF);
 static_assert(W4_Z_FLOATS <= W4_RS_FLOATS + 2 * W4_UBUF, "the exchange buffer aliases the staging buffers");
 
@@ -104,6 +110,33 @@ __device__ __forceinline__ f32x2 lds_read_b64(unsigned addr, int offset) {
 // Three rows of B^T applied to five consecutive samples. B^T (6 x 6), rows 0..5:
 //   [4 0 -5 0 1 0] [0 -4 -4 1 1 0] [0 4 -4 -1 1 0] [0 -2 -1 2 1 0] [0 2 -1 -2 1 0] [0 4 0 -5 0 1]
 // Q = 0: rows 0..2 of samples d0..d4 (= e0..e4); Q = 1: rows 3..5 of samples d1..d5 (= e0..e4).
+#ifdef MRCNN_W4_SCALAR_T
+// scalar variant of the transform arithmetic (tuning: packed fp32 VALU beside MFMAs is not always the cheaper form)
+__device__ __forceinline__ float s_fma(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float s_fnma(float a, float b, float c) { float r; asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float s_add(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float s_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <int Q>
+__device__ __forceinline__ void bt3(const f32x2 e0, const f32x2 e1, const f32x2 e2, const f32x2 e3, const f32x2 e4,
+                                    const f32x2 c4, const f32x2 c5, const f32x2 c2, f32x2& r0, f32x2& r1, f32x2& r2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if constexpr (Q == 0) {
+            const float t1 = s_fnma(c4[h], e2[h], e4[h]);
+            const float t2 = s_fnma(c4[h], e1[h], e3[h]);
+            r0[h] = s_fma(c4[h], e0[h], s_fnma(c5[h], e2[h], e4[h]));
+            r1[h] = s_add(t1, t2);
+            r2[h] = s_sub(t1, t2);
+        } else {
+            const float u1 = s_sub(e3[h], e1[h]);
+            const float u2 = s_sub(e2[h], e0[h]);
+            r0[h] = s_fma(c2[h], u2, u1);
+            r1[h] = s_fnma(c2[h], u2, u1);
+            r2[h] = s_fma(c4[h], e0[h], s_fnma(c5[h], e2[h], e4[h]));
+        }
+    }
+}
+#else
 template <int Q>
 __device__ __forceinline__ void bt3(const f32x2 e0, const f32x2 e1, const f32x2 e2, const f32x2 e3, const f32x2 e4,
                                     const f32x2 c4, const f32x2 c5, const f32x2 c2, f32x2& r0, f32x2& r1, f32x2& r2) {
@@ -122,6 +155,8 @@ __device__ __forceinline__ void bt3(const f32x2 e0, const f32x2 e1, const f32x2 
     }
 }
 
+#endif
+
 // A^T (4 x 6) applied to six samples: rows [1 1 1 1 1 0] [0 1 -1 2 -2 0] [0 1 1 4 4 0] [0 1 -1 8 -8 1]
 __device__ __forceinline__ void at4(const float m0, const float m1, const float m2, const float m3, const float m4,
                                     const float m5, float& y0, float& y1, float& y2, float& y3) {
@@ -134,10 +169,10 @@ __device__ __forceinline__ void at4(const float m0, const float m1, const float 
 
 // One wave's share of the kernel; QA, QB = its quadrant of the component grid (compile-time: the transform's operations
 // differ per quadrant; the four waves of a workgroup run four instances of this code and meet at the same barriers).
-template <int QA, int QB>
-__device__ __forceinline__ void wino4_wave(const Wino4Params& p, float* smem) {
-    f32x2* Rs = reinterpret_cast<f32x2*>(smem);  // [2][2][W4_RPLANE] channel pairs
-    float* Us = smem + W4_RS_FLOATS;             // [2][36][2][64][2]
+template <int QA, int QB, int DBG>
+__device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) {
+    lds_f32x2* Rs = (lds_f32x2*)smem;            // [2][2][W4_RPLANE] channel pairs
+    lds_f32* Us = smem + W4_RS_FLOATS;           // [2][36][2][64][2]
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int wave = QA * 2 + QB;
     const int ln = lane & 31, lh = lane >> 5;
@@ -188,7 +223,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, float* smem) {
             rr[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(r_off[i]), soff, 0);
         };
         auto write_raw1 = [&](int buf, int i) {
-            f32x2* base = Rs + buf * 2 * W4_RPLANE;
+            lds_f32x2* base = Rs + buf * 2 * W4_RPLANE;
             const float4 v = __builtin_bit_cast(float4, rr[i]);
             base[r_lds[i]] = f32x2{v.x, v.y};
             base[W4_RPLANE + r_lds[i]] = f32x2{v.z, v.w};
@@ -204,7 +239,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, float* smem) {
         const int rbase = lh * W4_RPLANE + 4 * lp_y * W4_RW + lp_y + 4 * lp_x;
         constexpr int cg0 = (3 * QA) * 6 + 3 * QB;  // the quadrant's first component
         // LDS byte addresses of the lane's patch origin / B column in both buffers (the reads are asm: see lds_read_b64)
-        const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) float*)smem));
+        const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
         const unsigned rp_addr[2] = {lds0 + static_cast<unsigned>(rbase) * 8u,
                                      lds0 + static_cast<unsigned>(2 * W4_RPLANE + rbase) * 8u};
         const unsigned up_addr[2] = {lds0 + static_cast<unsigned>(W4_RS_FLOATS * 4 + (lh * 64 + ln) * 8),
@@ -216,21 +251,26 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, float* smem) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-        // A: operand sets of the k tile in flight and the next one. B: ONE set, refreshed in place — the MFMAs run
-        // component-major, so Bv[q] is dead after slot 2q+1 and the next k tile's value is read into it at slot 2q+2;
-        // only the last one (q = 17, dead after the last slot) has a second register pair.
-        f32x2 A[2][9], Bv[17], Bl[2];
-        f32x2 e[2][5], t[3][5];
+        // A: operand sets of the k tile in flight and the next one. B: ONE set, refreshed in place — the MFMAs run in
+        // groups of four (two accumulators x two k steps, alternating, so that no MFMA waits for the one before it), Bv[2g]
+        // and Bv[2g+1] are dead after slot 4g+3 and the next k tile's values are read into them at slots 4g+4, 4g+5; only
+        // the last group (dead after the last slot) has a second register set.
+        f32x2 A[2][9], Bv[16], Bl[2][2];
+        f32x2 e[3][5], t[3][5];
         auto read_col = [&](int buf, int c) {  // column QB + c of the patch, rows QA..QA+4
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 const int dy = QA + r, dx = QB + c;
-                e[c & 1][r] = lds_read_b64(rp_addr[buf], (dy * W4_RW + (dy >= 4 ? 1 : 0) + dx) * 8);
+                e[c % 3][r] = lds_read_b64(rp_addr[buf], (dy * W4_RW + (dy >= 4 ? 1 : 0) + dx) * 8);
             }
         };
-        auto row_stage = [&](int c) {  // waits for the column's reads (and whatever LDS operation is older)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[c & 1][0]), "+v"(e[c & 1][1]), "+v"(e[c & 1][2]), "+v"(e[c & 1][3]), "+v"(e[c & 1][4]));
-            bt3<QA>(e[c & 1][0], e[c & 1][1], e[c & 1][2], e[c & 1][3], e[c & 1][4], c4, c5, c2, t[0][c], t[1][c], t[2][c]);
+        // newer LDS reads than the column's own may stay in flight (wait_n of them: the schedule below knows the count)
+        auto row_stage = [&](int c, int wait_n) {
+            if (wait_n >= 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(e[c % 3][0]), "+v"(e[c % 3][1]), "+v"(e[c % 3][2]), "+v"(e[c % 3][3]), "+v"(e[c % 3][4]));
+            else if (wait_n == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(e[c % 3][0]), "+v"(e[c % 3][1]), "+v"(e[c % 3][2]), "+v"(e[c % 3][3]), "+v"(e[c % 3][4]));
+            else if (wait_n == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(e[c % 3][0]), "+v"(e[c % 3][1]), "+v"(e[c % 3][2]), "+v"(e[c % 3][3]), "+v"(e[c % 3][4]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[c % 3][0]), "+v"(e[c % 3][1]), "+v"(e[c % 3][2]), "+v"(e[c % 3][3]), "+v"(e[c % 3][4]));
+            bt3<QA>(e[c % 3][0], e[c % 3][1], e[c % 3][2], e[c % 3][3], e[c % 3][4], c4, c5, c2, t[0][c], t[1][c], t[2][c]);
         };
         auto col_stage = [&](int set, int i) {
             bt3<QB>(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], c4, c5, c2, A[set][i * 3 + 0], A[set][i * 3 + 1], A[set][i * 3 + 2]);
@@ -238,12 +278,12 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, float* smem) {
         auto read_b = [&](int set, int buf, int q) {  // q = component * 2 + channel half of the N tile
             const int ci = q >> 1, nb = q & 1;
             const int off = (cg0 + (ci / 3) * 6 + ci % 3) * 128 + nb * 32;
-            if (q < 17) Bv[q] = lds_read_b64(up_addr[buf], off * 8);
-            else Bl[set] = lds_read_b64(up_addr[buf], off * 8);
+            if (q < 16) Bv[q] = lds_read_b64(up_addr[buf], off * 8);
+            else Bl[set][q - 16] = lds_read_b64(up_addr[buf], off * 8);
         };
-        auto mfma = [&](int set, int m) {  // m = (ci * 2 + nb) * 2 + s
-            const int s = m & 1, q = m >> 1;
-            const f32x2 bq = q < 17 ? Bv[q] : Bl[set];
+        auto mfma = [&](int set, int m) {  // slot m: group m / 4 = component; accumulator (channel half) m & 1, k step (m >> 1) & 1
+            const int s = (m >> 1) & 1, q = (m >> 2) * 2 + (m & 1);
+            const f32x2 bq = q < 16 ? Bv[q] : Bl[set][q - 16];
             const float a = s == 0 ? A[set][q >> 1].x : A[set][q >> 1].y;
             const float bb = s == 0 ? bq.x : bq.y;
             if (q < 16) mfma_a(acc[q], a, bb);
@@ -252,7 +292,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, float* smem) {
 
         auto tie_b = [&](int set) {  // the asm reads of B have landed (lgkmcnt(0) just before): order their consumers behind
             asm volatile("" : "+v"(Bv[0]), "+v"(Bv[1]), "+v"(Bv[2]), "+v"(Bv[3]), "+v"(Bv[4]), "+v"(Bv[5]), "+v"(Bv[6]), "+v"(Bv[7]), "+v"(Bv[8]));
-            asm volatile("" : "+v"(Bv[9]), "+v"(Bv[10]), "+v"(Bv[11]), "+v"(Bv[12]), "+v"(Bv[13]), "+v"(Bv[14]), "+v"(Bv[15]), "+v"(Bv[16]), "+v"(Bl[set]));
+            asm volatile("" : "+v"(Bv[9]), "+v"(Bv[10]), "+v"(Bv[11]), "+v"(Bv[12]), "+v"(Bv[13]), "+v"(Bv[14]), "+v"(Bv[15]), "+v"(Bl[set][0]), "+v"(Bl[set][1]));
         };
 
         // ---- prologue: k tiles 0 and 1 staged, operands of k tile 0 in registers, raw k tile 2 in flight
@@ -274,7 +314,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, float* smem) {
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
             read_col(0, c);
-            row_stage(c);
+            row_stage(c, 0);
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) col_stage(0, i);
@@ -284,24 +324,27 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, float* smem) {
         tie_b(0);
 
         // ---- one k tile. 36 MFMA slots, the order pinned (sched_barrier after every slot); beside the MFMAs of k tile kt:
-        //   slots 0-8    LDS-DMA of U(kt+2) into the buffer U(kt) has left (its B reads completed before the last barrier)
-        //   slots 0-4    the lane's patch of k tile kt+1, one column per slot;  slots 1-5 its row transform
-        //   slots 6-8    the column transform -> A(kt+1)
-        //   slots 2,4..  B(kt+1)[q] into the register B(kt)[q] has just left (slot 2q+2)
+        //   slots 10,11,14,15,..,26  LDS-DMA of U(kt+2) into the buffer U(kt) has left (its B reads completed before the last
+        //                barrier): the slots that carry nothing else — a DMA beside LDS reads and VALU work delays the next MFMA
+        //   slots 0-4    the lane's patch of k tile kt+1, one column per slot;  slots 2-6 its row transform (two slots
+        //                behind the reads, with a counted wait);  slots 7-9 the column transform -> A(kt+1)
+        //   slots 4-35   B(kt+1): slots 4g+4, 4g+5 refill the registers group g has left; slots 34, 35 the last group's
         //   slots 27-29  raw k tile kt+2: registers -> LDS (the buffer of kt, last read a k tile ago); reload with kt+3
         // then vmcnt(3) (the three raw loads may stay in flight, every DMA has landed), lgkmcnt(0), barrier.
+        auto b_in_slot = [](int sl) { return (sl >= 4 && sl <= 33 && (sl & 3) < 2) || sl == 34 || sl == 35 ? 1 : 0; };
         auto ktile = [&](auto par, int kt) {
             constexpr int CUR = decltype(par)::value, NXT = CUR ^ 1;
 #pragma unroll
             for (int slot = 0; slot < 36; ++slot) {
                 mfma(CUR, slot);
-                if (slot < 9) dma_u1(kt + 2, CUR, slot);
-                if (slot >= 1 && slot <= 5) row_stage(slot - 1);
-                if (slot < 5) read_col(NXT, slot);
-                if (slot >= 6 && slot <= 8) col_stage(NXT, slot - 6);
-                if (slot >= 2 && (slot & 1) == 0) read_b(NXT, NXT, (slot - 2) >> 1);   // q = 0..16
-                if (slot == 35) read_b(NXT, NXT, 17);
-                if (slot >= 27 && slot < 30) {
+                if (slot >= 10 && slot <= 26 && (slot & 3) >= 2 && !(DBG & 1)) dma_u1(kt + 2, CUR, ((slot - 10) >> 2) * 2 + (slot & 1));
+                if (slot >= 2 && slot <= 6 && !(DBG & 2))   // LDS reads issued after column slot-2's: the rest of its slot, all of the next
+                    row_stage(slot - 2, (DBG & 12) ? 0 : b_in_slot(slot - 2) + (slot - 1 < 5 ? 5 : 0) + b_in_slot(slot - 1));
+                if (slot >= 7 && slot <= 9 && !(DBG & 2)) col_stage(NXT, slot - 7);
+                if (slot < 5 && !(DBG & 4)) read_col(NXT, slot);
+                if (slot >= 4 && slot <= 33 && (slot & 3) < 2 && !(DBG & 8)) read_b(NXT, NXT, ((slot - 4) >> 2) * 2 + (slot & 1));
+                if (slot >= 34 && !(DBG & 8)) read_b(NXT, NXT, slot - 18);
+                if (slot >= 27 && slot < 30 && !(DBG & 16)) {
                     write_raw1(CUR, slot - 27);
                     load_raw1(kt + 3, slot - 27);
                 }
@@ -317,7 +360,14 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, float* smem) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         // ---- epilogue: four rounds of 8 positions (accumulator registers 4g..4g+3 of both lane halves)
-        float* Z = smem;
+        if (DBG & 64) {  // ablation: no epilogue at all (keeps the accumulators alive through one store)
+            float keep = 0.f;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) keep += acc[i][0];
+            if (keep == 12345.678f) p.y[0] = keep;
+            continue;
+        }
+        lds_f32* Z = smem;
         const int n = tid & 63, pq = tid >> 6;
         const int ng = n0 + n;
         const float sc = p.scale ? p.scale[ng] : 1.0f, sh = p.shift ? p.shift[ng] : 0.0f;
@@ -325,19 +375,35 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, float* smem) {
         const __amdgpu_buffer_rsrc_t yk_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.yk, 0, p.yk ? p.y_bytes : 0u, 0x00020000);
         const unsigned ncol = static_cast<unsigned>(ng) * 4u;
         const unsigned kcol = static_cast<unsigned>(ng >> 3) * p.yk_plane + static_cast<unsigned>(ng & 7) * 4u;
+        // byte offsets of the 16 pixels of a position relative to its first one, as scalar offsets of the stores
+        int so_y[16], so_k[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                so_y[i * 4 + j] = (i * p.W + j) * p.Cout * 4;
+                so_k[i * 4 + j] = (i * p.W + j) * 32;
+            }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            // Z[component][channel][8 positions, pitch 10]: a lane's four positions (registers 4g..4g+3) are two 8-byte
+            // writes, a thread's two positions one 8-byte read; the pitch keeps both conflict-free
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            Z[((cg0 + i * 6 + j) * 8 + 4 * lh + e) * 64 + nb * 32 + ln] = acc[(i * 3 + j) * 2 + nb][4 * g + e];
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const f32x16& a16 = acc[(i * 3 + j) * 2 + nb];
+                        lds_f32* zp = Z + ((cg0 + i * 6 + j) * 64 + nb * 32 + ln) * W4_ZP + 4 * lh;
+                        *(lds_f32x2*)zp = f32x2{a16[4 * g], a16[4 * g + 1]};
+                        *(lds_f32x2*)(zp + 2) = f32x2{a16[4 * g + 2], a16[4 * g + 3]};
+                    }
             __syncthreads();
-#pragma unroll 1
+            f32x2 m2[36];
+#pragma unroll
+            for (int c = 0; c < 36; ++c) m2[c] = *(const lds_f32x2*)(Z + (c * 64 + n) * W4_ZP + 2 * pq);
+#pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
                 const int p8 = 2 * pq + pp;
                 const int pos = 8 * g + p8;
@@ -348,25 +414,32 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, float* smem) {
                 for (int xi = 0; xi < 6; ++xi) {
                     float m[6];
 #pragma unroll
-                    for (int nu = 0; nu < 6; ++nu) m[nu] = Z[((xi * 6 + nu) * 8 + p8) * 64 + n];
+                    for (int nu = 0; nu < 6; ++nu) m[nu] = pp == 0 ? m2[xi * 6 + nu].x : m2[xi * 6 + nu].y;
                     at4(m[0], m[1], m[2], m[3], m[4], m[5], w[xi][0], w[xi][1], w[xi][2], w[xi][3]);
                 }
+                float yv[4][4];  // [j][i]
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float yv[4];
-                    at4(w[0][j], w[1][j], w[2][j], w[3][j], w[4][j], w[5][j], yv[0], yv[1], yv[2], yv[3]);
+                    at4(w[0][j], w[1][j], w[2][j], w[3][j], w[4][j], w[5][j], yv[j][0], yv[j][1], yv[j][2], yv[j][3]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float v = fmaf(yv[i], sc, sh);
-                        if (p.act) v = fmaxf(v, 0.f);
-                        const unsigned pix = static_cast<unsigned>((b * p.H + 4 * TY + i) * p.W + 4 * TX + j);
-                        if (p.y)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc,
-                                                                  static_cast<int>(valid ? pix * static_cast<unsigned>(p.Cout) * 4u + ncol : OOB), 0, 0);
-                        if (p.yk)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yk_rsrc,
-                                                                  static_cast<int>(valid ? pix * 32u + kcol : OOB), 0, 0);
+                        yv[j][i] = fmaf(yv[j][i], sc, sh);
+                        if (p.act) yv[j][i] = fmaxf(yv[j][i], 0.f);
                     }
+                }
+                if (DBG & 32) { if (yv[0][0] == 12345.678f) p.y[0] = yv[0][0]; continue; }
+                const unsigned pix = static_cast<unsigned>((b * p.H + 4 * TY) * p.W + 4 * TX);
+                if (p.y) {
+                    const unsigned base = valid ? pix * static_cast<unsigned>(p.Cout) * 4u + ncol : OOB;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[q & 3][q >> 2]), y_rsrc, static_cast<int>(base), so_y[q], 0);
+                }
+                if (p.yk) {
+                    const unsigned base = valid ? pix * 32u + kcol : OOB;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[q & 3][q >> 2]), yk_rsrc, static_cast<int>(base), so_k[q], 0);
                 }
             }
             __syncthreads();  // Z is read out: the next round / the next tile's staging may overwrite it
@@ -374,13 +447,17 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, float* smem) {
     }  // tiles
 }
 
+// DBG: timing ablations for tuning (wrong results): 1 no DMA, 2 no transform, 4 no patch reads, 8 no B reads, 16 no raw
+// staging. Only DBG = 0 is built unless MRCNN_W4_ABLATIONS is defined.
+template <int DBG>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const Wino4Params p) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) wino4_wave<0, 0>(p, smem);
-    else if (wave == 1) wino4_wave<0, 1>(p, smem);
-    else if (wave == 2) wino4_wave<1, 0>(p, smem);
-    else wino4_wave<1, 1>(p, smem);
+    lds_f32* lds = (lds_f32*)smem;
+    if (wave == 0) wino4_wave<0, 0, DBG>(p, lds);
+    else if (wave == 1) wino4_wave<0, 1, DBG>(p, lds);
+    else if (wave == 2) wino4_wave<1, 0, DBG>(p, lds);
+    else wino4_wave<1, 1, DBG>(p, lds);
 }
 
 // G g G^T in double, stored as the kernel's [Cin/4][36][2][Cout][2]. G (6 x 3):
@@ -458,15 +535,29 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
     p.x_bytes = static_cast<unsigned>(4LL * px * cin);
     p.u_bytes = static_cast<unsigned>(4LL * 36 * cin * cout);
     p.y_bytes = static_cast<unsigned>(4LL * px * cout);
+    p.debug = getenv("MRCNN_W4_DEBUG") ? atoi(getenv("MRCNN_W4_DEBUG")) : 0;
     const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
     MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd4: grid too large");
-    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wino4_f32), WINO4_LDS, "conv3x3_winograd4"))
+    void (*kern)(const Wino4Params) = conv3x3_wino4_f32<0>;
+#ifdef MRCNN_W4_ABLATIONS
+    switch (p.debug) {
+        case 1: kern = conv3x3_wino4_f32<1>; break;
+        case 2: kern = conv3x3_wino4_f32<2>; break;
+        case 4: kern = conv3x3_wino4_f32<4>; break;
+        case 8: kern = conv3x3_wino4_f32<8>; break;
+        case 16: kern = conv3x3_wino4_f32<16>; break;
+        case 31: kern = conv3x3_wino4_f32<31>; break;
+        case 63: kern = conv3x3_wino4_f32<63>; break;
+        case 95: kern = conv3x3_wino4_f32<95>; break;
+        default: break;
+    }
+#endif
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), WINO4_LDS, "conv3x3_winograd4"))
         return rc;
     const int cus = mrcnn::device_cu_count();
     if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd4: cannot query the device");
     const int ncu = cus >= 8 ? (cus / 8) * 8 : 8;
     const long long launch = grid > ncu ? ncu : grid;
-    hipLaunchKernelGGL(conv3x3_wino4_f32, dim3(static_cast<unsigned>(launch)), dim3(256), WINO4_LDS,
-                       mrcnn::as_stream(stream), p);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(launch)), dim3(256), WINO4_LDS, mrcnn::as_stream(stream), p);
     return mrcnn::check_launch("conv3x3_wino4_f32");
 }
