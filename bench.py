@@ -75,7 +75,8 @@ def conv_roofline(prof, args, H, W, modules):
     tag = [r[5] if len(r) > 5 else "direct" for r in prof]
     # multiply-adds the MFMA pipe really performs: Winograd F(2x2,3x3) needs 16 products per 2x2 outputs and channel
     # pair instead of 36
-    executed = [r[6] if len(r) > 6 else (r[2] / 2.25 if t.startswith("winograd") else r[2]) for r, t in zip(prof, tag)]
+    executed = [r[6] if len(r) > 6 else (r[2] / 4.0 if t == "winograd4" else r[2] / 2.25 if t.startswith("winograd") else r[2])
+                for r, t in zip(prof, tag)]
     peak = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else F16_MFMA_PEAK_TFLOPS
 
     def agg(sel):
@@ -96,7 +97,8 @@ def conv_roofline(prof, args, H, W, modules):
     by_tag = {t: agg([x == t for x in tag]) for t in sorted(set(tag))}
     dominant = max(by_tag, key=lambda t: by_tag[t]["ms_per_step"])
     dom = by_tag[dominant]
-    kernel_of = {"winograd": "conv3x3_wino8_f32", "winograd_spatial": "conv3x3_wino8s_f32", "direct": "conv_igemm_f32",
+    kernel_of = {"winograd": "conv3x3_wino8_f32", "winograd_spatial": "conv3x3_wino8s_f32", "winograd4": "conv3x3_wino4_f32",
+                 "direct": "conv_igemm_f32",
                  "stem": "stem7x7_s2_f32",
                  "f16": "conv_igemm_f16", "rpn_fused": "conv_igemm_f32<heads>", "bottleneck": "bottleneck_fused_f32"}
     if args.dump_conv:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 9
+#define MRCNN_ABI_VERSION 10
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -246,7 +246,8 @@ int mrcnn_rpn_scores_deltas_f32(const float* const heads[5], const int32_t level
                                 float* scores, float* deltas, mrcnn_stream_t stream);
 /* The same with a per-level input form (level_mode[l]): 0 = NHWC [batch][H_l][W_l][18] head outputs as above;
  * 1 / 2 = the head sums of mrcnn_conv3x3_winograd_heads_f32 in tile mode 1 / 2: [2][rows][32] fp32 in that function's row
- * order, bias not yet added: logits/deltas = (sum of the two k halves) + head_bias[c]. level_h/level_w: H_l, W_l. */
+ * order, bias not yet added: logits/deltas = (sum of the two k halves) + head_bias[c]; 3 = the head sums of
+ * mrcnn_conv3x3_winograd4_heads_f32: [rows][32], logits/deltas = sum + head_bias[c]. level_h/level_w: H_l, W_l. */
 int mrcnn_rpn_scores_deltas_v2_f32(const float* const heads[5], const int32_t level_h[5], const int32_t level_w[5],
                                    const int32_t level_mode[5], const float* head_bias, int32_t batch, float* scores,
                                    float* deltas, mrcnn_stream_t stream);
@@ -302,6 +303,14 @@ int32_t mrcnn_conv3x3_winograd4_supported(int32_t height, int32_t width, int32_t
 int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width, int32_t cin,
                                 const float* u, int32_t cout, const float* scale, const float* shift, int32_t activation,
                                 float* y_nhwc, float* y_kblocked, mrcnn_stream_t stream);
+/* The F(4x4) form of mrcnn_conv3x3_winograd_heads_f32 (RPN shared conv + its two 1x1 heads, model.py:605-641, in one
+ * launch): head_part fp32 [rows][32], rows = mrcnn_conv3x3_winograd4_heads_rows(batch, H, W); row of pixel (b,y,x) =
+ * mt*512 + ((y/4 & 3)*8 + (x/4 & 7))*16 + (y&3)*4 + (x&3), mt = (b*ceil(H/16) + y/16)*ceil(W/32) + x/32; the sums over
+ * all cout channels without the head bias — input form 3 of mrcnn_rpn_scores_deltas_v2_f32. Fully overwritten. */
+int64_t mrcnn_conv3x3_winograd4_heads_rows(int32_t batch, int32_t height, int32_t width);
+int mrcnn_conv3x3_winograd4_heads_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                      const float* u, int32_t cout, const float* scale, const float* shift,
+                                      int32_t activation, const float* w_head32, float* head_part, mrcnn_stream_t stream);
 
 /* Tile shape of mrcnn_conv3x3_winograd_f32 on maps of at least 8 x 8 tile positions: 1 (default) = 8 x 8 position blocks of
  * one image with the input transform done per lane out of a raw LDS region (conv3x3_wino8s_f32), 0 = 64 consecutive

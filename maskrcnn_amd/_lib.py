@@ -66,6 +66,9 @@ _SIGS = {
     "mrcnn_conv3x3_winograd4_supported": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "mrcnn_conv3x3_winograd4_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32,
                                                      c_vp, c_vp, c_vp]),
+    "mrcnn_conv3x3_winograd4_heads_rows": (c_i64, [c_i32, c_i32, c_i32]),
+    "mrcnn_conv3x3_winograd4_heads_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32,
+                                                           c_vp, c_vp, c_vp]),
     "mrcnn_conv3x3_winograd_heads_rows": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     "mrcnn_conv3x3_winograd_heads_tile_mode": (c_i32, [c_i32, c_i32]),
     "mrcnn_conv3x3_winograd_heads_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32,

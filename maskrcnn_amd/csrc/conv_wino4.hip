@@ -40,6 +40,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // LDS-DMA destination / asm read addresses are 32-bit LDS offsets anyway)
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 
 struct Wino4Params {
     const float* x;      // k-blocked input  [Cin/8][B*H*W][8]
@@ -53,6 +55,11 @@ struct Wino4Params {
     int tiles_m, tiles_n;
     unsigned x_plane, u_ktile, yk_plane;  // bytes per 8-channel plane of x, per k tile of u, per 8-channel output plane
     unsigned x_bytes, u_bytes, y_bytes;
+    // fused 1x1 heads (HEADS): w_head [32][Cout] (rows >= the real head count are zero); head_part [tiles_m * 512 pixel
+    // rows, M-tile-major: row = mt * 512 + position * 16 + i * 4 + j][32] sums over all channels, without the bias
+    const float* w_head;
+    float* head_part;
+    unsigned head_bytes;
     int debug;  // MRCNN_W4_DEBUG: timing ablations (wrong results): 1 no DMA, 2 no transform, 4 no patch reads, 8 no B reads, 16 no raw staging
 };
 
@@ -64,6 +71,8 @@ constexpr int W4_UBUF = 36 * 256;                     // floats per U buffer: [3
 constexpr int W4_ZP = 10;                             // floats per (component, channel) row of the exchange buffer
 constexpr int W4_Z_FLOATS = 36 * 64 * W4_ZP;          // epilogue exchange of a round: [36][64 channels][8 positions, padded]
 constexpr size_t WINO4_LDS = sizeof(float) * (W4_RS_FLOATS + 2 * W4_UBUF);
+constexpr int W4_T_FLOATS = 128 * W4_N;               // HEADS: a round's 128 pixels x 64 channels, transposed, behind the rest
+constexpr size_t WINO4_HEADS_LDS = WINO4_LDS + sizeof(float) * W4_T_FLOATS;
 static_assert(W4_Z_FLOATS <= W4_RS_FLOATS + 2 * W4_UBUF, "the exchange buffer aliases the staging buffers");
 
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
@@ -158,6 +167,14 @@ __device__ __forceinline__ void bt3(const f32x2 e0, const f32x2 e1, const f32x2 
 #endif
 
 // A^T (4 x 6) applied to six samples: rows [1 1 1 1 1 0] [0 1 -1 2 -2 0] [0 1 1 4 4 0] [0 1 -1 8 -8 1]
+__device__ __forceinline__ void at4p(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4, const f32x2 m5,
+                                     const f32x2 k2, const f32x2 k4, const f32x2 k8, f32x2& y0, f32x2& y1, f32x2& y2, f32x2& y3) {
+    const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
+    y0 = pk_add(pk_add(m0, s12), s34);
+    y1 = pk_fma(k2, d34, d12);
+    y2 = pk_fma(k4, s34, s12);
+    y3 = pk_add(pk_fma(k8, d34, d12), m5);
+}
 __device__ __forceinline__ void at4(const float m0, const float m1, const float m2, const float m3, const float m4,
                                     const float m5, float& y0, float& y1, float& y2, float& y3) {
     const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
@@ -169,7 +186,10 @@ __device__ __forceinline__ void at4(const float m0, const float m1, const float 
 
 // One wave's share of the kernel; QA, QB = its quadrant of the component grid (compile-time: the transform's operations
 // differ per quadrant; the four waves of a workgroup run four instances of this code and meet at the same barriers).
-template <int QA, int QB, int DBG>
+// HEADS: the output tile is not stored; it feeds the RPN's two 1x1 heads on chip (as conv3x3_wino8s_f32<true> of
+// conv_wino.hip): a workgroup owns whole M tiles and walks their N tiles, adding each N tile's contribution to the M tile's
+// head sums in global memory.
+template <int QA, int QB, int DBG, bool HEADS>
 __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) {
     lds_f32x2* Rs = (lds_f32x2*)smem;            // [2][2][W4_RPLANE] channel pairs
     lds_f32* Us = smem + W4_RS_FLOATS;           // [2][36][2][64][2]
@@ -185,13 +205,24 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
     for (int it = 0;; ++it) {
         // virtual tile b, b + grid, ... in the XCD-aware order of conv_wino.hip: the workgroups of one XCD walk the N
         // tiles of neighbouring M tiles, so the raw input region is shared in that XCD's L2
-        const int tile = blockIdx.x + it * gridDim.x;
+        // HEADS: M-tile units b, b + grid, ..., each walked over all its N tiles by this workgroup
+        const int tile = HEADS ? (blockIdx.x + (it / p.tiles_n) * gridDim.x) * p.tiles_n + it % p.tiles_n
+                               : blockIdx.x + it * gridDim.x;
         if (tile >= total_tiles) break;
-        const int xcd = tile & 7, seq = tile >> 3;
+        int xcd, seq;
+        if constexpr (HEADS) {
+            const int unit = tile / p.tiles_n;
+            xcd = unit & 7;
+            seq = (unit >> 3) * p.tiles_n + (tile - unit * p.tiles_n);
+        } else {
+            xcd = tile & 7;
+            seq = tile >> 3;
+        }
         const int mt_lo = (xcd * p.tiles_m) >> 3, mt_hi = ((xcd + 1) * p.tiles_m) >> 3;
         const int mt = mt_lo + seq / p.tiles_n;
         if (mt >= mt_hi) continue;  // uniform
-        const int n0 = (seq % p.tiles_n) * W4_N;
+        const int nt = seq % p.tiles_n;
+        const int n0 = nt * W4_N;
         const int per_img = p.tyb * p.txb;
         const int b = mt / per_img, trem = mt - b * per_img;
         const int tby = trem / p.txb, tbx = trem - tby * p.txb;
@@ -375,15 +406,17 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         const __amdgpu_buffer_rsrc_t yk_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.yk, 0, p.yk ? p.y_bytes : 0u, 0x00020000);
         const unsigned ncol = static_cast<unsigned>(ng) * 4u;
         const unsigned kcol = static_cast<unsigned>(ng >> 3) * p.yk_plane + static_cast<unsigned>(ng & 7) * 4u;
-        // byte offsets of the 16 pixels of a position relative to its first one, as scalar offsets of the stores
-        int so_y[16], so_k[16];
+        // HEADS: the round's 128 pixels x 64 channels, [pixel][channel ^ swizzle], behind the exchange buffer
+        lds_f32* Tt = smem + W4_RS_FLOATS + 2 * W4_UBUF;
+        float4 wh[8];
+        if constexpr (HEADS) {  // lane = head ln; k step (j, e): channels n0 + 8 j + e (k = 0), + 4 (k = 1)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                so_y[i * 4 + j] = (i * p.W + j) * p.Cout * 4;
-                so_k[i * 4 + j] = (i * p.W + j) * 32;
-            }
+            for (int j = 0; j < 8; ++j)
+                wh[j] = *reinterpret_cast<const float4*>(p.w_head + static_cast<int64_t>(ln) * p.Cout + n0 + j * 8 + lh * 4);
+        }
+        const __amdgpu_buffer_rsrc_t hp_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.head_part, 0, HEADS ? p.head_bytes : 0u, 0x00020000);
+        const int pixstep_y = p.Cout * 4, rowstep_y = p.W * pixstep_y, rowstep_k = p.W * 32;  // scalar store offsets
+        const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k8 = {8.f, 8.f}, sc2 = {sc, sc}, sh2 = {sh, sh};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             // Z[component][channel][8 positions, pitch 10]: a lane's four positions (registers 4g..4g+3) are two 8-byte
@@ -400,64 +433,101 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                         *(lds_f32x2*)(zp + 2) = f32x2{a16[4 * g + 2], a16[4 * g + 3]};
                     }
             __syncthreads();
-            f32x2 m2[36];
+            // a thread's two positions (2 pq, 2 pq + 1) are the halves of packed operations
+            f32x2 w[6][4];
 #pragma unroll
-            for (int c = 0; c < 36; ++c) m2[c] = *(const lds_f32x2*)(Z + (c * 64 + n) * W4_ZP + 2 * pq);
+            for (int xi = 0; xi < 6; ++xi) {
+                f32x2 m[6];
+#pragma unroll
+                for (int nu = 0; nu < 6; ++nu) m[nu] = *(const lds_f32x2*)(Z + ((xi * 6 + nu) * 64 + n) * W4_ZP + 2 * pq);
+                at4p(m[0], m[1], m[2], m[3], m[4], m[5], k2, k4, k8, w[xi][0], w[xi][1], w[xi][2], w[xi][3]);
+            }
+            f32x2 yv[4][4];  // [j][i]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                at4p(w[0][j], w[1][j], w[2][j], w[3][j], w[4][j], w[5][j], k2, k4, k8, yv[j][0], yv[j][1], yv[j][2], yv[j][3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    yv[j][i] = pk_fma(yv[j][i], sc2, sh2);
+                    if (p.act) yv[j][i] = f32x2{fmaxf(yv[j][i].x, 0.f), fmaxf(yv[j][i].y, 0.f)};
+                }
+            }
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
                 const int p8 = 2 * pq + pp;
                 const int pos = 8 * g + p8;
                 const int TY = TY0 + (pos >> 3), TX = TX0 + (pos & 7);
                 const bool valid = TY < p.TH && TX < p.TW;
-                float w[6][4];
+                if (DBG & 32) { if (yv[0][0].x == 12345.678f) p.y[0] = yv[0][0].x; continue; }
+                if constexpr (HEADS) {
 #pragma unroll
-                for (int xi = 0; xi < 6; ++xi) {
-                    float m[6];
-#pragma unroll
-                    for (int nu = 0; nu < 6; ++nu) m[nu] = pp == 0 ? m2[xi * 6 + nu].x : m2[xi * 6 + nu].y;
-                    at4(m[0], m[1], m[2], m[3], m[4], m[5], w[xi][0], w[xi][1], w[xi][2], w[xi][3]);
-                }
-                float yv[4][4];  // [j][i]
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    at4(w[0][j], w[1][j], w[2][j], w[3][j], w[4][j], w[5][j], yv[j][0], yv[j][1], yv[j][2], yv[j][3]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        yv[j][i] = fmaf(yv[j][i], sc, sh);
-                        if (p.act) yv[j][i] = fmaxf(yv[j][i], 0.f);
+                    for (int q = 0; q < 16; ++q) {  // pixel row of the round: position p8, pixel q = i * 4 + j
+                        const int pxl = p8 * 16 + q;
+                        Tt[pxl * W4_N + (n ^ ((pxl & 15) << 2))] = pp == 0 ? yv[q & 3][q >> 2].x : yv[q & 3][q >> 2].y;
                     }
+                    continue;
                 }
-                if (DBG & 32) { if (yv[0][0] == 12345.678f) p.y[0] = yv[0][0]; continue; }
                 const unsigned pix = static_cast<unsigned>((b * p.H + 4 * TY) * p.W + 4 * TX);
                 if (p.y) {
                     const unsigned base = valid ? pix * static_cast<unsigned>(p.Cout) * 4u + ncol : OOB;
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[q & 3][q >> 2]), y_rsrc, static_cast<int>(base), so_y[q], 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pp == 0 ? yv[q & 3][q >> 2].x : yv[q & 3][q >> 2].y), y_rsrc,
+                                                              static_cast<int>(base), (q >> 2) * rowstep_y + (q & 3) * pixstep_y, 0);
                 }
                 if (p.yk) {
                     const unsigned base = valid ? pix * 32u + kcol : OOB;
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[q & 3][q >> 2]), yk_rsrc, static_cast<int>(base), so_k[q], 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pp == 0 ? yv[q & 3][q >> 2].x : yv[q & 3][q >> 2].y), yk_rsrc,
+                                                              static_cast<int>(base), (q >> 2) * rowstep_k + (q & 3) * 32, 0);
                 }
             }
             __syncthreads();  // Z is read out: the next round / the next tile's staging may overwrite it
+            if constexpr (HEADS) {
+                // wave w: pixels 32 w .. 32 w + 31 of the round x 32 heads x all 64 channels; the sums of the earlier N
+                // tiles come back from global memory (same workgroup, same lanes: plain read-modify-write)
+                const int row0 = mt * 512 + g * 128 + wave * 32 + 4 * lh;
+                const unsigned hbase = static_cast<unsigned>(row0) * 128u + static_cast<unsigned>(ln) * 4u;
+                f32x16 hacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    hacc[r] = 0.f;
+                    if (nt != 0)
+                        hacc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            hp_rsrc, static_cast<int>(hbase + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * 128u), 0, 0));
+                }
+                const int pxl = wave * 32 + ln;
+                const lds_f32* trow = Tt + pxl * W4_N;
+                const int swz = (pxl & 15) << 2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f32x4 a4 = *(const lds_f32x4*)(trow + ((j * 8 + lh * 4) ^ swz));
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, wh[j].x, hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, wh[j].y, hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, wh[j].z, hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, wh[j].w, hacc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hacc[r]), hp_rsrc,
+                                                          static_cast<int>(hbase + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * 128u), 0, 0);
+            }
         }
     }  // tiles
 }
 
 // DBG: timing ablations for tuning (wrong results): 1 no DMA, 2 no transform, 4 no patch reads, 8 no B reads, 16 no raw
 // staging. Only DBG = 0 is built unless MRCNN_W4_ABLATIONS is defined.
-template <int DBG>
+template <int DBG, bool HEADS>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const Wino4Params p) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     lds_f32* lds = (lds_f32*)smem;
-    if (wave == 0) wino4_wave<0, 0, DBG>(p, lds);
-    else if (wave == 1) wino4_wave<0, 1, DBG>(p, lds);
-    else if (wave == 2) wino4_wave<1, 0, DBG>(p, lds);
-    else wino4_wave<1, 1, DBG>(p, lds);
+    if (wave == 0) wino4_wave<0, 0, DBG, HEADS>(p, lds);
+    else if (wave == 1) wino4_wave<0, 1, DBG, HEADS>(p, lds);
+    else if (wave == 2) wino4_wave<1, 0, DBG, HEADS>(p, lds);
+    else wino4_wave<1, 1, DBG, HEADS>(p, lds);
 }
 
 // G g G^T in double, stored as the kernel's [Cin/4][36][2][Cout][2]. G (6 x 3):
@@ -535,20 +605,21 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
     p.x_bytes = static_cast<unsigned>(4LL * px * cin);
     p.u_bytes = static_cast<unsigned>(4LL * 36 * cin * cout);
     p.y_bytes = static_cast<unsigned>(4LL * px * cout);
+    p.w_head = nullptr; p.head_part = nullptr; p.head_bytes = 0;
     p.debug = getenv("MRCNN_W4_DEBUG") ? atoi(getenv("MRCNN_W4_DEBUG")) : 0;
     const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
     MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd4: grid too large");
-    void (*kern)(const Wino4Params) = conv3x3_wino4_f32<0>;
+    void (*kern)(const Wino4Params) = conv3x3_wino4_f32<0, false>;
 #ifdef MRCNN_W4_ABLATIONS
     switch (p.debug) {
-        case 1: kern = conv3x3_wino4_f32<1>; break;
-        case 2: kern = conv3x3_wino4_f32<2>; break;
-        case 4: kern = conv3x3_wino4_f32<4>; break;
-        case 8: kern = conv3x3_wino4_f32<8>; break;
-        case 16: kern = conv3x3_wino4_f32<16>; break;
-        case 31: kern = conv3x3_wino4_f32<31>; break;
-        case 63: kern = conv3x3_wino4_f32<63>; break;
-        case 95: kern = conv3x3_wino4_f32<95>; break;
+        case 1: kern = conv3x3_wino4_f32<1, false>; break;
+        case 2: kern = conv3x3_wino4_f32<2, false>; break;
+        case 4: kern = conv3x3_wino4_f32<4, false>; break;
+        case 8: kern = conv3x3_wino4_f32<8, false>; break;
+        case 16: kern = conv3x3_wino4_f32<16, false>; break;
+        case 31: kern = conv3x3_wino4_f32<31, false>; break;
+        case 63: kern = conv3x3_wino4_f32<63, false>; break;
+        case 95: kern = conv3x3_wino4_f32<95, false>; break;
         default: break;
     }
 #endif
@@ -560,4 +631,51 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
     const long long launch = grid > ncu ? ncu : grid;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(launch)), dim3(256), WINO4_LDS, mrcnn::as_stream(stream), p);
     return mrcnn::check_launch("conv3x3_wino4_f32");
+}
+
+extern "C" int64_t mrcnn_conv3x3_winograd4_heads_rows(int32_t batch, int32_t height, int32_t width) {
+    if (batch < 1 || height < 4 || width < 4 || height % 4 || width % 4) return 0;
+    return static_cast<int64_t>(batch) * ((height / 4 + 3) / 4) * ((width / 4 + 7) / 8) * 512;
+}
+
+extern "C" int mrcnn_conv3x3_winograd4_heads_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width,
+                                                 int32_t cin, const float* u, int32_t cout, const float* scale,
+                                                 const float* shift, int32_t activation, const float* w_head32,
+                                                 float* head_part, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x_kblocked && u && w_head32 && head_part, "conv3x3_winograd4_heads: null pointer");
+    MRCNN_REQUIRE(batch >= 1 && mrcnn_conv3x3_winograd4_supported(height, width, cin, cout),
+                  "conv3x3_winograd4_heads: B=%d H=%d W=%d (%% 4 == 0) Cin=%d (%% 8 == 0) Cout=%d (%% 64 == 0) required",
+                  batch, height, width, cin, cout);
+    MRCNN_REQUIRE(activation == 0 || activation == 1, "conv3x3_winograd4_heads: activation must be 0 or 1");
+    const long long px = 1LL * batch * height * width;
+    const long long rows = mrcnn_conv3x3_winograd4_heads_rows(batch, height, width);
+    MRCNN_REQUIRE(px * cin < (1LL << 30) && 36LL * cin * cout < (1LL << 30) && rows * 32 < (1LL << 30),
+                  "conv3x3_winograd4_heads: tensor too large (32-bit buffer byte offsets)");
+    Wino4Params p;
+    p.x = x_kblocked; p.u = u; p.scale = scale; p.shift = shift; p.y = nullptr; p.yk = nullptr;
+    p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout;
+    p.TH = height / 4; p.TW = width / 4; p.act = activation;
+    p.tyb = (p.TH + 3) / 4; p.txb = (p.TW + 7) / 8;
+    p.tiles_m = batch * p.tyb * p.txb;
+    p.tiles_n = cout / W4_N;
+    p.x_plane = static_cast<unsigned>(4LL * px * 8);
+    p.u_ktile = static_cast<unsigned>(4LL * 36 * 4 * cout);
+    p.yk_plane = 0;
+    p.x_bytes = static_cast<unsigned>(4LL * px * cin);
+    p.u_bytes = static_cast<unsigned>(4LL * 36 * cin * cout);
+    p.y_bytes = 0;
+    p.w_head = w_head32; p.head_part = head_part;
+    p.head_bytes = static_cast<unsigned>(4LL * rows * 32);
+    p.debug = 0;
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wino4_f32<0, true>), WINO4_HEADS_LDS,
+                                           "conv3x3_winograd4_heads"))
+        return rc;
+    const int cus = mrcnn::device_cu_count();
+    if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd4_heads: cannot query the device");
+    const int ncu = cus >= 8 ? (cus / 8) * 8 : 8;
+    const long long units = 8LL * ((p.tiles_m + 7) / 8);  // M-tile units; a workgroup walks the N tiles of its units
+    const long long launch = units < ncu ? units : ncu;
+    hipLaunchKernelGGL((conv3x3_wino4_f32<0, true>), dim3(static_cast<unsigned>(launch)), dim3(256), WINO4_HEADS_LDS,
+                       mrcnn::as_stream(stream), p);
+    return mrcnn::check_launch("conv3x3_wino4_f32<heads>");
 }

@@ -267,19 +267,30 @@ __global__ __launch_bounds__(256) void rpn_scores_deltas(RpnLevels lv, int B, in
             int64_t row;
             if (lv.mode[l] == 1) {  // 64 consecutive positions per M tile: plain position-major order
                 row = ((static_cast<int64_t>(b) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * 4 + (y & 1) * 2 + (x & 1);
-            } else {                // 8 x 8 position blocks: M-tile-major
+            } else if (lv.mode[l] == 2) {  // 8 x 8 position blocks: M-tile-major
                 const int ty = y >> 1, tx = x >> 1, tyb = ((H >> 1) + 7) >> 3, txb = ((W >> 1) + 7) >> 3;
                 const int64_t mt = (static_cast<int64_t>(b) * tyb + (ty >> 3)) * txb + (tx >> 3);
                 row = mt * 256 + (((ty & 7) << 3) + (tx & 7)) * 4 + (y & 1) * 2 + (x & 1);
+            } else {                       // F(4x4): 4 x 8 blocks of 4 x 4-pixel positions, M-tile-major, one part
+                const int ty = y >> 2, tx = x >> 2, tyb = ((H >> 2) + 3) >> 2, txb = ((W >> 2) + 7) >> 3;
+                const int64_t mt = (static_cast<int64_t>(b) * tyb + (ty >> 2)) * txb + (tx >> 3);
+                row = mt * 512 + (((ty & 3) << 3) + (tx & 7)) * 16 + (y & 3) * 4 + (x & 3);
             }
             const float* p0 = lv.y[l] + row * 32;
-            const float* p1 = p0 + static_cast<int64_t>(lv.rows[l]) * 32;
             const float* bs = lv.bias;
+            if (lv.mode[l] == 3) {
+                l0 = p0[2 * r] + bs[2 * r];
+                l1 = p0[2 * r + 1] + bs[2 * r + 1];
+                d = make_float4(p0[6 + 4 * r] + bs[6 + 4 * r], p0[7 + 4 * r] + bs[7 + 4 * r], p0[8 + 4 * r] + bs[8 + 4 * r],
+                                p0[9 + 4 * r] + bs[9 + 4 * r]);
+            } else {
+            const float* p1 = p0 + static_cast<int64_t>(lv.rows[l]) * 32;
             // fixed order: (k half 0 + k half 1) + bias
             l0 = (p0[2 * r] + p1[2 * r]) + bs[2 * r];
             l1 = (p0[2 * r + 1] + p1[2 * r + 1]) + bs[2 * r + 1];
             d = make_float4((p0[6 + 4 * r] + p1[6 + 4 * r]) + bs[6 + 4 * r], (p0[7 + 4 * r] + p1[7 + 4 * r]) + bs[7 + 4 * r],
                             (p0[8 + 4 * r] + p1[8 + 4 * r]) + bs[8 + 4 * r], (p0[9 + 4 * r] + p1[9 + 4 * r]) + bs[9 + 4 * r]);
+            }
         }
         const float m = fmaxf(l0, l1);
         const float e0 = expf(l0 - m), e1 = expf(l1 - m);
@@ -335,10 +346,12 @@ extern "C" int mrcnn_rpn_scores_deltas_v2_f32(const float* const heads[5], const
     lv.bias = head_bias;
     for (int l = 0; l < 5; ++l) {
         MRCNN_REQUIRE(heads[l] && level_h[l] >= 1 && level_w[l] >= 1, "rpn_scores_deltas: bad level %d", l);
-        MRCNN_REQUIRE(level_mode[l] == 0 || ((level_mode[l] == 1 || level_mode[l] == 2) && head_bias &&
-                                               level_h[l] % 2 == 0 && level_w[l] % 2 == 0),
+        MRCNN_REQUIRE(level_mode[l] == 0 ||
+                          ((level_mode[l] == 1 || level_mode[l] == 2) && head_bias && level_h[l] % 2 == 0 && level_w[l] % 2 == 0) ||
+                          (level_mode[l] == 3 && head_bias && level_h[l] % 4 == 0 && level_w[l] % 4 == 0),
                       "rpn_scores_deltas: level %d: mode must be 0 (NHWC heads), 1 or 2 (head sums of "
-                      "mrcnn_conv3x3_winograd_heads_f32 in tile mode 1 / 2: even H, W and a bias vector)", l);
+                      "mrcnn_conv3x3_winograd_heads_f32 in tile mode 1 / 2: even H, W and a bias vector) or 3 (head sums "
+                      "of mrcnn_conv3x3_winograd4_heads_f32: H, W multiples of 4 and a bias vector)", l);
         lv.y[l] = heads[l];
         lv.hw[l] = level_h[l] * level_w[l];
         lv.w[l] = level_w[l];

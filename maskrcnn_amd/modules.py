@@ -172,6 +172,18 @@ FUSED_BOTTLENECK = os.environ.get("MRCNN_FUSED_BOTTLENECK", "0") == "1"
 # MRCNN_RPN_FUSED_HEADS=0 keeps the separate 18-channel head conv everywhere.
 RPN_FUSED_HEADS = os.environ.get("MRCNN_RPN_FUSED_HEADS", "1") != "0"
 RPN_HEADS_MIN_TILES = 64
+# Winograd F(4x4,3x3) (ops.conv3x3_winograd4: 4x instead of 2.25x fewer multiply-adds, max |err| ~2e-5 at unit scale) for
+# the layers that ask for it — the FPN smoothing convs and the RPN's shared conv, the big 3x3 layers at the END of the
+# trunk, where its rounding does not travel through further layers — on maps of at least WINOGRAD4_MIN_TILES M tiles
+# (16 x 32 output pixels) PER IMAGE (never a function of the batch: image i alone == slice i of the batch); the RPN heads
+# are fused into it from WINOGRAD4_HEADS_MIN_TILES per image. MRCNN_WINOGRAD4=0 keeps F(2x2) everywhere.
+WINOGRAD4 = os.environ.get("MRCNN_WINOGRAD4", "1") != "0"
+WINOGRAD4_MIN_TILES = 8
+WINOGRAD4_HEADS_MIN_TILES = 32
+
+
+def winograd4_tiles_per_image(h: int, w: int) -> int:
+    return -(-(h // 4) // 4) * -(-(w // 4) // 8)
 # "f16" mode (BASELINE config 5's fp16 MFMA path): activations are fp16 in HBM between convs — fp32 only at the boundary,
 # at the RoIAlign inputs (the smoothed pyramid) and at the head outputs. A conv reading an fp16 tensor sees exactly the
 # operand it would have rounded an fp32 tensor to; residual adds, the stem max-pool and the stores see fp16.
@@ -185,15 +197,18 @@ class ConvWeight:
        f16x3  fp16-operand MFMA, error-compensated 3-product split          — fp32-grade accuracy (~2^-21)
        f16    fp16-operand MFMA, plain (BASELINE config 5's fp16 MFMA path) — ~2^-11 per term"""
 
-    def __init__(self, w_ohwi: torch.Tensor, precision: str = "f32"):
+    def __init__(self, w_ohwi: torch.Tensor, precision: str = "f32", winograd4: bool = False):
         assert precision in PRECISIONS, precision
         self.precision = precision
         self.shape = tuple(w_ohwi.shape)
         self.u = None
+        self.u4 = None
         if precision == "f32":
             self.w = w_ohwi.contiguous()
             if WINOGRAD and tuple(self.shape[1:3]) == (3, 3) and self.shape[3] % 8 == 0 and self.w.is_cuda:
                 self.u = ops.winograd_weights(self.w)
+                if winograd4 and WINOGRAD4 and self.shape[0] % 64 == 0:
+                    self.u4 = ops.winograd4_weights(self.w)
         else:
             cin = w_ohwi.size(3)
             if cin % 8:  # fp16 kernel loads 8 halves at a time
@@ -214,12 +229,20 @@ class ConvWeight:
         return (self.u is not None and stride == 1 and tuple(pad) == (1, 1, 1, 1) and residual is None
                 and relu in (False, True, 0, 1) and h % 2 == 0 and w % 2 == 0)
 
+    def takes_winograd4(self, h, w, stride=1, pad=(1, 1, 1, 1), residual=None, relu=False):
+        """Would conv() run the F(4x4) kernel for a K-BLOCKED [., h, w, .] input with these arguments?"""
+        return (self.u4 is not None and self.takes_winograd(h, w, stride, pad, residual, relu)
+                and ops.conv3x3_winograd4_supported(h, w, self.shape[3], self.shape[0])
+                and winograd4_tiles_per_image(h, w) >= WINOGRAD4_MIN_TILES)
+
     def conv(self, x, scale, shift, stride=1, pad=(0, 0, 0, 0), relu=False, residual=None, res_div=1,
              algo_cin=None, out="nhwc", out_f16=False):
         """out: "nhwc" (default), or for the f32 mode "kblocked" / "both" (ops.conv3x3_winograd): the layout the next
         Winograd conv reads. x may itself be k-blocked (5-d) when this conv takes the Winograd kernel."""
         if self.precision == "f32":
             hh, ww = (x.size(2), x.size(3)) if x.dim() == 5 else (x.size(1), x.size(2))
+            if x.dim() == 5 and self.takes_winograd4(hh, ww, stride, pad, residual, relu):
+                return ops.conv3x3_winograd4(x, self.u4, scale, shift, bool(relu), algo_cin, out)
             if self.takes_winograd(hh, ww, stride, pad, residual, relu):
                 return ops.conv3x3_winograd(x, self.u, scale, shift, bool(relu), algo_cin, out)
             assert x.dim() == 4 and out in ("nhwc", "kblocked")
@@ -235,11 +258,11 @@ class FusedConv:
     """conv (+BN) (+ReLU) with SAME-style explicit padding, NHWC."""
 
     def __init__(self, sd, conv, bn, device, stride=1, relu=False, same_pad_kernel: int | None = None,
-                 pad=(0, 0, 0, 0), cin_pad=None, precision="f32", out_f16: bool | None = None):
+                 pad=(0, 0, 0, 0), cin_pad=None, precision="f32", out_f16: bool | None = None, winograd4: bool = False):
         # "f16" mode: the output is stored fp16 unless the layer says otherwise (out_f16=False: tensors that RoIAlign
         # or the caller reads)
         self.out_f16 = (precision == "f16" and F16_ACT) if out_f16 is None else (bool(out_f16) and precision == "f16" and F16_ACT)
-        self.w = ConvWeight(pack_weight(sd[conv + ".weight"], device, cin_pad), precision)
+        self.w = ConvWeight(pack_weight(sd[conv + ".weight"], device, cin_pad), precision, winograd4)
         self.scale, self.shift = fold_bn(sd, conv, bn, device)
         self.stride, self.relu, self.same_k, self.pad = stride, relu, same_pad_kernel, pad
         self.algo_cin = sd[conv + ".weight"].size(1)  # un-padded Cin for FLOP accounting
@@ -354,7 +377,8 @@ class FusedBackbone:
         self.lateral = {k: FusedConv(sd, f"{prefix}P{k}_conv1", None, device, precision=precision)
                         for k in (5, 4, 3, 2)}
         self.smooth = {k: FusedConv(sd, f"{prefix}P{k}_conv2.1", None, device, same_pad_kernel=3,
-                                    precision=precision, out_f16=False) for k in (5, 4, 3, 2)}   # RoIAlign reads these
+                                    precision=precision, out_f16=False, winograd4=True)
+                       for k in (5, 4, 3, 2)}   # RoIAlign reads these
 
     def __call__(self, image_nchw):
         x = ops.nchw_to_nhwc(image_nchw.contiguous(), self.cin_pad)   # 3 → 4 (8) channels, zero-padded
@@ -423,7 +447,7 @@ class FusedRPN:
             self.head_n = w.size(0)
         else:
             self.shared = FusedConv(sd, prefix + "conv_shared", None, device, relu=True, same_pad_kernel=3,
-                                    precision=precision)
+                                    precision=precision, winograd4=True)
             self.w_head = ConvWeight(pack_weight(w, device), precision)
             if precision == "f32" and self.shared.w.u is not None:   # heads inside the Winograd kernel (large levels)
                 w32 = torch.zeros(32, w.size(1), dtype=torch.float32)
@@ -436,7 +460,14 @@ class FusedRPN:
             return ops.rpn_level_fused(p, self.w_shared, self.b_shared, self.w_head32, self.b_head, self.head_n)
         if p_kblocked is not None and self.shared.takes_winograd(p.size(1), p.size(2)):
             b, h, w = p.size(0), p.size(1), p.size(2)
+            sw = self.shared.w
             if (RPN_FUSED_HEADS and getattr(self, "w_head32", None) is not None
+                    and sw.takes_winograd4(h, w, 1, (1, 1, 1, 1), None, True)
+                    and winograd4_tiles_per_image(h, w) >= WINOGRAD4_HEADS_MIN_TILES):
+                return ops.conv3x3_winograd4_heads(p_kblocked, sw.u4, self.shared.scale, self.shared.shift,
+                                                   self.w_head32, True, self.shared.algo_cin)
+            if (RPN_FUSED_HEADS and getattr(self, "w_head32", None) is not None
+                    and not sw.takes_winograd4(h, w, 1, (1, 1, 1, 1), None, True)
                     and -(-((h // 2) * (w // 2)) // 64) >= RPN_HEADS_MIN_TILES and self.shared.w.shape[0] % 64 == 0):
                 return ops.conv3x3_winograd_heads(p_kblocked, self.shared.w.u, self.shared.scale, self.shared.shift,
                                                   self.w_head32, True, self.shared.algo_cin)

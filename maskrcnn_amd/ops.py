@@ -501,6 +501,11 @@ class HeadSums:
             t = b * th * tw
             v = (self.part[0, :t * 4, :18] + self.part[1, :t * 4, :18]) + bias
             return v.view(b, th, tw, 2, 2, 18).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, 18).contiguous()
+        if self.tile_mode == 3:                                            # F(4x4): rows (b, tyb, txb, py4, px8, i4, j4)
+            tyb, txb = -(-(h // 4) // 4), -(-(w // 4) // 8)
+            v = self.part[:, :18] + bias
+            v = v.view(b, tyb, txb, 4, 8, 4, 4, 18).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(b, tyb * 16, txb * 32, 18)
+            return v[:, :h, :w].contiguous()
         tyb, txb = -(-th // 8), -(-tw // 8)
         v = (self.part[0, :, :18] + self.part[1, :, :18]) + bias          # rows: (b, tyb, txb, py, px, a, c)
         v = v.view(b, tyb, txb, 8, 8, 2, 2, 18).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(b, tyb * 16, txb * 16, 18)
@@ -941,6 +946,34 @@ def conv3x3_winograd4(x_kblocked: torch.Tensor, u4: torch.Tensor, scale, shift, 
                      4.0 * (m * cin + m * cout * (2 if out == "both" else 1) + 4 * cout * k), "winograd4",
                      2.0 * m * cout * k / 4.0))
     return y if out == "nhwc" else yk if out == "kblocked" else (y, yk)
+
+
+@_on_device
+def conv3x3_winograd4_heads(x_kblocked: torch.Tensor, u4: torch.Tensor, scale, shift, w_head32: torch.Tensor,
+                            relu: bool = True, algo_cin=None) -> HeadSums:
+    """The RPN level in one launch on the F(4x4) kernel: relu(conv3x3_same(x)*scale+shift) and its two 1x1 heads
+    (w_head32 [32, Cout]: rows 0..17 = conv_class then conv_bbox) → HeadSums with tile_mode 3."""
+    _need_gpu(x_kblocked, u4, scale, shift, w_head32)
+    assert x_kblocked.dim() == 5 and x_kblocked.is_contiguous() and x_kblocked.dtype == torch.float32
+    g, b, h, w, _ = x_kblocked.shape
+    cin, cout = g * 8, u4.size(3)
+    assert u4.is_contiguous() and u4.size(0) * 4 == cin and conv3x3_winograd4_supported(h, w, cin, cout)
+    assert w_head32.is_contiguous() and tuple(w_head32.shape) == (32, cout)
+    rows = int(lib.mrcnn_conv3x3_winograd4_heads_rows(b, h, w))
+    part = torch.empty(rows, 32, dtype=torch.float32, device=x_kblocked.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mrcnn_conv3x3_winograd4_heads_f32(x_kblocked.data_ptr(), b, h, w, cin, u4.data_ptr(), cout, _ptr(scale),
+                                                _ptr(shift), 1 if relu else 0, w_head32.data_ptr(), part.data_ptr(),
+                                                _stream()))
+    if prof is not None:
+        e1.record()
+        m, k = b * h * w, 9 * (algo_cin or cin)
+        prof.append((e0, e1, 2.0 * m * cout * (k + 18), (m, cout, k), 4.0 * (m * cin + part.numel() + 4 * cout * k),
+                     "winograd4", 2.0 * m * cout * (k / 4.0 + 32)))
+    return HeadSums(part, b, h, w, 3)
 
 
 @_on_device

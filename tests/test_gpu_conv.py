@@ -627,3 +627,35 @@ def test_conv3x3_winograd4_vs_torch_cpu(dev, b, h, w, cin, cout, relu):
     assert torch.equal(ops.nhwc_to_kblocked(y), yk)
     y2 = ops.conv3x3_winograd4(xk, u4, sc.to(dev), sh.to(dev), relu, out="nhwc")
     assert torch.equal(y2, y)                                         # deterministic
+
+
+@pytest.mark.parametrize("b,h,w", [(1, 16, 32), (2, 32, 64), (2, 20, 28), (1, 64, 64)])
+def test_winograd4_fused_rpn_heads(dev, b, h, w):
+    """F(4x4) shared conv + both 1x1 heads in one launch (model.py:605-641) against torch-CPU, then through the
+    scores/deltas kernel in its input form 3 against the NHWC form."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(h * 7 + w)
+    cin, cout = 64, 128
+    x = torch.randn(b, h, w, cin, generator=g).clamp_(min=0)
+    wt = torch.randn(cout, 3, 3, cin, generator=g) / (9 * cin * 0.5) ** 0.5
+    bs = torch.randn(cout, generator=g) * 0.1
+    wh = torch.randn(18, cout, generator=g) / (cout * 0.5) ** 0.5
+    bh = torch.randn(18, generator=g) * 0.1
+    shared = F.relu(F.conv2d(x.permute(0, 3, 1, 2).double(), wt.permute(0, 3, 1, 2).double(), bs.double(), padding=1))
+    ref = (torch.einsum("bchw,oc->bhwo", shared, wh.double()) + bh.double()).float()
+    w32 = torch.zeros(32, cout)
+    w32[:18] = wh
+    xk = ops.nhwc_to_kblocked(x.to(dev))
+    u4 = ops.winograd4_weights(wt.to(dev).contiguous())
+    sums = ops.conv3x3_winograd4_heads(xk, u4, None, bs.to(dev), w32.to(dev), True)
+    assert sums.tile_mode == 3
+    got = sums.to_nhwc(bh.to(dev)).cpu()
+    err = (got - ref).abs().max().item()
+    assert err <= TOL, f"max|err| {err:.3g} at max|ref| {ref.abs().max().item():.3g}"
+    again = ops.conv3x3_winograd4_heads(xk, u4, None, bs.to(dev), w32.to(dev), True)
+    assert torch.equal(again.to_nhwc(bh.to(dev)).cpu(), got)                          # deterministic
+    # the consumer reads the M-tile-major rows directly: same scores / deltas as from the NHWC form
+    small = [torch.randn(b, 4, 4, 18, generator=g).to(dev) for _ in range(4)]
+    s_a, d_a = ops.rpn_scores_deltas([sums] + small, bh.to(dev))
+    s_b, d_b = ops.rpn_scores_deltas([got.to(dev)] + small, bh.to(dev))
+    assert torch.equal(s_a, s_b) and torch.equal(d_a, d_b)
