@@ -178,6 +178,7 @@ RPN_HEADS_MIN_TILES = 64
 # (16 x 32 output pixels) PER IMAGE (never a function of the batch: image i alone == slice i of the batch); the RPN heads
 # are fused into it from WINOGRAD4_HEADS_MIN_TILES per image. MRCNN_WINOGRAD4=0 keeps F(2x2) everywhere.
 WINOGRAD4 = os.environ.get("MRCNN_WINOGRAD4", "1") != "0"
+WINOGRAD4_TRUNK = os.environ.get("MRCNN_WINOGRAD4_TRUNK", "1") != "0"   # also the Bottleneck conv2 layers (C2-C4 sizes)
 WINOGRAD4_MIN_TILES = 8
 WINOGRAD4_HEADS_MIN_TILES = 32
 
@@ -293,7 +294,7 @@ class FusedBottleneck:
         if precision != "f32" or WINOGRAD:
             c1 = FusedConv(sd, pre + "conv1", pre + "bn1", device, stride=stride, relu=True, precision=precision)
             c2 = FusedConv(sd, pre + "conv2", pre + "bn2", device, relu=True, same_pad_kernel=3,
-                           precision=precision)
+                           precision=precision, winograd4=WINOGRAD4_TRUNK)
             c3 = FusedConv(sd, pre + "conv3", pre + "bn3", device, relu=True, precision=precision)
             cd = None
             if (pre + "downsample.0.weight") in sd:

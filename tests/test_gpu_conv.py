@@ -449,7 +449,14 @@ def test_bottleneck_fused_whole_block(dev, shape):
     x = torch.randn(b, 256, h, w, generator=g)
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
     assert ops.bottleneck_fused_supported(h, w, 256, 64)
-    blk = modules.FusedBottleneck.from_state_dict(sd, "", 1, dev)
+    saved4 = modules.WINOGRAD4_TRUNK
+    try:
+        modules.WINOGRAD4_TRUNK = False      # the fused launch holds F(2x2): compare it with the F(2x2) three-launch path
+        blk = modules.FusedBottleneck.from_state_dict(sd, "", 1, dev)
+        modules.WINOGRAD4_TRUNK = True
+        blk4 = modules.FusedBottleneck.from_state_dict(sd, "", 1, dev)
+    finally:
+        modules.WINOGRAD4_TRUNK = saved4
     c1, c2, c3, cd = blk.convs
     assert cd is None
     fused = ops.bottleneck_fused(xd, c1.w.w, c1.scale, c1.shift, c2.w.u, c2.scale, c2.shift, c3.w.w, c3.scale, c3.shift)
@@ -467,6 +474,15 @@ def test_bottleneck_fused_whole_block(dev, shape):
     want = _ref_bottleneck(x, sd)
     err = (fused.permute(0, 3, 1, 2).cpu() - want).abs().max().item()
     assert err <= TOL, f"max abs err {err:.3e} (|ref|max {want.abs().max().item():.2f})"
+    # the three-launch path with conv2 on the F(4x4) kernel (where the map is large enough) meets the same bar
+    saved = modules.FUSED_BOTTLENECK
+    try:
+        modules.FUSED_BOTTLENECK = False
+        got4 = blk4(xd)
+    finally:
+        modules.FUSED_BOTTLENECK = saved
+    err4 = (got4.permute(0, 3, 1, 2).cpu() - want).abs().max().item()
+    assert err4 <= TOL, f"F(4x4): max abs err {err4:.3e} (|ref|max {want.abs().max().item():.2f})"
     # the registered op with the reference-shaped argument list routes to the same launch
     y = torch.ops.maskrcnn.bottleneck_forward(xd, c1.w.w, c1.scale, c1.shift, c2.w.w, c2.scale, c2.shift, c3.w.w,
                                               c3.scale, c3.shift, None, None, None, 1)
