@@ -72,7 +72,8 @@ constexpr int W4_ZP = 10;                             // floats per (component, 
 constexpr int W4_Z_FLOATS = 36 * 64 * W4_ZP;          // epilogue exchange of a round: [36][64 channels][8 positions, padded]
 constexpr size_t WINO4_LDS = sizeof(float) * (W4_RS_FLOATS + 2 * W4_UBUF);
 constexpr int W4_T_FLOATS = 128 * W4_N;               // HEADS: a round's 128 pixels x 64 channels, transposed, behind the rest
-constexpr size_t WINO4_HEADS_LDS = WINO4_LDS + sizeof(float) * W4_T_FLOATS;
+constexpr int W4_WH_FLOATS = 8 * 256;                 // HEADS: the N tile's head weights as the 8 B-operand pieces [j][lane][4]
+constexpr size_t WINO4_HEADS_LDS = WINO4_LDS + sizeof(float) * (W4_T_FLOATS + W4_WH_FLOATS);
 static_assert(W4_Z_FLOATS <= W4_RS_FLOATS + 2 * W4_UBUF, "the exchange buffer aliases the staging buffers");
 
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
@@ -408,11 +409,16 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         const unsigned kcol = static_cast<unsigned>(ng >> 3) * p.yk_plane + static_cast<unsigned>(ng & 7) * 4u;
         // HEADS: the round's 128 pixels x 64 channels, [pixel][channel ^ swizzle], behind the exchange buffer
         lds_f32* Tt = smem + W4_RS_FLOATS + 2 * W4_UBUF;
-        float4 wh[8];
-        if constexpr (HEADS) {  // lane = head ln; k step (j, e): channels n0 + 8 j + e (k = 0), + 4 (k = 1)
+        // the N tile's head weights: piece j = what lane (head ln, half lh) multiplies in k steps 4j..4j+3 (channels
+        // n0 + 8 j + 4 lh + e), by LDS-DMA behind T — in registers they are 32 VGPRs the transform below has not got
+        lds_f32* Wh = Tt + W4_T_FLOATS;
+        if constexpr (HEADS) {
+            const __amdgpu_buffer_rsrc_t wh_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w_head), 0, static_cast<unsigned>(p.Cout) * 128u, 0x00020000);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                wh[j] = *reinterpret_cast<const float4*>(p.w_head + static_cast<int64_t>(ln) * p.Cout + n0 + j * 8 + lh * 4);
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = wave * 2 + jj;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wh_rsrc, Wh + j * 256, 16, static_cast<int>((ln * p.Cout + n0 + lh * 4) * 4), j * 32, 0, 0);
+            }
         }
         const __amdgpu_buffer_rsrc_t hp_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.head_part, 0, HEADS ? p.head_bytes : 0u, 0x00020000);
         const int pixstep_y = p.Cout * 4, rowstep_y = p.W * pixstep_y, rowstep_k = p.W * 32;  // scalar store offsets
@@ -442,49 +448,53 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                 for (int nu = 0; nu < 6; ++nu) m[nu] = *(const lds_f32x2*)(Z + ((xi * 6 + nu) * 64 + n) * W4_ZP + 2 * pq);
                 at4p(m[0], m[1], m[2], m[3], m[4], m[5], k2, k4, k8, w[xi][0], w[xi][1], w[xi][2], w[xi][3]);
             }
-            f32x2 yv[4][4];  // [j][i]
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                at4p(w[0][j], w[1][j], w[2][j], w[3][j], w[4][j], w[5][j], k2, k4, k8, yv[j][0], yv[j][1], yv[j][2], yv[j][3]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    yv[j][i] = pk_fma(yv[j][i], sc2, sh2);
-                    if (p.act) yv[j][i] = f32x2{fmaxf(yv[j][i].x, 0.f), fmaxf(yv[j][i].y, 0.f)};
-                }
-            }
+            // second stage per output column j: its four pixels (i = 0..3) of both positions leave right away
+            unsigned base_y[2], base_k[2];
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
-                const int p8 = 2 * pq + pp;
-                const int pos = 8 * g + p8;
+                const int pos = 8 * g + 2 * pq + pp;
                 const int TY = TY0 + (pos >> 3), TX = TX0 + (pos & 7);
                 const bool valid = TY < p.TH && TX < p.TW;
-                if (DBG & 32) { if (yv[0][0].x == 12345.678f) p.y[0] = yv[0][0].x; continue; }
-                if constexpr (HEADS) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {  // pixel row of the round: position p8, pixel q = i * 4 + j
-                        const int pxl = p8 * 16 + q;
-                        Tt[pxl * W4_N + (n ^ ((pxl & 15) << 2))] = pp == 0 ? yv[q & 3][q >> 2].x : yv[q & 3][q >> 2].y;
-                    }
-                    continue;
-                }
                 const unsigned pix = static_cast<unsigned>((b * p.H + 4 * TY) * p.W + 4 * TX);
-                if (p.y) {
-                    const unsigned base = valid ? pix * static_cast<unsigned>(p.Cout) * 4u + ncol : OOB;
+                base_y[pp] = valid ? pix * static_cast<unsigned>(p.Cout) * 4u + ncol : OOB;
+                base_k[pp] = valid ? pix * 32u + kcol : OOB;
+            }
 #pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pp == 0 ? yv[q & 3][q >> 2].x : yv[q & 3][q >> 2].y), y_rsrc,
-                                                              static_cast<int>(base), (q >> 2) * rowstep_y + (q & 3) * pixstep_y, 0);
+            for (int j = 0; j < 4; ++j) {
+                f32x2 yv[4];
+                at4p(w[0][j], w[1][j], w[2][j], w[3][j], w[4][j], w[5][j], k2, k4, k8, yv[0], yv[1], yv[2], yv[3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    yv[i] = pk_fma(yv[i], sc2, sh2);
+                    if (p.act) yv[i] = f32x2{fmaxf(yv[i].x, 0.f), fmaxf(yv[i].y, 0.f)};
                 }
-                if (p.yk) {
-                    const unsigned base = valid ? pix * 32u + kcol : OOB;
+                if (DBG & 32) { if (yv[0].x == 12345.678f) p.y[0] = yv[0].x; continue; }
 #pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pp == 0 ? yv[q & 3][q >> 2].x : yv[q & 3][q >> 2].y), yk_rsrc,
-                                                              static_cast<int>(base), (q >> 2) * rowstep_k + (q & 3) * 32, 0);
+                for (int pp = 0; pp < 2; ++pp) {
+                    if constexpr (HEADS) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {  // pixel row of the round: position 2 pq + pp, pixel i * 4 + j
+                            const int pxl = (2 * pq + pp) * 16 + i * 4 + j;
+                            Tt[pxl * W4_N + (n ^ ((pxl & 15) << 2))] = pp == 0 ? yv[i].x : yv[i].y;
+                        }
+                    } else {
+                        if (p.y) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pp == 0 ? yv[i].x : yv[i].y), y_rsrc,
+                                                                      static_cast<int>(base_y[pp]), i * rowstep_y + j * pixstep_y, 0);
+                        }
+                        if (p.yk) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pp == 0 ? yv[i].x : yv[i].y), yk_rsrc,
+                                                                      static_cast<int>(base_k[pp]), i * rowstep_k + j * 32, 0);
+                        }
+                    }
                 }
             }
             __syncthreads();  // Z is read out: the next round / the next tile's staging may overwrite it
-            if constexpr (HEADS) {
+            if constexpr (HEADS && !(DBG & 128)) {
                 // wave w: pixels 32 w .. 32 w + 31 of the round x 32 heads x all 64 channels; the sums of the earlier N
                 // tiles come back from global memory (same workgroup, same lanes: plain read-modify-write)
                 const int row0 = mt * 512 + g * 128 + wave * 32 + 4 * lh;
@@ -503,10 +513,11 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const f32x4 a4 = *(const lds_f32x4*)(trow + ((j * 8 + lh * 4) ^ swz));
-                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, wh[j].x, hacc, 0, 0, 0);
-                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, wh[j].y, hacc, 0, 0, 0);
-                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, wh[j].z, hacc, 0, 0, 0);
-                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, wh[j].w, hacc, 0, 0, 0);
+                    const f32x4 b4 = *(const lds_f32x4*)(Wh + j * 256 + lane * 4);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, hacc, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, hacc, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
@@ -564,6 +575,7 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restr
 }
 
 }  // namespace
+
 
 extern "C" int mrcnn_winograd4_weights_f32(const float* w_ohwi, int32_t cout, int32_t cin, float* u,
                                            mrcnn_stream_t stream) {
@@ -666,16 +678,23 @@ extern "C" int mrcnn_conv3x3_winograd4_heads_f32(const float* x_kblocked, int32_
     p.y_bytes = 0;
     p.w_head = w_head32; p.head_part = head_part;
     p.head_bytes = static_cast<unsigned>(4LL * rows * 32);
-    p.debug = 0;
-    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wino4_f32<0, true>), WINO4_HEADS_LDS,
-                                           "conv3x3_winograd4_heads"))
+    p.debug = getenv("MRCNN_W4_DEBUG") ? atoi(getenv("MRCNN_W4_DEBUG")) : 0;
+    void (*kern)(const Wino4Params) = conv3x3_wino4_f32<0, true>;
+#ifdef MRCNN_W4_ABLATIONS
+    switch (p.debug) {
+        case 32: kern = conv3x3_wino4_f32<32, true>; break;
+        case 128: kern = conv3x3_wino4_f32<128, true>; break;
+        case 160: kern = conv3x3_wino4_f32<160, true>; break;
+        default: break;
+    }
+#endif
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), WINO4_HEADS_LDS, "conv3x3_winograd4_heads"))
         return rc;
     const int cus = mrcnn::device_cu_count();
     if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd4_heads: cannot query the device");
     const int ncu = cus >= 8 ? (cus / 8) * 8 : 8;
     const long long units = 8LL * ((p.tiles_m + 7) / 8);  // M-tile units; a workgroup walks the N tiles of its units
     const long long launch = units < ncu ? units : ncu;
-    hipLaunchKernelGGL((conv3x3_wino4_f32<0, true>), dim3(static_cast<unsigned>(launch)), dim3(256), WINO4_HEADS_LDS,
-                       mrcnn::as_stream(stream), p);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(launch)), dim3(256), WINO4_HEADS_LDS, mrcnn::as_stream(stream), p);
     return mrcnn::check_launch("conv3x3_wino4_f32<heads>");
 }

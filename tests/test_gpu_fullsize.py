@@ -102,6 +102,34 @@ def test_winograd_full_spatial_size_vs_torch_cpu(dev, case):
     assert err <= 1e-4, f"max|err| {err:.3e} > 1e-4 abs (max|ref| {rng:.2f})"
 
 
+@pytest.mark.parametrize("case", [c for c in FULL_3X3 if c[1] % 4 == 0 and c[2] % 4 == 0 and c[4] % 64 == 0 and c[1] >= 64],
+                         ids=lambda c: "x".join(str(v) for v in c[:5]))
+def test_winograd4_full_spatial_size_vs_torch_cpu(dev, case):
+    """The Winograd F(4x4,3x3) kernel on every layer shape the pipeline routes to it (modules.WINOGRAD4*: FPN smoothing,
+    RPN shared conv, Bottleneck conv2, maps of 64 x 64 and more) at FULL spatial size, same data and the same 1e-4
+    absolute bar as the F(2x2) test above."""
+    from maskrcnn_amd import ops
+    b, h, w, cin, cout, relu, affine = case
+    g = torch.Generator().manual_seed(1000 + h + cin + cout + b)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin))
+    scale = (torch.rand(cout, generator=g) + 0.5) if affine else None
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x, wt, None, padding=1)
+    if scale is not None:
+        ref = ref * scale.view(1, -1, 1, 1)
+    ref = ref + shift.view(1, -1, 1, 1)
+    ref = (F.relu(ref) if relu else ref).permute(0, 2, 3, 1)
+    u4 = ops.winograd4_weights(wt.permute(0, 2, 3, 1).contiguous().to(dev))
+    xk = ops.nhwc_to_kblocked(x.permute(0, 2, 3, 1).contiguous().to(dev))
+    y = ops.conv3x3_winograd4(xk, u4, None if scale is None else scale.to(dev), shift.to(dev), relu).cpu()
+    err = (y - ref).abs().max().item()
+    rng = ref.abs().max().item()
+    REPORT["layer3x3_f4/" + "x".join(str(v) for v in case[:5])] = {"max_abs_err": err, "max_abs_ref": rng, "bar": 1e-4,
+                                                                   "meets_1e-4_abs": bool(err <= 1e-4)}
+    assert err <= 1e-4, f"max|err| {err:.3e} > 1e-4 abs (max|ref| {rng:.2f})"
+
+
 FULL_1X1 = [
     # (B, H, W, Cin, Cout, stride, relu, residual)  — the direct kernel's bottleneck layers at full spatial size
     (1, 256, 256, 64, 256, 1, True, True),      # C2 conv3 + residual

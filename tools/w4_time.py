@@ -18,3 +18,12 @@ e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / 10
 fl = 2.0 * b * h * w * cout * 9 * cin / 4.0
 print(f"W4_DEBUG={os.environ.get('MRCNN_W4_DEBUG', '0')}: {t:.3f} ms ({fl/t/1e9/157.3:.3f})", flush=True)
+# the same layer with the RPN heads fused
+w32 = torch.zeros(32, cout, device=dev); w32[:18] = torch.randn(18, cout, generator=g).to(dev) * 0.02
+for _ in range(3): ops.conv3x3_winograd4_heads(x, u4, None, sh, w32, True)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(10): ops.conv3x3_winograd4_heads(x, u4, None, sh, w32, True)
+e1.record(); torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / 10
+print(f"  with heads: {t:.3f} ms ({fl/t/1e9/157.3:.3f})", flush=True)
