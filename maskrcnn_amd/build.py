@@ -28,7 +28,7 @@ SOURCES = {
     "conv.hip": [],
     "conv_f16.hip": [],
     "conv_wino.hip": [],
-    "conv_wino4.hip": (["-DMRCNN_W4_ABLATIONS"] if os.environ.get("MRCNN_W4_ABLATIONS") else []) + (["-DMRCNN_W4_SCALAR_T"] if os.environ.get("MRCNN_W4_SCALAR_T") else []),
+    "conv_wino4.hip": (["-DMRCNN_W4_ABLATIONS"] if os.environ.get("MRCNN_W4_ABLATIONS") else []),
     "stem.hip": [],
     "bottleneck.hip": [],
     "misc.hip": ["-ffp-contract=off"],

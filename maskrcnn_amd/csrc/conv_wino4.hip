@@ -6,7 +6,8 @@
 // (tests/test_gpu_conv.py).
 //
 //   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A       g: 3x3 filter, d: 6x6 input patch, Y: 4x4 outputs
-//   interpolation points 0, +-1, +-2, inf (Lavin & Gray 2015, the matrices below)
+//   interpolation points 0, +-3/4, +-3/2, inf: the usual 0, +-1, +-2 scaled by 3/4, which cuts the fp32 error of the
+//   transforms to a third (measured; every matrix entry stays a dyadic rational, exact in fp32)
 //
 //   GEMM view   36 independent products, one per transform component (xi, nu): M[T x N] = V[T x C] U[C x N], T = tile
 //               positions (one per 4x4 output pixels), N = Cout, C = Cin.
@@ -91,6 +92,11 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {  // a * b +
     asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 b, f32x2 c) {  // c - a * b
     f32x2 r;
     asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -117,74 +123,49 @@ __device__ __forceinline__ f32x2 lds_read_b64(unsigned addr, int offset) {
     return v;
 }
 
-// Three rows of B^T applied to five consecutive samples. B^T (6 x 6), rows 0..5:
-//   [4 0 -5 0 1 0] [0 -4 -4 1 1 0] [0 4 -4 -1 1 0] [0 -2 -1 2 1 0] [0 2 -1 -2 1 0] [0 4 0 -5 0 1]
-// Q = 0: rows 0..2 of samples d0..d4 (= e0..e4); Q = 1: rows 3..5 of samples d1..d5 (= e0..e4).
-#ifdef MRCNN_W4_SCALAR_T
-// scalar variant of the transform arithmetic (tuning: packed fp32 VALU beside MFMAs is not always the cheaper form)
-__device__ __forceinline__ float s_fma(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float s_fnma(float a, float b, float c) { float r; asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float s_add(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float s_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-template <int Q>
-__device__ __forceinline__ void bt3(const f32x2 e0, const f32x2 e1, const f32x2 e2, const f32x2 e3, const f32x2 e4,
-                                    const f32x2 c4, const f32x2 c5, const f32x2 c2, f32x2& r0, f32x2& r1, f32x2& r2) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if constexpr (Q == 0) {
-            const float t1 = s_fnma(c4[h], e2[h], e4[h]);
-            const float t2 = s_fnma(c4[h], e1[h], e3[h]);
-            r0[h] = s_fma(c4[h], e0[h], s_fnma(c5[h], e2[h], e4[h]));
-            r1[h] = s_add(t1, t2);
-            r2[h] = s_sub(t1, t2);
-        } else {
-            const float u1 = s_sub(e3[h], e1[h]);
-            const float u2 = s_sub(e2[h], e0[h]);
-            r0[h] = s_fma(c2[h], u2, u1);
-            r1[h] = s_fnma(c2[h], u2, u1);
-            r2[h] = s_fma(c4[h], e0[h], s_fnma(c5[h], e2[h], e4[h]));
-        }
-    }
+// Three rows of B^T applied to five consecutive samples. With the points 0, +-a, +-b, inf (a = 3/4, b = 3/2) the rows are
+//   [a2b2 0 -(a2+b2) 0 1 0] [0 -ab2 -b2 a 1 0] [0 ab2 -b2 -a 1 0] [0 -a2b -a2 b 1 0] [0 a2b -a2 -b 1 0] [0 a2b2 0 -(a2+b2) 0 1]
+// (a2 = a^2 ...; a = 1, b = 2 gives the textbook matrix). Q = 0: rows 0..2 of samples d0..d4 (= e0..e4); Q = 1: rows 3..5
+// of samples d1..d5 (= e0..e4).
+constexpr float W4_A = 0.75f, W4_B = 1.5f;
+struct W4Consts { f32x2 a2b2, sab, b2, a, a2, b; };  // sab = a2 + b2
+__device__ __forceinline__ W4Consts w4_consts() {
+    constexpr float a2 = W4_A * W4_A, b2 = W4_B * W4_B;
+    return {{a2 * b2, a2 * b2}, {a2 + b2, a2 + b2}, {b2, b2}, {W4_A, W4_A}, {a2, a2}, {W4_B, W4_B}};
 }
-#else
 template <int Q>
 __device__ __forceinline__ void bt3(const f32x2 e0, const f32x2 e1, const f32x2 e2, const f32x2 e3, const f32x2 e4,
-                                    const f32x2 c4, const f32x2 c5, const f32x2 c2, f32x2& r0, f32x2& r1, f32x2& r2) {
+                                    const W4Consts& k, f32x2& r0, f32x2& r1, f32x2& r2) {
     if constexpr (Q == 0) {
-        const f32x2 t1 = pk_fnma(c4, e2, e4);   // d4 - 4 d2
-        const f32x2 t2 = pk_fnma(c4, e1, e3);   // d3 - 4 d1
-        r0 = pk_fma(c4, e0, pk_fnma(c5, e2, e4));  // 4 d0 - 5 d2 + d4
-        r1 = pk_add(t1, t2);
-        r2 = pk_sub(t1, t2);
+        const f32x2 t1 = pk_fnma(k.b2, e2, e4);   // d4 - b2 d2
+        const f32x2 t2 = pk_fnma(k.b2, e1, e3);   // d3 - b2 d1
+        r0 = pk_fma(k.a2b2, e0, pk_fnma(k.sab, e2, e4));  // a2b2 d0 - (a2+b2) d2 + d4
+        r1 = pk_fma(k.a, t2, t1);
+        r2 = pk_fnma(k.a, t2, t1);
     } else {
-        const f32x2 u1 = pk_sub(e3, e1);        // d4 - d2
-        const f32x2 u2 = pk_sub(e2, e0);        // d3 - d1
-        r0 = pk_fma(c2, u2, u1);                // -2 d1 - d2 + 2 d3 + d4
-        r1 = pk_fnma(c2, u2, u1);               //  2 d1 - d2 - 2 d3 + d4
-        r2 = pk_fma(c4, e0, pk_fnma(c5, e2, e4));  // 4 d1 - 5 d3 + d5
+        const f32x2 u1 = pk_fnma(k.a2, e1, e3);   // d4 - a2 d2
+        const f32x2 u2 = pk_fnma(k.a2, e0, e2);   // d3 - a2 d1
+        r0 = pk_fma(k.b, u2, u1);
+        r1 = pk_fnma(k.b, u2, u1);
+        r2 = pk_fma(k.a2b2, e0, pk_fnma(k.sab, e2, e4));  // a2b2 d1 - (a2+b2) d3 + d5
     }
 }
-
-#endif
 
 // A^T (4 x 6) applied to six samples: rows [1 1 1 1 1 0] [0 1 -1 2 -2 0] [0 1 1 4 4 0] [0 1 -1 8 -8 1]
+// A^T (4 x 6) applied to six samples; the columns of +-a and +-b carry a factor 1/a, 1/b (their G rows a, b):
+//   [1 1/a 1/a 1/b 1/b 0] [0 1 -1 1 -1 0] [0 a a b b 0] [0 a2 -a2 b2 -b2 1]
+struct W4OutConsts { f32x2 ia, ib, a, b, a2, b2; };
+__device__ __forceinline__ W4OutConsts w4_out_consts() {
+    return {{1.f / W4_A, 1.f / W4_A}, {1.f / W4_B, 1.f / W4_B}, {W4_A, W4_A}, {W4_B, W4_B}, {W4_A * W4_A, W4_A * W4_A}, {W4_B * W4_B, W4_B * W4_B}};
+}
 __device__ __forceinline__ void at4p(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4, const f32x2 m5,
-                                     const f32x2 k2, const f32x2 k4, const f32x2 k8, f32x2& y0, f32x2& y1, f32x2& y2, f32x2& y3) {
+                                     const W4OutConsts& k, f32x2& y0, f32x2& y1, f32x2& y2, f32x2& y3) {
     const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
-    y0 = pk_add(pk_add(m0, s12), s34);
-    y1 = pk_fma(k2, d34, d12);
-    y2 = pk_fma(k4, s34, s12);
-    y3 = pk_add(pk_fma(k8, d34, d12), m5);
+    y0 = pk_fma(k.ib, s34, pk_fma(k.ia, s12, m0));
+    y1 = pk_add(d12, d34);
+    y2 = pk_fma(k.b, s34, pk_mul(k.a, s12));
+    y3 = pk_fma(k.b2, d34, pk_fma(k.a2, d12, m5));
 }
-__device__ __forceinline__ void at4(const float m0, const float m1, const float m2, const float m3, const float m4,
-                                    const float m5, float& y0, float& y1, float& y2, float& y3) {
-    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-    y0 = (m0 + s12) + s34;
-    y1 = fmaf(2.f, d34, d12);
-    y2 = fmaf(4.f, s34, s12);
-    y3 = fmaf(8.f, d34, d12) + m5;
-}
-
 // One wave's share of the kernel; QA, QB = its quadrant of the component grid (compile-time: the transform's operations
 // differ per quadrant; the four waves of a workgroup run four instances of this code and meet at the same barriers).
 // HEADS: the output tile is not stored; it feeds the RPN's two 1x1 heads on chip (as conv3x3_wino8s_f32<true> of
@@ -201,7 +182,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
     const int nk = p.Cin >> 2;
     const int total_tiles = 8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
-    const f32x2 c4 = {4.f, 4.f}, c5 = {5.f, 5.f}, c2 = {2.f, 2.f};
+    const W4Consts kin = w4_consts();
 
     for (int it = 0;; ++it) {
         // virtual tile b, b + grid, ... in the XCD-aware order of conv_wino.hip: the workgroups of one XCD walk the N
@@ -302,10 +283,10 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
             else if (wait_n == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(e[c % 3][0]), "+v"(e[c % 3][1]), "+v"(e[c % 3][2]), "+v"(e[c % 3][3]), "+v"(e[c % 3][4]));
             else if (wait_n == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(e[c % 3][0]), "+v"(e[c % 3][1]), "+v"(e[c % 3][2]), "+v"(e[c % 3][3]), "+v"(e[c % 3][4]));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[c % 3][0]), "+v"(e[c % 3][1]), "+v"(e[c % 3][2]), "+v"(e[c % 3][3]), "+v"(e[c % 3][4]));
-            bt3<QA>(e[c % 3][0], e[c % 3][1], e[c % 3][2], e[c % 3][3], e[c % 3][4], c4, c5, c2, t[0][c], t[1][c], t[2][c]);
+            bt3<QA>(e[c % 3][0], e[c % 3][1], e[c % 3][2], e[c % 3][3], e[c % 3][4], kin, t[0][c], t[1][c], t[2][c]);
         };
         auto col_stage = [&](int set, int i) {
-            bt3<QB>(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], c4, c5, c2, A[set][i * 3 + 0], A[set][i * 3 + 1], A[set][i * 3 + 2]);
+            bt3<QB>(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], kin, A[set][i * 3 + 0], A[set][i * 3 + 1], A[set][i * 3 + 2]);
         };
         auto read_b = [&](int set, int buf, int q) {  // q = component * 2 + channel half of the N tile
             const int ci = q >> 1, nb = q & 1;
@@ -422,7 +403,8 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         }
         const __amdgpu_buffer_rsrc_t hp_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.head_part, 0, HEADS ? p.head_bytes : 0u, 0x00020000);
         const int pixstep_y = p.Cout * 4, rowstep_y = p.W * pixstep_y, rowstep_k = p.W * 32;  // scalar store offsets
-        const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k8 = {8.f, 8.f}, sc2 = {sc, sc}, sh2 = {sh, sh};
+        const W4OutConsts kout = w4_out_consts();
+        const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             // Z[component][channel][8 positions, pitch 10]: a lane's four positions (registers 4g..4g+3) are two 8-byte
@@ -446,7 +428,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                 f32x2 m[6];
 #pragma unroll
                 for (int nu = 0; nu < 6; ++nu) m[nu] = *(const lds_f32x2*)(Z + ((xi * 6 + nu) * 64 + n) * W4_ZP + 2 * pq);
-                at4p(m[0], m[1], m[2], m[3], m[4], m[5], k2, k4, k8, w[xi][0], w[xi][1], w[xi][2], w[xi][3]);
+                at4p(m[0], m[1], m[2], m[3], m[4], m[5], kout, w[xi][0], w[xi][1], w[xi][2], w[xi][3]);
             }
             // second stage per output column j: its four pixels (i = 0..3) of both positions leave right away
             unsigned base_y[2], base_k[2];
@@ -462,7 +444,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x2 yv[4];
-                at4p(w[0][j], w[1][j], w[2][j], w[3][j], w[4][j], w[5][j], k2, k4, k8, yv[0], yv[1], yv[2], yv[3]);
+                at4p(w[0][j], w[1][j], w[2][j], w[3][j], w[4][j], w[5][j], kout, yv[0], yv[1], yv[2], yv[3]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     yv[i] = pk_fma(yv[i], sc2, sh2);
@@ -541,8 +523,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const Wino4Params p)
     else wino4_wave<1, 1, DBG, HEADS>(p, lds);
 }
 
-// G g G^T in double, stored as the kernel's [Cin/4][36][2][Cout][2]. G (6 x 3):
-//   [1/4 0 0] [-1/6 -1/6 -1/6] [-1/6 1/6 -1/6] [1/24 1/12 1/6] [1/24 -1/12 1/6] [0 0 1]
+// G g G^T in double, stored as the kernel's [Cin/4][36][2][Cout][2]. G (6 x 3): row of point p = [1 p p^2] * s_p / N_p, N_p the
+// product of (p - q) over the other finite points, s_p the factor taken out of A^T; last row [0 0 1]
 __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restrict__ w, int cout, int cin,
                                                             float* __restrict__ u) {
     const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
@@ -551,13 +533,16 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restr
     double g[3][3];
     for (int ky = 0; ky < 3; ++ky)
         for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((static_cast<int64_t>(n) * 3 + ky) * 3 + kx) * cin + c];
-    auto g6 = [](double a, double b2, double c2, double (&r)[6]) {
-        r[0] = a / 4.0;
-        r[1] = -(a + b2 + c2) / 6.0;
-        r[2] = -(a - b2 + c2) / 6.0;
-        r[3] = a / 24.0 + b2 / 12.0 + c2 / 6.0;
-        r[4] = a / 24.0 - b2 / 12.0 + c2 / 6.0;
-        r[5] = c2;
+    auto g6 = [](double x0, double x1, double x2, double (&r)[6]) {
+        const double a = W4_A, b = W4_B;
+        const double pts[5] = {0.0, a, -a, b, -b}, scl[5] = {1.0, a, a, b, b};  // scl: see at4p
+        for (int j = 0; j < 5; ++j) {
+            double nj = 1.0;
+            for (int l = 0; l < 5; ++l)
+                if (l != j) nj *= pts[j] - pts[l];
+            r[j] = (x0 + pts[j] * x1 + pts[j] * pts[j] * x2) * scl[j] / nj;
+        }
+        r[5] = x2;
     };
     double t[6][3];
     for (int kx = 0; kx < 3; ++kx) {
