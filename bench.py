@@ -14,8 +14,9 @@ synthetic 1024x1024) → weak scaling; N=8 is configs[3] (batch 64 sharded over 
 in HBM before the timed region. fp32 throughout (exact-fp32 MFMA).
 
 Prints ONE JSON line on rank 0 with the driver's contract fields plus
-  `roofline`      the dominant kernel (conv3x3_wino8s_f32, the spatial-tile Winograd kernel): the multiply-adds it EXECUTES (2*M*N*K / 2.25 for Winograd
-                  F(2x2,3x3)) / its summed launch durations — HIP events on the launch stream around every conv
+  `roofline`      the dominant kernel (largest summed duration in a step: the direct implicit-GEMM kernel conv_igemm_f32 or
+                  the F(4x4) Winograd kernel conv3x3_wino4_f32): the multiply-adds it EXECUTES (2*M*N*K, / 2.25 for Winograd
+                  F(2x2,3x3), / 4 for F(4x4,3x3)) / its summed launch durations — HIP events on the launch stream around every conv
                   launch, in an instrumented pass right after the timed region — against the fp32-MFMA peak, so
                   `frac` <= 1; the convolution-equivalent (algorithmic) rate and the whole conv path sit beside it;
   `roofline_ops`  RoIAlign (BASELINE config 2 shape + the pipeline's pyramid call; HBM-bound) and NMS 8 x 1000
@@ -127,7 +128,9 @@ def conv_roofline(prof, args, H, W, modules):
                     and tj.get("proposals") == args.proposals and tj.get("winograd") == bool(modules.WINOGRAD)
                     and tj.get("stem_kernel") == bool(modules.STEM_KERNEL)
                     and tj.get("fused_bottleneck") == bool(getattr(modules, "FUSED_BOTTLENECK", False))
-                    and tj.get("rpn_fused_heads") == bool(getattr(modules, "RPN_FUSED_HEADS", False)))
+                    and tj.get("rpn_fused_heads") == bool(getattr(modules, "RPN_FUSED_HEADS", False))
+                    and tj.get("winograd4") == bool(getattr(modules, "WINOGRAD4", False))
+                    and tj.get("winograd4_trunk") == bool(getattr(modules, "WINOGRAD4_TRUNK", False)))
             k = tj.get("per_kernel", {}).get(kernel_of.get(dominant, dominant))
             if same and k and k.get("launches_per_step") == dom["launches_per_step"]:
                 traffic = k["hbm_bytes_per_step"]
@@ -136,7 +139,7 @@ def conv_roofline(prof, args, H, W, modules):
             traffic = None
     return {"bound": "mfma", "kernel": kernel_of.get(dominant, dominant),
             "achieved": dom["executed_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["executed_frac"],
-            "definition": "achieved = multiply-adds the kernel executes x 2 (Winograd F(2x2,3x3): 2*M*N*K / 2.25) / "
+            "definition": "achieved = multiply-adds the kernel executes x 2 (Winograd F(2x2,3x3): 2*M*N*K / 2.25, F(4x4,3x3): / 4) / "
                           "summed launch durations of that kernel in one step (HIP events on the launch stream); "
                           "frac = achieved / fp32-MFMA peak",
             "launches_per_step": dom["launches_per_step"], "ms_per_step": dom["ms_per_step"],
@@ -388,7 +391,10 @@ def main():
                        "parallelism": f"dp{world}: image shards, replicated weights, one RCCL all-gather of "
                                       f"detections [{world * args.batch},{cfg.detection_max_instances},6]",
                        "hipgraph": bool(args.graph),
-                       "conv3x3": ("winograd F(2x2,3x3), fp32 arithmetic on the fp32 MFMA"
+                       "conv3x3": (("winograd F(4x4,3x3) on maps of >= 8 tiles of 16x32 pixels per image"
+                                    + ("" if modules.WINOGRAD4_TRUNK else " (FPN smoothing and RPN only)")
+                                    + ", F(2x2,3x3) elsewhere; fp32 arithmetic on the fp32 MFMA"
+                                    if modules.WINOGRAD4 else "winograd F(2x2,3x3), fp32 arithmetic on the fp32 MFMA")
                                    if (args.precision == "f32" and modules.WINOGRAD) else "direct implicit GEMM"),
                        "mean_valid_proposals": round(float(net_last_counts(net, images, windows)), 1),
                        "mean_detections": round(float(det.counts.float().mean().item()), 1)},

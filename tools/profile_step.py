@@ -61,7 +61,9 @@ def main():
             "arch": args.arch, "proposals": args.proposals, "winograd": bool(modules.WINOGRAD),
             "stem_kernel": bool(modules.STEM_KERNEL),
             "fused_bottleneck": bool(getattr(modules, "FUSED_BOTTLENECK", False)),
-            "rpn_fused_heads": bool(getattr(modules, "RPN_FUSED_HEADS", False))}
+            "rpn_fused_heads": bool(getattr(modules, "RPN_FUSED_HEADS", False)),
+            "winograd4": bool(getattr(modules, "WINOGRAD4", False)),
+            "winograd4_trunk": bool(getattr(modules, "WINOGRAD4_TRUNK", False))}
     if args.meta:
         with open(args.meta, "w") as fh:
             json.dump(meta, fh)
