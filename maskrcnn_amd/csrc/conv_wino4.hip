@@ -37,6 +37,7 @@ namespace {
 using namespace mrcnn_conv;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // LDS pointers stay in their address space: arithmetic on generic pointers costs a null check per conversion (and the
 // LDS-DMA destination / asm read addresses are 32-bit LDS offsets anyway)
 typedef __attribute__((address_space(3))) float lds_f32;
@@ -69,8 +70,7 @@ constexpr int W4_RW = 40;                             // channel pairs per raw r
 constexpr int W4_RPLANE = 18 * W4_RW + 8;             // pairs per (buffer, channel pair) plane, rotation included
 constexpr int W4_RS_FLOATS = 2 * 2 * W4_RPLANE * 2;   // raw region: [2 buffers][2 channel pairs][plane][2]
 constexpr int W4_UBUF = 36 * 256;                     // floats per U buffer: [36][2 channel pairs][64][2]
-constexpr int W4_ZP = 10;                             // floats per (component, channel) row of the exchange buffer
-constexpr int W4_Z_FLOATS = 36 * 64 * W4_ZP;          // epilogue exchange of a round: [36][64 channels][8 positions, padded]
+constexpr int W4_Z_FLOATS = 36 * 8 * 64;              // epilogue exchange of a round: [36 components][8 positions][64 channels]
 constexpr size_t WINO4_LDS = sizeof(float) * (W4_RS_FLOATS + 2 * W4_UBUF);
 constexpr int W4_T_FLOATS = 128 * W4_N;               // HEADS: a round's 128 pixels x 64 channels, transposed, behind the rest
 constexpr int W4_WH_FLOATS = 8 * 256;                 // HEADS: the N tile's head weights as the 8 B-operand pieces [j][lane][4]
@@ -184,7 +184,12 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
     const int total_tiles = 8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
     const W4Consts kin = w4_consts();
 
+    unsigned long long stamp[12];
+    int nstamp = 0;
+    auto STAMP = [&]() { if constexpr ((DBG & 2048) != 0) { if (nstamp < 12) stamp[nstamp++] = __builtin_readcyclecounter(); } };
     for (int it = 0;; ++it) {
+        if ((DBG & 2048) && it == 1) nstamp = 0;
+        STAMP();  // 0: tile start
         // virtual tile b, b + grid, ... in the XCD-aware order of conv_wino.hip: the workgroups of one XCD walk the N
         // tiles of neighbouring M tiles, so the raw input region is shared in that XCD's L2
         // HEADS: M-tile units b, b + grid, ..., each walked over all its N tiles by this workgroup
@@ -308,19 +313,31 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
             asm volatile("" : "+v"(Bv[9]), "+v"(Bv[10]), "+v"(Bv[11]), "+v"(Bv[12]), "+v"(Bv[13]), "+v"(Bv[14]), "+v"(Bv[15]), "+v"(Bl[set][0]), "+v"(Bl[set][1]));
         };
 
-        // ---- prologue: k tiles 0 and 1 staged, operands of k tile 0 in registers, raw k tile 2 in flight
+        STAMP();  // 1: setup done
+        // ---- prologue: k tiles 0 and 1 staged, operands of k tile 0 in registers, raw k tile 2 in flight. All loads of k tiles
+        // 0 and 1 go out together (one memory round trip, not two)
+        {
+            u32x4 r0[3], r1[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) load_raw1(0, i);
+            for (int i = 0; i < 3; ++i) {
+                r0[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(r_off[i]), 0, 0);
+                r1[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(r_off[i]), 16, 0);
+            }
 #pragma unroll
-        for (int j = 0; j < 9; ++j) dma_u1(0, 0, j);
+            for (int j = 0; j < 9; ++j) dma_u1(0, 0, j);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) write_raw1(0, i);
+            for (int j = 0; j < 9; ++j) dma_u1(1, 1, j);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) load_raw1(1, i);
+            for (int i = 0; i < 3; ++i) {
+                rr[i] = r0[i];
+                write_raw1(0, i);
+            }
 #pragma unroll
-        for (int j = 0; j < 9; ++j) dma_u1(1, 1, j);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) write_raw1(1, i);
+            for (int i = 0; i < 3; ++i) {
+                rr[i] = r1[i];
+                write_raw1(1, i);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) load_raw1(2, i);
         asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -366,11 +383,13 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
             asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             tie_b(NXT);
         };
+        STAMP();  // 2: prologue done
         for (int kt = 0; kt < nk; kt += 2) {
             ktile(std::integral_constant<int, 0>{}, kt);
             ktile(std::integral_constant<int, 1>{}, kt + 1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP();  // 3: k loop done
 
         // ---- epilogue: four rounds of 8 positions (accumulator registers 4g..4g+3 of both lane halves)
         if (DBG & 64) {  // ablation: no epilogue at all (keeps the accumulators alive through one store)
@@ -381,9 +400,13 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
             continue;
         }
         lds_f32* Z = smem;
-        const int n = tid & 63, pq = tid >> 6;
+        // epilogue thread = (position p8 of the round, channel pair n, n + 1): the pair rides in packed operations and leaves
+        // in 8-byte stores
+        const int n = 2 * (tid & 31), p8 = tid >> 5;
         const int ng = n0 + n;
-        const float sc = p.scale ? p.scale[ng] : 1.0f, sh = p.shift ? p.shift[ng] : 0.0f;
+        f32x2 sc2 = {1.0f, 1.0f}, sh2 = {0.0f, 0.0f};
+        if (p.scale) sc2 = *reinterpret_cast<const f32x2*>(p.scale + ng);
+        if (p.shift) sh2 = *reinterpret_cast<const f32x2*>(p.shift + ng);
         const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y ? p.y_bytes : 0u, 0x00020000);
         const __amdgpu_buffer_rsrc_t yk_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.yk, 0, p.yk ? p.y_bytes : 0u, 0x00020000);
         const unsigned ncol = static_cast<unsigned>(ng) * 4u;
@@ -404,11 +427,10 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         const __amdgpu_buffer_rsrc_t hp_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.head_part, 0, HEADS ? p.head_bytes : 0u, 0x00020000);
         const int pixstep_y = p.Cout * 4, rowstep_y = p.W * pixstep_y, rowstep_k = p.W * 32;  // scalar store offsets
         const W4OutConsts kout = w4_out_consts();
-        const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            // Z[component][channel][8 positions, pitch 10]: a lane's four positions (registers 4g..4g+3) are two 8-byte
-            // writes, a thread's two positions one 8-byte read; the pitch keeps both conflict-free
+            // Z[component][position][channel]: a lane's four positions (registers 4g..4g+3) are four 4-byte writes (32
+            // consecutive channels per half-wave), a thread's channel pair one 8-byte read: both conflict-free
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -416,31 +438,31 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
                         const f32x16& a16 = acc[(i * 3 + j) * 2 + nb];
-                        lds_f32* zp = Z + ((cg0 + i * 6 + j) * 64 + nb * 32 + ln) * W4_ZP + 4 * lh;
-                        *(lds_f32x2*)zp = f32x2{a16[4 * g], a16[4 * g + 1]};
-                        *(lds_f32x2*)(zp + 2) = f32x2{a16[4 * g + 2], a16[4 * g + 3]};
+                        lds_f32* zp = Z + ((cg0 + i * 6 + j) * 8 + 4 * lh) * 64 + nb * 32 + ln;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) zp[e * 64] = a16[4 * g + e];
+                        __builtin_amdgcn_sched_barrier(0);  // or all 72 accumulator registers of the round are copied out at once
                     }
-            __syncthreads();
-            // a thread's two positions (2 pq, 2 pq + 1) are the halves of packed operations
+            // barriers of the epilogue: LDS only. __syncthreads() would also wait (vmcnt(0)) for the previous round's global
+            // stores — output pixels or head sums — to complete: their whole latency, once per round
+            if (g == 0 || g == 1) STAMP();  // after the Z writes
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (g == 0 || g == 1) STAMP();  // after the first barrier
             f32x2 w[6][4];
 #pragma unroll
             for (int xi = 0; xi < 6; ++xi) {
                 f32x2 m[6];
 #pragma unroll
-                for (int nu = 0; nu < 6; ++nu) m[nu] = *(const lds_f32x2*)(Z + ((xi * 6 + nu) * 64 + n) * W4_ZP + 2 * pq);
+                for (int nu = 0; nu < 6; ++nu) m[nu] = *(const lds_f32x2*)(Z + ((xi * 6 + nu) * 8 + p8) * 64 + n);
                 at4p(m[0], m[1], m[2], m[3], m[4], m[5], kout, w[xi][0], w[xi][1], w[xi][2], w[xi][3]);
             }
-            // second stage per output column j: its four pixels (i = 0..3) of both positions leave right away
-            unsigned base_y[2], base_k[2];
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int pos = 8 * g + 2 * pq + pp;
-                const int TY = TY0 + (pos >> 3), TX = TX0 + (pos & 7);
-                const bool valid = TY < p.TH && TX < p.TW;
-                const unsigned pix = static_cast<unsigned>((b * p.H + 4 * TY) * p.W + 4 * TX);
-                base_y[pp] = valid ? pix * static_cast<unsigned>(p.Cout) * 4u + ncol : OOB;
-                base_k[pp] = valid ? pix * 32u + kcol : OOB;
-            }
+            // second stage per output column j: its four pixels (i = 0..3) leave right away
+            const int pos = 8 * g + p8;
+            const int TY = TY0 + (pos >> 3), TX = TX0 + (pos & 7);
+            const bool valid = TY < p.TH && TX < p.TW;
+            const unsigned pix = static_cast<unsigned>((b * p.H + 4 * TY) * p.W + 4 * TX);
+            const unsigned base_y = valid ? pix * static_cast<unsigned>(p.Cout) * 4u + ncol : OOB;
+            const unsigned base_k = valid ? pix * 32u + kcol : OOB;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x2 yv[4];
@@ -451,31 +473,31 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                     if (p.act) yv[i] = f32x2{fmaxf(yv[i].x, 0.f), fmaxf(yv[i].y, 0.f)};
                 }
                 if (DBG & 32) { if (yv[0].x == 12345.678f) p.y[0] = yv[0].x; continue; }
+                if constexpr (HEADS) {
 #pragma unroll
-                for (int pp = 0; pp < 2; ++pp) {
-                    if constexpr (HEADS) {
+                    for (int i = 0; i < 4; ++i) {  // pixel row of the round: position p8, pixel i * 4 + j
+                        const int pxl = p8 * 16 + i * 4 + j;
+                        *(lds_f32x2*)(Tt + pxl * W4_N + (n ^ ((pxl & 15) << 2))) = yv[i];
+                    }
+                } else {
+                    if (p.y) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {  // pixel row of the round: position 2 pq + pp, pixel i * 4 + j
-                            const int pxl = (2 * pq + pp) * 16 + i * 4 + j;
-                            Tt[pxl * W4_N + (n ^ ((pxl & 15) << 2))] = pp == 0 ? yv[i].x : yv[i].y;
-                        }
-                    } else {
-                        if (p.y) {
+                        for (int i = 0; i < 4; ++i)
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, yv[i]), y_rsrc, static_cast<int>(base_y),
+                                                                  i * rowstep_y + j * pixstep_y, 0);
+                    }
+                    if (p.yk) {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pp == 0 ? yv[i].x : yv[i].y), y_rsrc,
-                                                                      static_cast<int>(base_y[pp]), i * rowstep_y + j * pixstep_y, 0);
-                        }
-                        if (p.yk) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pp == 0 ? yv[i].x : yv[i].y), yk_rsrc,
-                                                                      static_cast<int>(base_k[pp]), i * rowstep_k + j * 32, 0);
-                        }
+                        for (int i = 0; i < 4; ++i)
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, yv[i]), yk_rsrc, static_cast<int>(base_k),
+                                                                  i * rowstep_k + j * 32, 0);
                     }
                 }
             }
-            __syncthreads();  // Z is read out: the next round / the next tile's staging may overwrite it
+            if (g == 0 || g == 1) STAMP();  // after transform + stores
+            if (HEADS && g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the head-weight DMA has landed
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // Z is read out: the next round / tile may overwrite it
+            if (g == 0 || g == 1) STAMP();  // round end
             if constexpr (HEADS && !(DBG & 128)) {
                 // wave w: pixels 32 w .. 32 w + 31 of the round x 32 heads x all 64 channels; the sums of the earlier N
                 // tiles come back from global memory (same workgroup, same lanes: plain read-modify-write)
@@ -485,7 +507,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     hacc[r] = 0.f;
-                    if (nt != 0)
+                    if (nt != 0 && !(DBG & 512))
                         hacc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                             hp_rsrc, static_cast<int>(hbase + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * 128u), 0, 0));
                 }
@@ -496,16 +518,21 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                 for (int j = 0; j < 8; ++j) {
                     const f32x4 a4 = *(const lds_f32x4*)(trow + ((j * 8 + lh * 4) ^ swz));
                     const f32x4 b4 = *(const lds_f32x4*)(Wh + j * 256 + lane * 4);
+                    if (DBG & 1024) { hacc[j] += a4.x * b4.x; continue; }
                     hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, hacc, 0, 0, 0);
                     hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, hacc, 0, 0, 0);
                     hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, hacc, 0, 0, 0);
                     hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, hacc, 0, 0, 0);
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
+                for (int r = 0; r < (DBG & 256 ? 1 : 16); ++r)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hacc[r]), hp_rsrc,
                                                           static_cast<int>(hbase + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * 128u), 0, 0);
             }
+        }
+        if constexpr ((DBG & 2048) != 0) {
+            if (it == 1 && blockIdx.x == 0 && threadIdx.x == 0 && p.yk)
+                for (int i = 0; i < nstamp; ++i) reinterpret_cast<unsigned long long*>(p.yk)[i] = stamp[i];
         }
     }  // tiles
 }
@@ -615,6 +642,7 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
         case 8: kern = conv3x3_wino4_f32<8, false>; break;
         case 16: kern = conv3x3_wino4_f32<16, false>; break;
         case 31: kern = conv3x3_wino4_f32<31, false>; break;
+        case 2048: kern = conv3x3_wino4_f32<2048, false>; break;
         case 63: kern = conv3x3_wino4_f32<63, false>; break;
         case 95: kern = conv3x3_wino4_f32<95, false>; break;
         default: break;
@@ -670,6 +698,10 @@ extern "C" int mrcnn_conv3x3_winograd4_heads_f32(const float* x_kblocked, int32_
         case 32: kern = conv3x3_wino4_f32<32, true>; break;
         case 128: kern = conv3x3_wino4_f32<128, true>; break;
         case 160: kern = conv3x3_wino4_f32<160, true>; break;
+        case 256: kern = conv3x3_wino4_f32<256, true>; break;
+        case 512: kern = conv3x3_wino4_f32<512, true>; break;
+        case 1024: kern = conv3x3_wino4_f32<1024, true>; break;
+        case 1792: kern = conv3x3_wino4_f32<1792, true>; break;
         default: break;
     }
 #endif
