@@ -72,9 +72,17 @@ constexpr int W4_RS_FLOATS = 2 * 2 * W4_RPLANE * 2;   // raw region: [2 buffers]
 constexpr int W4_UBUF = 36 * 256;                     // floats per U buffer: [36][2 channel pairs][64][2]
 constexpr int W4_Z_FLOATS = 36 * 8 * 64;              // epilogue exchange of a round: [36 components][8 positions][64 channels]
 constexpr size_t WINO4_LDS = sizeof(float) * (W4_RS_FLOATS + 2 * W4_UBUF);
-constexpr int W4_T_FLOATS = 128 * W4_N;               // HEADS: a round's 128 pixels x 64 channels, transposed, behind the rest
-constexpr int W4_WH_FLOATS = 8 * 256;                 // HEADS: the N tile's head weights as the 8 B-operand pieces [j][lane][4]
-constexpr size_t WINO4_HEADS_LDS = WINO4_LDS + sizeof(float) * (W4_T_FLOATS + W4_WH_FLOATS);
+// HEADS, epilogue: behind Z the round's transposed tile T (128 pixels x 64 channels; it overlaps U buffer 1, dead then), the
+// N tile's head weights (the 8 B-operand pieces [j][lane][4]) and — alive through the whole N-tile walk of an M tile, beyond
+// the staging area — the M tile's head sums [512 pixels][20] (18 real columns)
+constexpr int W4_T_FLOATS = 128 * W4_N;
+constexpr int W4_WH_FLOATS = 8 * 256;
+constexpr int W4_HP = 20;
+constexpr int W4_T_OFF = W4_Z_FLOATS;
+constexpr int W4_WH_OFF = W4_T_OFF + W4_T_FLOATS;
+constexpr int W4_H_OFF = W4_WH_OFF + W4_WH_FLOATS;
+constexpr size_t WINO4_HEADS_LDS = sizeof(float) * (W4_H_OFF + 512 * W4_HP);
+static_assert(W4_H_OFF >= W4_RS_FLOATS + 2 * W4_UBUF && WINO4_HEADS_LDS <= 160 * 1024, "HEADS LDS map");
 static_assert(W4_Z_FLOATS <= W4_RS_FLOATS + 2 * W4_UBUF, "the exchange buffer aliases the staging buffers");
 
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
@@ -412,10 +420,10 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         const unsigned ncol = static_cast<unsigned>(ng) * 4u;
         const unsigned kcol = static_cast<unsigned>(ng >> 3) * p.yk_plane + static_cast<unsigned>(ng & 7) * 4u;
         // HEADS: the round's 128 pixels x 64 channels, [pixel][channel ^ swizzle], behind the exchange buffer
-        lds_f32* Tt = smem + W4_RS_FLOATS + 2 * W4_UBUF;
+        lds_f32* Tt = smem + W4_T_OFF;
         // the N tile's head weights: piece j = what lane (head ln, half lh) multiplies in k steps 4j..4j+3 (channels
         // n0 + 8 j + 4 lh + e), by LDS-DMA behind T — in registers they are 32 VGPRs the transform below has not got
-        lds_f32* Wh = Tt + W4_T_FLOATS;
+        lds_f32* Wh = smem + W4_WH_OFF;
         if constexpr (HEADS) {
             const __amdgpu_buffer_rsrc_t wh_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w_head), 0, static_cast<unsigned>(p.Cout) * 128u, 0x00020000);
 #pragma unroll
@@ -499,17 +507,18 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // Z is read out: the next round / tile may overwrite it
             if (g == 0 || g == 1) STAMP();  // round end
             if constexpr (HEADS && !(DBG & 128)) {
-                // wave w: pixels 32 w .. 32 w + 31 of the round x 32 heads x all 64 channels; the sums of the earlier N
-                // tiles come back from global memory (same workgroup, same lanes: plain read-modify-write)
-                const int row0 = mt * 512 + g * 128 + wave * 32 + 4 * lh;
-                const unsigned hbase = static_cast<unsigned>(row0) * 128u + static_cast<unsigned>(ln) * 4u;
+                // wave w: pixels 32 w .. 32 w + 31 of the round x 32 heads x all 64 channels. The M tile's sums over the N
+                // tiles walked so far stay in LDS (this workgroup walks all of them back to back); only the last N tile
+                // writes them out
+                const int prow = g * 128 + wave * 32 + 4 * lh;
+                lds_f32* hrow = smem + W4_H_OFF + prow * W4_HP + ln;
+                const bool hcol = ln < W4_HP;
                 f32x16 hacc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    hacc[r] = 0.f;
-                    if (nt != 0 && !(DBG & 512))
-                        hacc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                            hp_rsrc, static_cast<int>(hbase + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * 128u), 0, 0));
+                for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+                if (nt != 0 && hcol && !(DBG & 512)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hacc[r] = hrow[((r & 3) + 8 * (r >> 2)) * W4_HP];
                 }
                 const int pxl = wave * 32 + ln;
                 const lds_f32* trow = Tt + pxl * W4_N;
@@ -524,10 +533,20 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                     hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, hacc, 0, 0, 0);
                     hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, hacc, 0, 0, 0);
                 }
+                if (nt != p.tiles_n - 1) {
+                    if (hcol) {
 #pragma unroll
-                for (int r = 0; r < (DBG & 256 ? 1 : 16); ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hacc[r]), hp_rsrc,
-                                                          static_cast<int>(hbase + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * 128u), 0, 0);
+                        for (int r = 0; r < 16; ++r) hrow[((r & 3) + 8 * (r >> 2)) * W4_HP] = hacc[r];
+                    }
+                } else {
+                    const unsigned hbase = static_cast<unsigned>(mt * 512 + prow) * 128u + static_cast<unsigned>(ln) * 4u;
+#pragma unroll
+                    for (int r = 0; r < (DBG & 256 ? 1 : 16); ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hacc[r]), hp_rsrc,
+                                                              static_cast<int>(hbase + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * 128u), 0, 0);
+                }
+                // T overlaps U buffer 1: the next tile's prologue must not start before every wave has read it
+                if (g == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
         }
         if constexpr ((DBG & 2048) != 0) {
