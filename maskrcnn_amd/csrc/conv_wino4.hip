@@ -1,9 +1,10 @@
 // 3x3 stride-1 SAME convolution + per-channel affine + ReLU as a fused Winograd F(4x4, 3x3) on the exact-fp32 MFMA
 // (v_mfma_f32_32x32x2_f32): 4x fewer multiply-adds than the direct implicit GEMM (F(2x2,3x3) of conv_wino.hip: 2.25x)
-// for the large-map 3x3 layers — FPN smoothing (model.py:154-157) and the RPN's shared conv (model.py:605,624). All
-// arithmetic is fp32 (filter transform in double, once); the transforms' larger coefficients (up to 8) cost about one
-// decimal digit against F(2x2): max |err| 2e-5 at unit scale and K = 2304, inside the 1e-4 parity bar
-// (tests/test_gpu_conv.py).
+// for the large-map 3x3 layers — FPN smoothing (model.py:154-157), the RPN's shared conv (model.py:605,624; with the two
+// 1x1 heads fused, model.py:606-607,627-641) and the Bottleneck conv2 layers (model.py:182). All arithmetic is fp32
+// (filter transform in double, once); the transforms' larger coefficients cost about half a decimal digit against
+// F(2x2): max |err| 1.8e-5 .. 3.3e-5 at |act| ~ 8 on the full-size layers, inside the 1e-4 parity bar
+// (tests/test_gpu_conv.py, tests/test_gpu_fullsize.py).
 //
 //   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A       g: 3x3 filter, d: 6x6 input patch, Y: 4x4 outputs
 //   interpolation points 0, +-3/4, +-3/2, inf: the usual 0, +-1, +-2 scaled by 3/4, which cuts the fp32 error of the
@@ -26,7 +27,9 @@
 //               its wave's components — V is never stored. Each A operand feeds two MFMAs (the two 32-channel halves
 //               of the N tile).
 //   epilogue    the 36 components of 8 positions x 64 channels go through LDS per round; every thread then applies
-//               A^T . A to two (position, channel) pairs, affine, ReLU, stores NHWC and/or k-blocked.
+//               A^T . A to one position x one channel pair (the pair rides in packed operations), affine, ReLU, 8-byte
+//               stores NHWC and/or k-blocked. HEADS variant: instead of the stores the round's 128 pixels x 64 channels
+//               feed the RPN's 1x1 heads by MFMA (details at wino4_wave).
 #include "conv_common.hpp"
 
 #include <cstdlib>
@@ -178,7 +181,9 @@ __device__ __forceinline__ void at4p(const f32x2 m0, const f32x2 m1, const f32x2
 // differ per quadrant; the four waves of a workgroup run four instances of this code and meet at the same barriers).
 // HEADS: the output tile is not stored; it feeds the RPN's two 1x1 heads on chip (as conv3x3_wino8s_f32<true> of
 // conv_wino.hip): a workgroup owns whole M tiles and walks their N tiles, adding each N tile's contribution to the M tile's
-// head sums in global memory.
+// head sums, which stay in LDS until the last N tile writes them out.
+// DBG: compile-time tuning variants (MRCNN_W4_ABLATIONS builds): bits 1..1024 leave parts out (wrong results, timing only),
+// 2048 records s_memtime stamps of a tile's phases (tools/w4_stamp.py). DBG = 0 is the product.
 template <int QA, int QB, int DBG, bool HEADS>
 __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) {
     lds_f32x2* Rs = (lds_f32x2*)smem;            // [2][2][W4_RPLANE] channel pairs
