@@ -163,19 +163,20 @@ __device__ __forceinline__ void bt3(const f32x2 e0, const f32x2 e1, const f32x2 
 }
 
 // A^T (4 x 6) applied to six samples: rows [1 1 1 1 1 0] [0 1 -1 2 -2 0] [0 1 1 4 4 0] [0 1 -1 8 -8 1]
-// A^T (4 x 6) applied to six samples; the columns of +-a and +-b carry a factor 1/a, 1/b (their G rows a, b):
-//   [1 1/a 1/a 1/b 1/b 0] [0 1 -1 1 -1 0] [0 a a b b 0] [0 a2 -a2 b2 -b2 1]
-struct W4OutConsts { f32x2 ia, ib, a, b, a2, b2; };
+// A^T (4 x 6) applied to six samples: [1 1 1 1 1 0] [0 a -a b -b 0] [0 a2 a2 b2 b2 0] [0 a3 -a3 b3 -b3 1] — dyadic rationals
+// like B^T's entries, so the kernel applies both transforms without rounding a coefficient
+struct W4OutConsts { f32x2 a, b, a2, b2, a3, b3; };
 __device__ __forceinline__ W4OutConsts w4_out_consts() {
-    return {{1.f / W4_A, 1.f / W4_A}, {1.f / W4_B, 1.f / W4_B}, {W4_A, W4_A}, {W4_B, W4_B}, {W4_A * W4_A, W4_A * W4_A}, {W4_B * W4_B, W4_B * W4_B}};
+    constexpr float a2 = W4_A * W4_A, b2 = W4_B * W4_B;
+    return {{W4_A, W4_A}, {W4_B, W4_B}, {a2, a2}, {b2, b2}, {a2 * W4_A, a2 * W4_A}, {b2 * W4_B, b2 * W4_B}};
 }
 __device__ __forceinline__ void at4p(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4, const f32x2 m5,
                                      const W4OutConsts& k, f32x2& y0, f32x2& y1, f32x2& y2, f32x2& y3) {
     const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
-    y0 = pk_fma(k.ib, s34, pk_fma(k.ia, s12, m0));
-    y1 = pk_add(d12, d34);
-    y2 = pk_fma(k.b, s34, pk_mul(k.a, s12));
-    y3 = pk_fma(k.b2, d34, pk_fma(k.a2, d12, m5));
+    y0 = pk_add(pk_add(m0, s12), s34);
+    y1 = pk_fma(k.b, d34, pk_mul(k.a, d12));
+    y2 = pk_fma(k.b2, s34, pk_mul(k.a2, s12));
+    y3 = pk_fma(k.b3, d34, pk_fma(k.a3, d12, m5));
 }
 // One wave's share of the kernel; QA, QB = its quadrant of the component grid (compile-time: the transform's operations
 // differ per quadrant; the four waves of a workgroup run four instances of this code and meet at the same barriers).
@@ -574,8 +575,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const Wino4Params p)
     else wino4_wave<1, 1, DBG, HEADS>(p, lds);
 }
 
-// G g G^T in double, stored as the kernel's [Cin/4][36][2][Cout][2]. G (6 x 3): row of point p = [1 p p^2] * s_p / N_p, N_p the
-// product of (p - q) over the other finite points, s_p the factor taken out of A^T; last row [0 0 1]
+// G g G^T in double, stored as the kernel's [Cin/4][36][2][Cout][2]. G (6 x 3): row of point p = [1 p p^2] / N_p, N_p the
+// product of (p - q) over the other finite points; last row [0 0 1]
 __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restrict__ w, int cout, int cin,
                                                             float* __restrict__ u) {
     const int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
@@ -586,12 +587,12 @@ __global__ __launch_bounds__(256) void wino4_weights_kernel(const float* __restr
         for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((static_cast<int64_t>(n) * 3 + ky) * 3 + kx) * cin + c];
     auto g6 = [](double x0, double x1, double x2, double (&r)[6]) {
         const double a = W4_A, b = W4_B;
-        const double pts[5] = {0.0, a, -a, b, -b}, scl[5] = {1.0, a, a, b, b};  // scl: see at4p
+        const double pts[5] = {0.0, a, -a, b, -b};
         for (int j = 0; j < 5; ++j) {
             double nj = 1.0;
             for (int l = 0; l < 5; ++l)
                 if (l != j) nj *= pts[j] - pts[l];
-            r[j] = (x0 + pts[j] * x1 + pts[j] * pts[j] * x2) * scl[j] / nj;
+            r[j] = (x0 + pts[j] * x1 + pts[j] * pts[j] * x2) / nj;
         }
         r[5] = x2;
     };

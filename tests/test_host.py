@@ -155,3 +155,30 @@ def test_all_gather_detections_gloo_world2(global_batch):
         assert t == 2.0                                              # max over ranks
         assert ncalls == 1, "one collective per step"
         assert bad_raised
+
+
+def test_winograd4_point_set_is_exact_and_dyadic():
+    """The F(4x4,3x3) kernel's matrices (csrc/conv_wino4.hip: points 0, +-3/4, +-3/2, inf) are an exact Winograd algorithm
+    — checked in float64 on random data — and B^T / A^T hold only dyadic rationals with short mantissas, i.e. the fp32
+    kernel applies both transforms without rounding a coefficient (G g G^T is evaluated in double, once)."""
+    import numpy as np
+    a, b = 0.75, 1.5
+    BT = np.array([[a * a * b * b, 0, -(a * a + b * b), 0, 1, 0],
+                   [0, -a * b * b, -b * b, a, 1, 0], [0, a * b * b, -b * b, -a, 1, 0],
+                   [0, -a * a * b, -a * a, b, 1, 0], [0, a * a * b, -a * a, -b, 1, 0],
+                   [0, a * a * b * b, 0, -(a * a + b * b), 0, 1]])
+    AT = np.array([[1, 1, 1, 1, 1, 0], [0, a, -a, b, -b, 0], [0, a * a, a * a, b * b, b * b, 0],
+                   [0, a ** 3, -a ** 3, b ** 3, -b ** 3, 1]])
+    pts, scl = [0, a, -a, b, -b], [1, 1, 1, 1, 1]
+    G = np.zeros((6, 3))
+    for j, pj in enumerate(pts):
+        nj = np.prod([pj - q for l, q in enumerate(pts) if l != j])
+        G[j] = np.array([1, pj, pj * pj]) * scl[j] / nj
+    G[5] = [0, 0, 1]
+    rng = np.random.default_rng(0)
+    d, g = rng.standard_normal((6, 6)), rng.standard_normal((3, 3))
+    y = AT @ ((G @ g @ G.T) * (BT @ d @ BT.T)) @ AT.T
+    ref = np.array([[np.sum(d[i:i + 3, j:j + 3] * g) for j in range(4)] for i in range(4)])
+    assert np.abs(y - ref).max() < 1e-13
+    for m in (BT, AT):
+        assert np.array_equal(m.astype(np.float32).astype(np.float64), m)
