@@ -645,13 +645,14 @@ def test_conv3x3_winograd4_vs_torch_cpu(dev, b, h, w, cin, cout, relu):
     assert torch.equal(y2, y)                                         # deterministic
 
 
-@pytest.mark.parametrize("b,h,w", [(1, 16, 32), (2, 32, 64), (2, 20, 28), (1, 64, 64)])
-def test_winograd4_fused_rpn_heads(dev, b, h, w):
+@pytest.mark.parametrize("b,h,w,cout", [(1, 16, 32, 128), (2, 32, 64, 128), (2, 20, 28, 128), (1, 64, 64, 128),
+                                        (1, 16, 32, 64), (2, 36, 40, 256)])   # one, two and four N tiles
+def test_winograd4_fused_rpn_heads(dev, b, h, w, cout):
     """F(4x4) shared conv + both 1x1 heads in one launch (model.py:605-641) against torch-CPU, then through the
     scores/deltas kernel in its input form 3 against the NHWC form."""
     from maskrcnn_amd import ops
-    g = torch.Generator().manual_seed(h * 7 + w)
-    cin, cout = 64, 128
+    g = torch.Generator().manual_seed(h * 7 + w + cout)
+    cin = 64
     x = torch.randn(b, h, w, cin, generator=g).clamp_(min=0)
     wt = torch.randn(cout, 3, 3, cin, generator=g) / (9 * cin * 0.5) ** 0.5
     bs = torch.randn(cout, generator=g) * 0.1
