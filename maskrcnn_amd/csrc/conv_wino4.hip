@@ -116,13 +116,14 @@ __device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 b, f32x2 c) {  // c - a 
 
 // The MFMA with the accumulator's register class fixed by the constraint: 16 of a wave's 18 accumulators live in AGPRs,
 // 2 in VGPRs (left to itself the register allocator shuttles 288 accumulator registers between the two files inside the
-// loop). s_nop 1: the A / B operand may have been written by the VALU instruction just before (the compiler pads only
-// its own instructions).
+// loop). No wait state in front: the compiler pads only its own instructions, but in this kernel an MFMA's A operand was
+// written by VALU code a whole k tile earlier (the prologue's at least a barrier earlier) and its B operand by an LDS read
+// that an s_waitcnt has retired — never by the instruction just before.
 __device__ __forceinline__ void mfma_a(f32x16& acc, float a, float b) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_v(f32x16& acc, float a, float b) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
 // One ds_read_b64, as asm: left to the compiler, pairs of these reads become ds_read2_b64 (half rate, banked mod 32 — the
@@ -144,21 +145,29 @@ __device__ __forceinline__ W4Consts w4_consts() {
     constexpr float a2 = W4_A * W4_A, b2 = W4_B * W4_B;
     return {{a2 * b2, a2 * b2}, {a2 + b2, a2 + b2}, {b2, b2}, {W4_A, W4_A}, {a2, a2}, {W4_B, W4_B}};
 }
+// One asm statement per call: every statement boundary costs a compiler-inserted wait state in this loop.
 template <int Q>
 __device__ __forceinline__ void bt3(const f32x2 e0, const f32x2 e1, const f32x2 e2, const f32x2 e3, const f32x2 e4,
                                     const W4Consts& k, f32x2& r0, f32x2& r1, f32x2& r2) {
+    f32x2 t1, t2;
     if constexpr (Q == 0) {
-        const f32x2 t1 = pk_fnma(k.b2, e2, e4);   // d4 - b2 d2
-        const f32x2 t2 = pk_fnma(k.b2, e1, e3);   // d3 - b2 d1
-        r0 = pk_fma(k.a2b2, e0, pk_fnma(k.sab, e2, e4));  // a2b2 d0 - (a2+b2) d2 + d4
-        r1 = pk_fma(k.a, t2, t1);
-        r2 = pk_fnma(k.a, t2, t1);
+        asm("v_pk_fma_f32 %3, %10, %7, %9 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"    // t1 = d4 - b2 d2
+            "v_pk_fma_f32 %4, %10, %6, %8 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"    // t2 = d3 - b2 d1
+            "v_pk_fma_f32 %0, %11, %7, %9 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"    // r0 = d4 - (a2+b2) d2
+            "v_pk_fma_f32 %1, %13, %4, %3\n\t"                                   // r1 = t1 + a t2
+            "v_pk_fma_f32 %2, %13, %4, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"    // r2 = t1 - a t2
+            "v_pk_fma_f32 %0, %12, %5, %0"                                        // r0 += a2b2 d0
+            : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(t1), "=&v"(t2)
+            : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(e4), "v"(k.b2), "v"(k.sab), "v"(k.a2b2), "v"(k.a));
     } else {
-        const f32x2 u1 = pk_fnma(k.a2, e1, e3);   // d4 - a2 d2
-        const f32x2 u2 = pk_fnma(k.a2, e0, e2);   // d3 - a2 d1
-        r0 = pk_fma(k.b, u2, u1);
-        r1 = pk_fnma(k.b, u2, u1);
-        r2 = pk_fma(k.a2b2, e0, pk_fnma(k.sab, e2, e4));  // a2b2 d1 - (a2+b2) d3 + d5
+        asm("v_pk_fma_f32 %3, %10, %6, %8 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"    // u1 = d4 - a2 d2   (e3 - a2 e1)
+            "v_pk_fma_f32 %4, %10, %5, %7 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"    // u2 = d3 - a2 d1   (e2 - a2 e0)
+            "v_pk_fma_f32 %2, %11, %7, %9 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"    // r2 = d5 - (a2+b2) d3
+            "v_pk_fma_f32 %0, %13, %4, %3\n\t"                                   // r0 = u1 + b u2
+            "v_pk_fma_f32 %1, %13, %4, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"    // r1 = u1 - b u2
+            "v_pk_fma_f32 %2, %12, %5, %2"                                        // r2 += a2b2 d1
+            : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(t1), "=&v"(t2)
+            : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(e4), "v"(k.a2), "v"(k.sab), "v"(k.a2b2), "v"(k.b));
     }
 }
 
