@@ -181,11 +181,21 @@ __device__ __forceinline__ W4OutConsts w4_out_consts() {
 }
 __device__ __forceinline__ void at4p(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4, const f32x2 m5,
                                      const W4OutConsts& k, f32x2& y0, f32x2& y1, f32x2& y2, f32x2& y3) {
-    const f32x2 s12 = pk_add(m1, m2), d12 = pk_sub(m1, m2), s34 = pk_add(m3, m4), d34 = pk_sub(m3, m4);
-    y0 = pk_add(pk_add(m0, s12), s34);
-    y1 = pk_fma(k.b, d34, pk_mul(k.a, d12));
-    y2 = pk_fma(k.b2, s34, pk_mul(k.a2, s12));
-    y3 = pk_fma(k.b3, d34, pk_fma(k.a3, d12, m5));
+    f32x2 s12, d12, s34, d34;
+    asm("v_pk_add_f32 %4, %9, %10\n\t"                                   // s12 = m1 + m2
+        "v_pk_add_f32 %5, %9, %10 neg_lo:[0,1] neg_hi:[0,1]\n\t"         // d12 = m1 - m2
+        "v_pk_add_f32 %6, %11, %12\n\t"                                  // s34 = m3 + m4
+        "v_pk_add_f32 %7, %11, %12 neg_lo:[0,1] neg_hi:[0,1]\n\t"        // d34 = m3 - m4
+        "v_pk_add_f32 %0, %8, %4\n\t"                                    // y0 = m0 + s12
+        "v_pk_mul_f32 %1, %14, %5\n\t"                                   // y1 = a d12
+        "v_pk_mul_f32 %2, %16, %4\n\t"                                   // y2 = a2 s12
+        "v_pk_fma_f32 %3, %18, %5, %13\n\t"                              // y3 = a3 d12 + m5
+        "v_pk_add_f32 %0, %0, %6\n\t"                                    // y0 += s34
+        "v_pk_fma_f32 %1, %15, %7, %1\n\t"                               // y1 += b d34
+        "v_pk_fma_f32 %2, %17, %6, %2\n\t"                               // y2 += b2 s34
+        "v_pk_fma_f32 %3, %19, %7, %3"                                    // y3 += b3 d34
+        : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "=&v"(s12), "=&v"(d12), "=&v"(s34), "=&v"(d34)
+        : "v"(m0), "v"(m1), "v"(m2), "v"(m3), "v"(m4), "v"(m5), "v"(k.a), "v"(k.b), "v"(k.a2), "v"(k.b2), "v"(k.a3), "v"(k.b3));
 }
 // One wave's share of the kernel; QA, QB = its quadrant of the component grid (compile-time: the transform's operations
 // differ per quadrant; the four waves of a workgroup run four instances of this code and meet at the same barriers).
