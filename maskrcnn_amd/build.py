@@ -57,14 +57,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     headers += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     jobs = []
     objs = []
+    stamps = []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
             continue
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or not _newer(o, [s] + headers):
+        # an object is reused only when it was built with the same flags (e.g. MRCNN_W4_ABLATIONS toggles variants)
+        flags = " ".join([*COMMON, *extra])
+        stamp = o + ".flags"
+        same_flags = os.path.exists(stamp) and open(stamp).read() == flags
+        if force or not same_flags or not _newer(o, [s] + headers):
             jobs.append([cc, *COMMON, *extra, "-c", s, "-o", o])
+            stamps.append((stamp, flags))
 
     def run(cmd):
         if verbose:
@@ -77,6 +83,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with cf.ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
+    for stamp, flags in stamps:   # only after every compile succeeded
+        with open(stamp, "w") as fh:
+            fh.write(flags)
     if jobs or force or not _newer(LIB, objs):
         run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB])
     return LIB
