@@ -19,3 +19,16 @@ d = [st[i + 1] - st[i] for i in range(11)]
 print("cycles: setup %d | prologue %d | k loop %d (%d per k tile)" % (d[0], d[1], d[2], d[2] // (cin // 4)))
 print("  round 0: Z write %d | barrier %d | read+transform+stores %d | barrier %d" % tuple(d[3:7]))
 print("  round 1: Z write %d | barrier %d | read+transform+stores %d | barrier %d" % tuple(d[7:11]))
+
+# the heads variant: stamps land in the shift vector
+w32 = torch.zeros(32, cout, device=dev); w32[:18] = torch.randn(18, cout, generator=g).to(dev) * 0.02
+sh2 = torch.zeros(cout, device=dev)
+for _ in range(3):
+    sh2.zero_()
+    ops.conv3x3_winograd4_heads(x, u4, None, sh2, w32, True)
+torch.cuda.synchronize()
+st = sh2[:32].view(torch.int64).cpu().tolist()
+d = [st[i + 1] - st[i] for i in range(13)]
+print("heads: setup %d | prologue %d | k loop %d (%d per k tile)" % (d[0], d[1], d[2], d[2] // (cin // 4)))
+print("  round 0: Z write %d | barrier %d | read+transform+T %d | barrier %d | head MFMAs + sums %d" % tuple(d[3:8]))
+print("  round 1: Z write %d | barrier %d | read+transform+T %d | barrier %d | head MFMAs + sums %d" % tuple(d[8:13]))
