@@ -66,6 +66,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int kq = tid % TPR, r0 = tid / TPR;
+    // scale / shift of the lane's channels in flight under the whole main loop — except on the residual layers, short-K
+    // and HBM-bound, whose residual burst they would only delay (measured: C4/C5 1x1 layers -3..5 %, C2 conv3 +10 %)
+    constexpr bool EARLY_AFFINE = RES == 0 || RES == 3 || RES == 4;
+    AffineRegs<TN> affine;
+    if constexpr (EARLY_AFFINE) load_affine<TN, WTN>(p, n0, wn, lane, affine);
 
     // ---- per-thread row bookkeeping for the im2col gather ---------------------------------------------
     int a_off[PA], a_iy[PA], a_ix[PA];
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
     // ---- epilogue: affine + residual + activation (conv_common.hpp) -------------------------------------
     ResidualRegs<TM, TN, RES> rv;  // fetched in one burst, ahead of every store
     if constexpr (RES != 5) load_residual<TM, TN, WTM, WTN, RES>(p, m0, n0, wm, wn, lane, rv);
-    if constexpr (RES != 5) epilogue<TM, TN, WTM, WTN, RES>(p, acc, rv, m0, n0, wm, wn, lane);
+    if constexpr (RES != 5) epilogue<TM, TN, WTM, WTN, RES>(p, acc, rv, m0, n0, wm, wn, lane, EARLY_AFFINE ? &affine : nullptr);
 }
 
 template <int BM, int BN, int WM, int WN, int BK>

@@ -149,12 +149,30 @@ __device__ __forceinline__ void load_residual(const ConvCommon& p, int m0, int n
     }
 }
 
+// The lane's per-channel affine, fetched by the caller BEFORE its main loop when it can spare the registers: loaded at
+// the top of the epilogue the two loads sit in front of the first store with their whole memory latency exposed, once per
+// tile.
+template <int TN>
+struct AffineRegs {
+    float sc[TN], sh[TN];
+};
+template <int TN, int WTN>
+__device__ __forceinline__ void load_affine(const ConvCommon& p, int n0, int wn, int lane, AffineRegs<TN>& a) {
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn * WTN + jn * 32 + (lane & 31);
+        const bool n_ok = n < p.Cout;
+        a.sc[jn] = (n_ok && p.scale) ? p.scale[n] : 1.0f;
+        a.sh[jn] = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+    }
+}
+
 // Epilogue: act(acc*scale[c] + shift[c] (+ residual)) → y, 128-byte channel runs per half-wave. Branch-free:
 // stores go through a buffer descriptor; out-of-tile rows/channels get an out-of-range offset (dropped).
 template <int TM, int TN, int WTM, int WTN, int RES>
 __device__ __forceinline__ void epilogue(const ConvCommon& p, f32x16 (&acc)[TM][TN],
                                          const ResidualRegs<TM, TN, RES>& rv, int m0, int n0, int wm, int wn,
-                                         int lane) {
+                                         int lane, const AffineRegs<TN>* pre = nullptr) {
     static_assert(RES >= 0 && RES <= 4, "variant 5 (fused heads) lives in conv.hip");
     const int ln = lane & 31, lh = lane >> 5;
     const int ohw = p.OH * p.OW;
@@ -165,8 +183,13 @@ __device__ __forceinline__ void epilogue(const ConvCommon& p, f32x16 (&acc)[TM][
     for (int jn = 0; jn < TN; ++jn) {
         const int n = n0 + wn * WTN + jn * 32 + ln;
         const bool n_ok = n < p.Cout;
-        sc[jn] = (n_ok && p.scale) ? p.scale[n] : 1.0f;
-        sh[jn] = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+        if (pre) {
+            sc[jn] = pre->sc[jn];
+            sh[jn] = pre->sh[jn];
+        } else {
+            sc[jn] = (n_ok && p.scale) ? p.scale[n] : 1.0f;
+            sh[jn] = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+        }
         if constexpr (RES != 4) {
             ncol[jn] = !n_ok ? OOB
                        : p.out_mode == 2 ? static_cast<unsigned>(n >> 3) * (static_cast<unsigned>(p.M) * 32u) +
