@@ -325,6 +325,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
 
     // ---- epilogue: affine + residual + activation (conv_common.hpp) -------------------------------------
     ResidualRegs<TM, TN, RES> rv;  // fetched in one burst, ahead of every store
+    // 8-byte accesses on channel pairs: measured per layer class — the deconv scatter gains 7 % (its 4-byte stores hit four
+    // output rows per instruction), the C5 residual layers 3..6 %, but the short-K HBM-bound layers (C2 / C3 conv3, the
+    // downsample convs) LOSE 5..12 % and dominate: only the scatter uses it
+    if constexpr (RES == 4) {
+        if ((p.Cout & 1) == 0 && ((p.Cout >> 2) & 1) == 0) {  // never across a deconv quadrant
+            load_residual_pairs<TM, TN, WTM, WTN, RES>(p, m0, n0, wm, wn, lane, rv);
+            epilogue_pairs<TM, TN, WTM, WTN, RES>(p, acc, rv, m0, n0, wm, wn, lane, EARLY_AFFINE ? &affine : nullptr);
+            return;
+        }
+    }
     if constexpr (RES != 5) load_residual<TM, TN, WTM, WTN, RES>(p, m0, n0, wm, wn, lane, rv);
     if constexpr (RES != 5) epilogue<TM, TN, WTM, WTN, RES>(p, acc, rv, m0, n0, wm, wn, lane, EARLY_AFFINE ? &affine : nullptr);
 }

@@ -234,6 +234,138 @@ __device__ __forceinline__ void epilogue(const ConvCommon& p, f32x16 (&acc)[TM][
     }
 }
 
+// ---- the same epilogue with 8-byte accesses (Cout even) -----------------------------------------------------------
+// A lane holds ONE channel of 16 rows, so the plain epilogue moves 4 bytes per lane and instruction — 64 + 64 vector-memory
+// instructions per 32 x 32 block with a residual, and in-kernel stamps put the epilogue at a quarter of a tile's time on the
+// 1x1 expansion layers. Lanes 2j and 2j+1 (adjacent channels) pair up instead: the even lane ends up with both channels of
+// rows 0..7 of its 16, the odd lane with both channels of rows 8..15 (one DPP swap per value pair), and each moves 8 bytes
+// per instruction: half the loads and stores. rv holds the pair layout: v[i][jn][2k], [2k+1] = the two channels of the lane's
+// k-th row.
+__device__ __forceinline__ float swap_lane_pair(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+}
+
+template <int TM, int TN, int WTM, int WTN, int RES>
+__device__ __forceinline__ void load_residual_pairs(const ConvCommon& p, int m0, int n0, int wm, int wn, int lane,
+                                                    ResidualRegs<TM, TN, RES>& rv) {
+    if constexpr (RES == 1 || RES == 2) {
+        const int ln = lane & 31, lh = lane >> 5, odd = ln & 1;
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.residual), 0, p.r_bytes, 0x00020000);
+        const int rh = p.OH >> 1, rw = p.OW >> 1;
+        const unsigned row_bytes = p.res_kblocked ? 32u : static_cast<unsigned>(p.Cout) * 4u;
+        const unsigned rplane = static_cast<unsigned>(RES == 1 ? p.M : p.M >> 2) * 32u;  // bytes per 8-channel plane
+        unsigned ncol[TN];
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int n = n0 + wn * WTN + jn * 32 + ln, np = n & ~1;
+            ncol[jn] = n >= p.Cout ? OOB
+                       : p.res_kblocked ? static_cast<unsigned>(np >> 3) * rplane + static_cast<unsigned>(np & 7) * 4u
+                                        : static_cast<unsigned>(np) * 4u;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * WTM + i * 32 + 4 * lh + 16 * odd;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int m = mb + (k & 3) + 8 * (k >> 2);
+                const bool ok = m < p.M;
+                unsigned rrow;
+                if constexpr (RES == 1) {
+                    rrow = ok ? static_cast<unsigned>(m) * row_bytes : OOB;
+                } else {  // residual at half size: (oy/2, ox/2) (FPN nearest-neighbour upsample + add)
+                    const int mm = ok ? m : 0;
+                    int b, oy, ox;
+                    decode_pixel(p, mm, b, oy, ox);
+                    rrow = ok ? static_cast<unsigned>((b * rh + (oy >> 1)) * rw + (ox >> 1)) * row_bytes : OOB;
+                }
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) {
+                    const unsigned off = (rrow | ncol[jn]) >= OOB ? OOB : rrow + ncol[jn];
+                    const auto w = __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, static_cast<int>(off), 0, 0);
+                    rv.v[i][jn][2 * k] = __uint_as_float(w[0]);
+                    rv.v[i][jn][2 * k + 1] = __uint_as_float(w[1]);
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int WTM, int WTN, int RES>
+__device__ __forceinline__ void epilogue_pairs(const ConvCommon& p, f32x16 (&acc)[TM][TN],
+                                               const ResidualRegs<TM, TN, RES>& rv, int m0, int n0, int wm, int wn,
+                                               int lane, const AffineRegs<TN>* pre = nullptr) {
+    static_assert(RES == 0 || RES == 1 || RES == 2 || RES == 4, "sigmoid (odd channel counts) keeps the 4-byte epilogue");
+    const int ln = lane & 31, lh = lane >> 5;
+    const bool odd = ln & 1;
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    float sc[TN], sh[TN];
+    unsigned ncol[TN];  // byte offset of the lane pair's first channel, or OOB
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n0 + wn * WTN + jn * 32 + ln, np = n & ~1;
+        const bool n_ok = n < p.Cout;  // Cout is even: both channels of a pair are in or out together
+        if (pre) {
+            sc[jn] = pre->sc[jn];
+            sh[jn] = pre->sh[jn];
+        } else {
+            sc[jn] = (n_ok && p.scale) ? p.scale[n] : 1.0f;
+            sh[jn] = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+        }
+        if constexpr (RES != 4) {
+            ncol[jn] = !n_ok ? OOB
+                       : p.out_mode == 2 ? static_cast<unsigned>(np >> 3) * (static_cast<unsigned>(p.M) * 32u) +
+                                               static_cast<unsigned>(np & 7) * 4u
+                                         : static_cast<unsigned>(np) * 4u;
+        } else {  // n = (dy*2 + dx)*cq + co  →  pixel (2i+dy, 2j+dx), channel co of the [B][2*OH][2*OW][cq] output (cq even)
+            const int cq = p.Cout >> 2, q = np / cq, co = np - q * cq;
+            ncol[jn] = n_ok ? static_cast<unsigned>(((q >> 1) * 2 * p.OW + (q & 1)) * cq + co) * 4u : OOB;
+        }
+    }
+    const unsigned row_bytes = p.out_mode == 2 ? 32u : static_cast<unsigned>(p.Cout) * 4u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * WTM + i * 32 + 4 * lh + (odd ? 16 : 0);  // the lane's rows: mb + (k&3) + 8*(k>>2)
+        unsigned yrow[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int m = mb + (k & 3) + 8 * (k >> 2);
+            const bool ok = m < p.M;
+            if constexpr (RES != 4) {
+                yrow[k] = ok ? static_cast<unsigned>(m) * row_bytes : OOB;
+            } else {
+                const int mm = ok ? m : 0;
+                int b, oy, ox;
+                decode_pixel(p, mm, b, oy, ox);
+                yrow[k] = ok ? static_cast<unsigned>((b * 2 * p.OH + 2 * oy) * (2 * p.OW) + 2 * ox) * (row_bytes >> 2)
+                             : OOB;
+            }
+        }
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float va = acc[i][jn][k] * sc[jn] + sh[jn];          // own channel, row k
+                const float vb = acc[i][jn][k + 8] * sc[jn] + sh[jn];      // own channel, row k + 8
+                const float got = swap_lane_pair(odd ? va : vb);           // the partner's channel at the row this lane keeps
+                float lo = odd ? got : va, hi = odd ? vb : got;            // channels np, np + 1
+                if constexpr (RES == 1 || RES == 2) {
+                    lo += rv.v[i][jn][2 * k];
+                    hi += rv.v[i][jn][2 * k + 1];
+                }
+                if (p.act) {
+                    lo = lo > 0.f ? lo : 0.f;
+                    hi = hi > 0.f ? hi : 0.f;
+                }
+                const unsigned off = (yrow[k] | ncol[jn]) >= OOB ? OOB : yrow[k] + ncol[jn];
+                typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(lo), __float_as_uint(hi)}, y_rsrc,
+                                                      static_cast<int>(off), 0, 0);
+            }
+        }
+    }
+}
+
 // Host-side validation + fill of the common part; returns MRCNN_OK or sets the error message.
 inline int fill_common(ConvCommon& p, const char* who, const float* x, int batch, int height, int width, int cin,
                        int cin_multiple, int cout, int kh, int kw, int stride, int pad_top, int pad_left,
