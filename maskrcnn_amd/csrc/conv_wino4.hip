@@ -69,6 +69,7 @@ struct Wino4Params {
 };
 
 constexpr int W4_N = 64;                              // output channels per workgroup
+constexpr int W4_TSLOT = 6;                           // MFMA slot of the k loop that carries the input transform
 constexpr int W4_RW = 40;                             // channel pairs per raw row in LDS (34 used; == 0 mod 8)
 constexpr int W4_RPLANE = 18 * W4_RW + 8;             // pairs per (buffer, channel pair) plane, rotation included
 constexpr int W4_RS_FLOATS = 2 * 2 * W4_RPLANE * 2;   // raw region: [2 buffers][2 channel pairs][plane][2]
@@ -312,21 +313,22 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         // and Bv[2g+1] are dead after slot 4g+3 and the next k tile's values are read into them at slots 4g+4, 4g+5; only
         // the last group (dead after the last slot) has a second register set.
         f32x2 A[2][9], Bv[16], Bl[2][2];
-        f32x2 e[3][5], t[3][5];
+        f32x2 e[5][5], t[3][5];
         auto read_col = [&](int buf, int c) {  // column QB + c of the patch, rows QA..QA+4
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 const int dy = QA + r, dx = QB + c;
-                e[c % 3][r] = lds_read_b64(rp_addr[buf], (dy * W4_RW + (dy >= 4 ? 1 : 0) + dx) * 8);
+                e[c][r] = lds_read_b64(rp_addr[buf], (dy * W4_RW + (dy >= 4 ? 1 : 0) + dx) * 8);
             }
         };
         // newer LDS reads than the column's own may stay in flight (wait_n of them: the schedule below knows the count)
         auto row_stage = [&](int c, int wait_n) {
-            if (wait_n >= 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(e[c % 3][0]), "+v"(e[c % 3][1]), "+v"(e[c % 3][2]), "+v"(e[c % 3][3]), "+v"(e[c % 3][4]));
-            else if (wait_n == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(e[c % 3][0]), "+v"(e[c % 3][1]), "+v"(e[c % 3][2]), "+v"(e[c % 3][3]), "+v"(e[c % 3][4]));
-            else if (wait_n == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(e[c % 3][0]), "+v"(e[c % 3][1]), "+v"(e[c % 3][2]), "+v"(e[c % 3][3]), "+v"(e[c % 3][4]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[c % 3][0]), "+v"(e[c % 3][1]), "+v"(e[c % 3][2]), "+v"(e[c % 3][3]), "+v"(e[c % 3][4]));
-            bt3<QA>(e[c % 3][0], e[c % 3][1], e[c % 3][2], e[c % 3][3], e[c % 3][4], kin, t[0][c], t[1][c], t[2][c]);
+            if (wait_n < 0) {}
+            else if (wait_n >= 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(e[c][0]), "+v"(e[c][1]), "+v"(e[c][2]), "+v"(e[c][3]), "+v"(e[c][4]));
+            else if (wait_n == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(e[c][0]), "+v"(e[c][1]), "+v"(e[c][2]), "+v"(e[c][3]), "+v"(e[c][4]));
+            else if (wait_n == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(e[c][0]), "+v"(e[c][1]), "+v"(e[c][2]), "+v"(e[c][3]), "+v"(e[c][4]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e[c][0]), "+v"(e[c][1]), "+v"(e[c][2]), "+v"(e[c][3]), "+v"(e[c][4]));
+            bt3<QA>(e[c][0], e[c][1], e[c][2], e[c][3], e[c][4], kin, t[0][c], t[1][c], t[2][c]);
         };
         auto col_stage = [&](int set, int i) {
             bt3<QB>(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], kin, A[set][i * 3 + 0], A[set][i * 3 + 1], A[set][i * 3 + 2]);
@@ -394,8 +396,11 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         // ---- one k tile. 36 MFMA slots, the order pinned (sched_barrier after every slot); beside the MFMAs of k tile kt:
         //   slots 10,11,14,15,..,26  LDS-DMA of U(kt+2) into the buffer U(kt) has left (its B reads completed before the last
         //                barrier): the slots that carry nothing else — a DMA beside LDS reads and VALU work delays the next MFMA
-        //   slots 0-4    the lane's patch of k tile kt+1, one column per slot;  slots 2-6 its row transform (two slots
-        //                behind the reads, with a counted wait);  slots 7-9 the column transform -> A(kt+1)
+        //   slots 0-4    the lane's patch of k tile kt+1, one column per slot;  slot 6 its whole transform -> A(kt+1), all 48
+        //                packed operations behind one MFMA (a counted wait in front). Spread over eight slots, six operations
+        //                each, the same work cost 3 % more of the kernel: every switch between the MFMA stream and VALU
+        //                work costs, so VALU work is bunched — LDS reads and DMA pieces, the opposite, are spread (bunched
+        //                they stall their queues: all 25 patch reads in one slot +2.5 %, all 9 DMA pieces +4 %)
         //   slots 4-35   B(kt+1): slots 4g+4, 4g+5 refill the registers group g has left; slots 34, 35 the last group's
         //   slots 27-29  raw k tile kt+2: registers -> LDS (the buffer of kt, last read a k tile ago); reload with kt+3
         // then vmcnt(3) (the three raw loads may stay in flight, every DMA has landed), lgkmcnt(0), barrier.
@@ -406,9 +411,12 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
             for (int slot = 0; slot < 36; ++slot) {
                 mfma(CUR, slot);
                 if (slot >= 10 && slot <= 26 && (slot & 3) >= 2 && !(DBG & 1)) dma_u1(kt + 2, CUR, ((slot - 10) >> 2) * 2 + (slot & 1));
-                if (slot >= 2 && slot <= 6 && !(DBG & 2))   // LDS reads issued after column slot-2's: the rest of its slot, all of the next
-                    row_stage(slot - 2, (DBG & 12) ? 0 : b_in_slot(slot - 2) + (slot - 1 < 5 ? 5 : 0) + b_in_slot(slot - 1));
-                if (slot >= 7 && slot <= 9 && !(DBG & 2)) col_stage(NXT, slot - 7);
+                if (slot == W4_TSLOT && !(DBG & 2)) {   // the whole transform behind ONE MFMA (see the slot table above)
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) row_stage(c, c == 0 ? ((DBG & 12) ? 0 : b_in_slot(4) + b_in_slot(5)) : -1);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) col_stage(NXT, i);
+                }
                 if (slot < 5 && !(DBG & 4)) read_col(NXT, slot);
                 if (slot >= 4 && slot <= 33 && (slot & 3) < 2 && !(DBG & 8)) read_b(NXT, NXT, ((slot - 4) >> 2) * 2 + (slot & 1));
                 if (slot >= 34 && !(DBG & 8)) read_b(NXT, NXT, slot - 18);
