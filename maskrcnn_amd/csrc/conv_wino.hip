@@ -155,12 +155,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const WinoParams p) {
         t[2][dx] = pk_sub(d2, d1);
         t[3][dx] = pk_sub(d1, d3);
     };
-    auto v_store = [&](int xi, float* vbuf) {
+    auto v_comp = [&](int xi) {
         const int i = xi >> 2, j = xi & 3;
-        const f32x2 v = j == 0 ? pk_sub(t[i][0], t[i][2]) : j == 1 ? pk_add(t[i][1], t[i][2])
-                      : j == 2 ? pk_sub(t[i][2], t[i][1]) : pk_sub(t[i][1], t[i][3]);
-        *reinterpret_cast<f32x2*>(vbuf + xi * PLANE) = v;
+        return j == 0 ? pk_sub(t[i][0], t[i][2]) : j == 1 ? pk_add(t[i][1], t[i][2])
+             : j == 2 ? pk_sub(t[i][2], t[i][1]) : pk_sub(t[i][1], t[i][3]);
     };
+    auto v_store = [&](int xi, float* vbuf) { *reinterpret_cast<f32x2*>(vbuf + xi * PLANE) = v_comp(xi); };
+    f32x2 vv[16];   // main loop: the 16 components, computed in one go (see the slot comment there)
     auto u_store = [&](int i, float* ubuf) { *reinterpret_cast<u32x4*>(ubuf + i * 2 * PLANE) = ul[i]; };
 
     // wave w owns transform row i = w: components xi = 4w + j, j = 0..3, for the WHOLE 64 x 64 workgroup tile
@@ -438,12 +439,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32(const WinoParams p) 
         t[2][dx] = pk_sub(d2, d1);
         t[3][dx] = pk_sub(d1, d3);
     };
-    auto v_store = [&](int xi, float* vbuf) {
+    auto v_comp = [&](int xi) {
         const int i = xi >> 2, j = xi & 3;
-        const f32x2 v = j == 0 ? pk_sub(t[i][0], t[i][2]) : j == 1 ? pk_add(t[i][1], t[i][2])
-                      : j == 2 ? pk_sub(t[i][2], t[i][1]) : pk_sub(t[i][1], t[i][3]);
-        *reinterpret_cast<f32x2*>(vbuf + xi * PLANE) = v;
+        return j == 0 ? pk_sub(t[i][0], t[i][2]) : j == 1 ? pk_add(t[i][1], t[i][2])
+             : j == 2 ? pk_sub(t[i][2], t[i][1]) : pk_sub(t[i][1], t[i][3]);
     };
+    auto v_store = [&](int xi, float* vbuf) { *reinterpret_cast<f32x2*>(vbuf + xi * PLANE) = v_comp(xi); };
+    f32x2 vv[16];   // main loop: the 16 components, computed in one go (see the slot comment there)
     auto u_store = [&](int i, float* ubuf) {
         *reinterpret_cast<u32x4*>(ubuf + i * 2 * PLANE) = u32x4{ld[2 * i].x, ld[2 * i].y, ld[2 * i + 1].x, ld[2 * i + 1].y};
     };
@@ -515,9 +517,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8_f32(const WinoParams p) 
                             acc[j][a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j][a][c], 0, 0, 0);
                             const int m = j * 16 + stp * 4 + a * 2 + c;  // MFMA slot 0..31
                             if constexpr (VROLE) {
-                                if (m < 4) column_pass(m);
+                                // the whole transform (32 packed adds) behind ONE MFMA: every switch between the MFMA
+                                // stream and VALU work costs (measured on the F(4x4) kernel: -3 %); the LDS writes and
+                                // the loads stay one per slot
+                                if (m == 0) {
+#pragma unroll
+                                    for (int dx = 0; dx < 4; ++dx) column_pass(dx);
+#pragma unroll
+                                    for (int xi = 0; xi < 16; ++xi) vv[xi] = v_comp(xi);
+                                }
                                 if (m >= 4 && m < 20) v_load(m - 4, kt + 2);
-                                if (m >= 8 && m < 24) v_store(m - 8, vnext);
+                                if (m >= 8 && m < 24) *reinterpret_cast<f32x2*>(vnext + (m - 8) * PLANE) = vv[m - 8];
                             } else {
                                 if (m >= 4 && m < 12) {
                                     u_store(m - 4, unext);
