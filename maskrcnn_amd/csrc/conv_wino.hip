@@ -852,9 +852,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8s_f32(const WinoSParams p
         col_pass(0);
         // ---- main loop, order pinned (sched_barrier after every MFMA); 32 MFMAs per k tile and wave:
         //   slots  0-15  position half 0 (j = 0: 0-7, j = 1: 8-15): fb[1] of this k tile, the six patch reads of half 1
-        //                (one per slot), their transform (slots 8-11), the six LDS writes of k tile kt+1 (10-15)
+        //                (one per slot), their transform (slot 8), the six LDS writes of k tile kt+1 (10-15)
         //   slots 16-31  position half 1: the six global loads of k tile kt+2 (16-21); the barrier sits after slot 23, then
-        //                fb[0] and the patch reads of half 0 of k tile kt+1 (24-29) and their transform (30-31) — the
+        //                fb[0] and the patch reads of half 0 of k tile kt+1 (24-29) and their transform (30) — the
         //                next k tile starts with its operands in registers.
         // the k loop is unrolled by two so that the buffer index is a compile-time constant: every LDS address is then a
         // per-thread base plus an instruction-immediate offset (no address VALU in the loop)
@@ -875,8 +875,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8s_f32(const WinoSParams p
                             const int m = a * 16 + j * 8 + stp * 2 + c;  // slot 0..31
                             if (m == 0) fb_read(1, buf);
                             if (m < 6) patch_read(m, buf, 1);
-                            if (m >= 8 && m < 11) row_pass(m - 8);
-                            if (m == 11) col_pass(1);
+                            if (m == 8) {   // each transform behind ONE MFMA: switching between MFMAs and VALU work costs
+                                row_pass(0); row_pass(1); row_pass(2);
+                                col_pass(1);
+                            }
                             if (m >= 10 && m < 16) store_piece(m - 10, buf ^ 1);
                             if (m >= 16 && m < 22) load_piece(m - 16, kt + 2);
                             if (m == 23) {
@@ -884,8 +886,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino8s_f32(const WinoSParams p
                                 fb_read(0, buf ^ 1);
                             }
                             if (m >= 24 && m < 30) patch_read(m - 24, buf ^ 1, 0);
-                            if (m == 30) { row_pass(0); row_pass(1); row_pass(2); }
-                            if (m == 31) col_pass(0);
+                            if (m == 30) {
+                                row_pass(0); row_pass(1); row_pass(2);
+                                col_pass(0);
+                            }
                             __builtin_amdgcn_sched_barrier(0);
                         }
         };
