@@ -410,7 +410,12 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
     // Bottleneck conv3 (1x1 expansion + residual, K = planes <= 256): latency-bound on load -> MFMA -> residual -> store
     // per tile; a 128x64 BK16 tile (30 KB of LDS, 32 accumulator registers) keeps five workgroups per CU in flight
     // instead of two: 7 % faster on those layers, slower on everything else (measured per layer, round 1)
-    if (!generic && force != 1 && (force == 5 || (p.K <= 256 && p.residual && p.res_div == 1 && cout >= 128)))
+    // The same tile when 128x128 tiles would not even give every CU one workgroup (P5 lateral at batch 8: 128 tiles; 131 ->
+    // 94 us). Same products in the same order per output: the choice never changes a result.
+    const long long tiles128 = ((p.M + 127) / 128) * static_cast<long long>((cout + 127) / 128);
+    const bool underfilled = cout >= 128 && tiles128 < mrcnn::device_cu_count();
+    if (!generic && force != 1 &&
+        (force == 5 || underfilled || (p.K <= 256 && p.residual && p.res_div == 1 && cout >= 128)))
         return launch_conv<128, 64, 2, 2, 16>(p, mode, s);
     return launch_conv<128, 128, 2, 2, 32>(p, mode, s);
 }
