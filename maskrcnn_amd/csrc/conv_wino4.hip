@@ -205,7 +205,7 @@ __device__ __forceinline__ void at4p(const f32x2 m0, const f32x2 m1, const f32x2
 // head sums, which stay in LDS until the last N tile writes them out.
 // DBG: compile-time tuning variants (MRCNN_W4_ABLATIONS builds): bits 1..1024 leave parts out (wrong results, timing only),
 // 2048 records s_memtime stamps of a tile's phases (tools/w4_stamp.py). DBG = 0 is the product.
-template <int QA, int QB, int DBG, bool HEADS>
+template <int QA, int QB, int DBG, bool HEADS, bool ACT>
 __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) {
     lds_f32x2* Rs = (lds_f32x2*)smem;            // [2][2][W4_RPLANE] channel pairs
     lds_f32* Us = smem + W4_RS_FLOATS;           // [2][36][2][64][2]
@@ -514,9 +514,11 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                 f32x2 yv[4];
                 at4p(w[0][j], w[1][j], w[2][j], w[3][j], w[4][j], w[5][j], kout, yv[0], yv[1], yv[2], yv[3]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    yv[i] = pk_fma(yv[i], sc2, sh2);
-                    if (p.act) yv[i] = f32x2{fmaxf(yv[i].x, 0.f), fmaxf(yv[i].y, 0.f)};
+                for (int i = 0; i < 4; ++i) yv[i] = pk_fma(yv[i], sc2, sh2);
+                if constexpr (ACT) {  // one v_max per value (fmaxf() costs a canonicalising v_max, the v_max and a select each)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        asm("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1" : "+v"(yv[i].x), "+v"(yv[i].y));
                 }
                 if (DBG & 32) { if (yv[0].x == 12345.678f) p.y[0] = yv[0].x; continue; }
                 if constexpr (HEADS) {
@@ -599,15 +601,15 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
 
 // DBG: timing ablations for tuning (wrong results): 1 no DMA, 2 no transform, 4 no patch reads, 8 no B reads, 16 no raw
 // staging. Only DBG = 0 is built unless MRCNN_W4_ABLATIONS is defined.
-template <int DBG, bool HEADS>
+template <int DBG, bool HEADS, bool ACT = true>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const Wino4Params p) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     lds_f32* lds = (lds_f32*)smem;
-    if (wave == 0) wino4_wave<0, 0, DBG, HEADS>(p, lds);
-    else if (wave == 1) wino4_wave<0, 1, DBG, HEADS>(p, lds);
-    else if (wave == 2) wino4_wave<1, 0, DBG, HEADS>(p, lds);
-    else wino4_wave<1, 1, DBG, HEADS>(p, lds);
+    if (wave == 0) wino4_wave<0, 0, DBG, HEADS, ACT>(p, lds);
+    else if (wave == 1) wino4_wave<0, 1, DBG, HEADS, ACT>(p, lds);
+    else if (wave == 2) wino4_wave<1, 0, DBG, HEADS, ACT>(p, lds);
+    else wino4_wave<1, 1, DBG, HEADS, ACT>(p, lds);
 }
 
 // G g G^T in double, stored as the kernel's [Cin/4][36][2][Cout][2]. G (6 x 3): row of point p = [1 p p^2] / N_p, N_p the
@@ -693,7 +695,7 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
     p.debug = getenv("MRCNN_W4_DEBUG") ? atoi(getenv("MRCNN_W4_DEBUG")) : 0;
     const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
     MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd4: grid too large");
-    void (*kern)(const Wino4Params) = conv3x3_wino4_f32<0, false>;
+    void (*kern)(const Wino4Params) = activation ? conv3x3_wino4_f32<0, false, true> : conv3x3_wino4_f32<0, false, false>;
 #ifdef MRCNN_W4_ABLATIONS
     switch (p.debug) {
         case 1: kern = conv3x3_wino4_f32<1, false>; break;
@@ -752,7 +754,7 @@ extern "C" int mrcnn_conv3x3_winograd4_heads_f32(const float* x_kblocked, int32_
     p.w_head = w_head32; p.head_part = head_part;
     p.head_bytes = static_cast<unsigned>(4LL * rows * 32);
     p.debug = getenv("MRCNN_W4_DEBUG") ? atoi(getenv("MRCNN_W4_DEBUG")) : 0;
-    void (*kern)(const Wino4Params) = conv3x3_wino4_f32<0, true>;
+    void (*kern)(const Wino4Params) = activation ? conv3x3_wino4_f32<0, true, true> : conv3x3_wino4_f32<0, true, false>;
 #ifdef MRCNN_W4_ABLATIONS
     switch (p.debug) {
         case 32: kern = conv3x3_wino4_f32<32, true>; break;
