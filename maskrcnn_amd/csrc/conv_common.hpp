@@ -10,6 +10,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond every buffer descriptor's num_records
 
+// row offset + column offset where either may be OOB: a saturating add (one v_add_u32 ... clamp) keeps the sum out of range
+// — the or / compare / add / select it replaces are VALU instructions of an epilogue that runs beside the other workgroup's
+// MFMAs on the same SIMD, and VALU work does not co-execute with this MFMA.
+__device__ __forceinline__ unsigned oob_add(unsigned a, unsigned b) { return __builtin_elementwise_add_sat(a, b); }
+
 // Everything about the convolution that does not depend on how the weights are stored.
 struct ConvCommon {
     const float* x;
@@ -140,7 +145,7 @@ __device__ __forceinline__ void load_residual(const ConvCommon& p, int m0, int n
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
                     // OOB in either term must stay OOB
-                    const unsigned off = (rrow | ncol[jn]) >= OOB ? OOB : rrow + ncol[jn];
+                    const unsigned off = oob_add(rrow, ncol[jn]);
                     rv.v[i][jn][r] =
                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, static_cast<int>(off), 0, 0));
                 }
@@ -227,7 +232,7 @@ __device__ __forceinline__ void epilogue(const ConvCommon& p, f32x16 (&acc)[TM][
                 if constexpr (RES == 1 || RES == 2) v += rv.v[i][jn][r];
                 if constexpr (RES == 3) v = 1.0f / (1.0f + expf(-v));
                 else if (p.act) v = v > 0.f ? v : 0.f;
-                const unsigned off = (yrow[r] | ncol[jn]) >= OOB ? OOB : yrow[r] + ncol[jn];
+                const unsigned off = oob_add(yrow[r], ncol[jn]);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(off), 0, 0);
             }
         }
@@ -281,7 +286,7 @@ __device__ __forceinline__ void load_residual_pairs(const ConvCommon& p, int m0,
                 }
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
-                    const unsigned off = (rrow | ncol[jn]) >= OOB ? OOB : rrow + ncol[jn];
+                    const unsigned off = oob_add(rrow, ncol[jn]);
                     const auto w = __builtin_amdgcn_raw_buffer_load_b64(r_rsrc, static_cast<int>(off), 0, 0);
                     rv.v[i][jn][2 * k] = __uint_as_float(w[0]);
                     rv.v[i][jn][2 * k + 1] = __uint_as_float(w[1]);
@@ -357,7 +362,7 @@ __device__ __forceinline__ void epilogue_pairs(const ConvCommon& p, f32x16 (&acc
                     lo = lo > 0.f ? lo : 0.f;
                     hi = hi > 0.f ? hi : 0.f;
                 }
-                const unsigned off = (yrow[k] | ncol[jn]) >= OOB ? OOB : yrow[k] + ncol[jn];
+                const unsigned off = oob_add(yrow[k], ncol[jn]);
                 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
                 __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(lo), __float_as_uint(hi)}, y_rsrc,
                                                       static_cast<int>(off), 0, 0);

@@ -113,7 +113,7 @@ __device__ __forceinline__ void epilogue16(const ConvCommon& p, f32x16 (&acc)[TM
             if constexpr (RES == 1 || RES == 2) {
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) {
-                    const unsigned off = (rrow | rcol[jn]) >= OOB ? OOB : rrow + rcol[jn];
+                    const unsigned off = oob_add(rrow, rcol[jn]);
                     rw[i][rp][jn] = __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, static_cast<int>(off), 0, 0);
                 }
             }
@@ -145,7 +145,7 @@ __device__ __forceinline__ void epilogue16(const ConvCommon& p, f32x16 (&acc)[TM
                 const unsigned h1 = __builtin_bit_cast(unsigned short, static_cast<_Float16>(v1));
                 const unsigned keep = odd ? h1 : h0, got = swap_pair(odd ? h0 : h1);
                 const unsigned word = odd ? (got | (keep << 16)) : (keep | (got << 16));
-                const unsigned off = (yrow[i][rp] | ncol[jn]) >= OOB ? OOB : yrow[i][rp] + ncol[jn];
+                const unsigned off = oob_add(yrow[i][rp], ncol[jn]);
                 __builtin_amdgcn_raw_buffer_store_b32(word, y_rsrc, static_cast<int>(off), 0, 0);
             }
         }
