@@ -231,7 +231,7 @@ __device__ __forceinline__ void epilogue(const ConvCommon& p, f32x16 (&acc)[TM][
                 float v = acc[i][jn][r] * sc[jn] + sh[jn];
                 if constexpr (RES == 1 || RES == 2) v += rv.v[i][jn][r];
                 if constexpr (RES == 3) v = 1.0f / (1.0f + expf(-v));
-                else if (p.act) v = v > 0.f ? v : 0.f;
+                else if (p.act) asm("v_max_f32 %0, 0, %0" : "+v"(v));   // NaN -> 0 like (v > 0 ? v : 0), one instruction
                 const unsigned off = oob_add(yrow[r], ncol[jn]);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(off), 0, 0);
             }
@@ -358,10 +358,7 @@ __device__ __forceinline__ void epilogue_pairs(const ConvCommon& p, f32x16 (&acc
                     lo += rv.v[i][jn][2 * k];
                     hi += rv.v[i][jn][2 * k + 1];
                 }
-                if (p.act) {
-                    lo = lo > 0.f ? lo : 0.f;
-                    hi = hi > 0.f ? hi : 0.f;
-                }
+                if (p.act) asm("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1" : "+v"(lo), "+v"(hi));
                 const unsigned off = oob_add(yrow[k], ncol[jn]);
                 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
                 __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(lo), __float_as_uint(hi)}, y_rsrc,
