@@ -10,7 +10,7 @@ Sources of truth used here (nothing of theirs is copied into the repo — only i
     c++ext/maskrcnn/__init__.py:21-45 does (that file's legacy autograd.Function cannot run on
     torch >= 1.5).
 
-Usage:  python tests/golden/make_golden.py [nms crop roi_align anchors graph refine schema image config1]
+Usage:  python tests/golden/make_golden.py [nms crop roi_align roi_levels anchors graph refine schema image config1]
         (no argument: rewrite every fixture; deterministic)
 """
 import contextlib
@@ -248,6 +248,52 @@ def gen_roi_align(rmodel):
         pooled = rmodel.roi_align([boxes.unsqueeze(0)] + [f.clone() for f in fms], pool, image_shape)
         out[f"pooled{pool}"] = pooled.numpy()
     save("roi_align", **out)
+
+
+def level_sweep_boxes(hh, ww):
+    """Boxes whose sqrt(area) sits within +-4 ulp (and +-16 / +-64 ulp) of every pyramid-level boundary k = 2.5 / 3.5 /
+    4.5 of an hh x ww image, square and at seven aspect ratios, at two offsets (the sweep of
+    tests/test_gpu_fullsize.py::test_level_boundaries_ulp_sweep; the boxes are stored, the test does not rebuild them)."""
+    area = float(hh * ww)
+    rows = []
+    for k in (2.5, 3.5, 4.5):
+        s0 = (224.0 / np.sqrt(area)) * 2.0 ** (k - 4.0)                  # sqrt(h*w) at the boundary
+        for ratio in (1.0, 2.0, 0.5, 4.0, 0.125, 3.0, 1.7):
+            h0 = torch.tensor(s0 * np.sqrt(ratio), dtype=torch.float32)
+            w0 = torch.tensor(s0 / np.sqrt(ratio), dtype=torch.float32)
+            if h0 > 1 or w0 > 1:
+                continue
+            for dh in list(range(-4, 5)) + [-64, -16, 16, 64]:
+                for dw in (-2, -1, 0, 1, 2):
+                    h, w = h0.clone(), w0.clone()
+                    for _ in range(abs(dh)):
+                        h = torch.nextafter(h, torch.tensor(2.0 if dh > 0 else 0.0))
+                    for _ in range(abs(dw)):
+                        w = torch.nextafter(w, torch.tensor(2.0 if dw > 0 else 0.0))
+                    for y1, x1 in ((0.0, 0.0), (0.25, 0.125)):
+                        rows.append([y1, x1, y1 + h.item(), x1 + w.item()])
+    rois = torch.tensor(rows, dtype=torch.float32)
+    return rois[(rois[:, 2] <= 1) & (rois[:, 3] <= 1)].contiguous()
+
+
+def gen_roi_levels(rmodel):
+    """The pyramid level the REFERENCE gives every box of the ulp sweep: model.roi_align (model.py:276-393, unmodified)
+    on four constant-valued maps (level l holds the value l), pool size 1 — the crop of a box inside the image is the
+    constant of the map it was taken from, i.e. the level `roi_level` (model.py:331-338) assigned in this container
+    (torch-CPU log2 = MKL VML here). A random set of ordinary boxes rides along."""
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    for hh, ww in ((1024, 1024), (832, 1344)):
+        rois = torch.cat([level_sweep_boxes(hh, ww), rand_boxes(g, 400, lo=0.01, hi=0.9)], 0)
+        fms = [torch.full((1, 1, 4, 4), float(l)) for l in (2, 3, 4, 5)]
+        pooled = rmodel.roi_align([rois.unsqueeze(0)] + fms, 1, np.array([hh, ww, 3]))
+        lv = pooled.reshape(-1)
+        assert lv.numel() == rois.size(0) and bool(((lv == lv.round()) & (lv >= 2) & (lv <= 5)).all())
+        out[f"rois_{hh}x{ww}"] = rois.numpy()
+        out[f"levels_{hh}x{ww}"] = lv.to(torch.int32).numpy()
+        print(f"levels {hh}x{ww}: {rois.size(0)} boxes, histogram {torch.bincount(lv.long(), minlength=6).tolist()}")
+    out["torch_version"] = np.array(torch.__version__)
+    save("roi_levels", **out)
 
 
 def gen_anchors_boxes(rconfig, rutils, rdata):
@@ -550,6 +596,8 @@ def main():
         gen_crop(refc)
     if want("roi_align"):
         gen_roi_align(rmodel)
+    if want("roi_levels"):
+        gen_roi_levels(rmodel)
     if want("anchors"):
         gen_anchors_boxes(rconfig, rutils, rdata)
     if want("graph"):

@@ -105,6 +105,32 @@ def test_roi_align_golden(oracle):
         assert np.array_equal(got.numpy(), z[f"pooled{pool}"])
 
 
+def test_roi_levels_reference_sweep(oracle):
+    """tests/golden/roi_levels.npz = the level the reference's own model.roi_align assigned (build container) to every
+    box of the +-4 / +-16 / +-64 ulp sweeps around the k = 2.5 / 3.5 / 4.5 boundaries + 400 ordinary boxes, both image
+    shapes. (a) the formula of model.py:331-338 with every fp32 operation correctly rounded — machine-independent, and
+    what the HIP kernel evaluates — equals the reference on EVERY box; (b) the oracle's torch expression (this host's
+    MKL log2) equals it on every ordinary box, and is at most one level off on boundary boxes (identical in the build
+    container; VML's last bit differs between CPUs)."""
+    z = load_golden("roi_levels")
+    for hh, ww in ((1024, 1024), (832, 1344)):
+        r, ref = z[f"rois_{hh}x{ww}"], z[f"levels_{hh}x{ww}"]
+        area = float(hh * ww)
+        h32, w32 = (r[:, 2] - r[:, 0]).astype(np.float32), (r[:, 3] - r[:, 1]).astype(np.float32)
+        hw32 = (h32 * w32).astype(np.float32)
+        denom = (np.float64(224.0) / np.sqrt(np.float64(np.float32(area))).astype(np.float32)).astype(np.float32)
+        with np.errstate(divide="ignore"):
+            ratio = (np.sqrt(hw32.astype(np.float64)).astype(np.float32).astype(np.float64) / np.float64(denom)).astype(np.float32)
+            k = (np.float32(4.0) + np.log2(ratio.astype(np.float64)).astype(np.float32)).astype(np.float32)
+        k = np.where(np.isfinite(k), k, np.float32(-100.0))
+        exact = np.clip(np.rint(k), 2, 5).astype(np.int32)
+        assert np.array_equal(exact, ref), f"{(exact != ref).sum()} boxes: reference != correctly rounded formula"
+        got = oracle.roi_levels(torch.from_numpy(r), (hh, ww, 3)).numpy()
+        assert np.array_equal(got[-400:], ref[-400:])
+        assert np.abs(got - ref).max() <= 1 and (got != ref).mean() <= 0.15
+        assert all((ref == l).sum() > 100 for l in (2, 3, 4, 5))
+
+
 def test_anchors_known_answers(oracle):
     z = load_golden("anchors_boxes")
     cfg = oracle.Cfg()
