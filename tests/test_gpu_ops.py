@@ -162,6 +162,47 @@ def test_crop_forward_random_vs_oracle(dev, oracle):
         assert torch.equal(got.cpu(), want), (b, c, h, w, n, ch, cw)
 
 
+def _bits_equal(a, b):
+    """Bit for bit, the sign of a zero included (torch.equal would pass -0.0 == +0.0)."""
+    return torch.equal(a.contiguous().view(torch.int32), b.contiguous().view(torch.int32))
+
+
+def test_crop_forward_staged_path_vs_oracle(dev, oracle, monkeypatch):
+    """The LDS-staged NCHW kernel (crop sizes with ch*cw % 4 == 0 and <= 256, W % 4 == 0): small and large footprints (the
+    latter fall back to the gather path inside the same launch), boxes partly / wholly outside, reversed boxes, samples that
+    land exactly on pixels (lo == hi taps, lerp 0), channel counts that leave waves / groups ragged, several images, a bad
+    box_index, negative zeros in the image. Bit for bit against the CPU oracle AND against the gather kernel."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(77)
+    cases = [(2, 70, 64, 64, 40, 14, 14, 0.02, 0.9), (1, 256, 256, 256, 48, 14, 14, 0.02, 0.12),
+             (3, 37, 40, 48, 50, 16, 16, 0.02, 0.5), (1, 5, 8, 8, 20, 2, 2, 0.1, 0.9), (1, 9, 12, 20, 20, 4, 1, 0.05, 0.9),
+             (1, 130, 32, 32, 30, 8, 8, 0.02, 0.3), (2, 64, 128, 128, 30, 1, 4, 0.02, 0.4), (1, 19, 16, 36, 25, 14, 14, 0.3, 1.5),
+             (1, 1, 4, 4, 7, 2, 6, 0.1, 0.9), (1, 256, 32, 32, 64, 14, 14, 0.02, 0.12)]
+    for (b, c, h, w, n, ch, cw, lo, hi) in cases:
+        img = torch.randn(b, c, h, w, generator=g)
+        img[img.abs() < 0.05] = -0.0
+        boxes = _rand_boxes(g, n, lo, hi, spill=True)
+        boxes[0] = torch.tensor([0.0, 0.0, 1.0, 1.0])                       # the whole image
+        boxes[1] = torch.tensor([0.75, 0.9, 0.25, 0.1])                     # reversed
+        boxes[2] = torch.tensor([2.0 / (h - 1), 1.0 / (w - 1), (2.0 + ch - 1) / (h - 1), (1.0 + cw - 1) / (w - 1)]) \
+            if ch > 1 and cw > 1 else boxes[2]                              # samples exactly on pixels
+        boxes[3] = torch.tensor([-0.5, -0.5, -0.1, -0.1])                   # wholly outside
+        boxes[4] = torch.tensor([0.5, 0.5, 0.5, 0.5])                       # a single point
+        ind = torch.randint(0, b, (n,), generator=g, dtype=torch.int32)
+        want = oracle.crop_forward(img, boxes, ind, -1.25, ch, cw)
+        ind_bad = ind.clone()
+        ind_bad[5] = b + 3
+        monkeypatch.setenv("MRCNN_CROP_STAGED", "1")
+        got = ops.crop(img.to(dev), boxes.to(dev), ind.to(dev), -1.25, ch, cw)
+        got_bad = ops.crop(img.to(dev), boxes.to(dev), ind_bad.to(dev), -1.25, ch, cw)
+        monkeypatch.setenv("MRCNN_CROP_STAGED", "0")
+        gather = ops.crop(img.to(dev), boxes.to(dev), ind.to(dev), -1.25, ch, cw)
+        monkeypatch.delenv("MRCNN_CROP_STAGED")
+        assert _bits_equal(got.cpu(), want), (b, c, h, w, n, ch, cw)
+        assert _bits_equal(got.cpu(), gather.cpu()), (b, c, h, w, n, ch, cw)
+        assert bool((got_bad[5] == -1.25).all()) and _bits_equal(got_bad[6:].cpu(), want[6:])
+
+
 def test_crop_config2_microbench_shape(dev, oracle):
     """BASELINE config 2: 256 RoIs x 256 ch x 14x14 on P2 (256x256 map), SURVEY §8d inputs."""
     from maskrcnn_amd import ops
