@@ -40,8 +40,24 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measure
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 
 
+TRAFFIC_PROFILE = "r03_hbm_traffic.json"
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def kernel_source_sha16():
+    """sha256 over maskrcnn_amd/csrc/*.{hip,hpp} (sorted by name): ties a committed PMC profile to the kernels it profiled."""
+    import hashlib
+    d = os.path.join(ROOT, "maskrcnn_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def calibrate_heads_(sd, make_net, images, windows):
@@ -118,7 +134,7 @@ def conv_roofline(prof, args, H, W, modules):
     # HBM traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, summarised per kernel by
     # profiles/summarize_pmc.py into a file that records the mode it was taken in; anything else → null
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
     if os.path.exists(tpath):
         try:
             with open(tpath) as fh:
@@ -130,11 +146,13 @@ def conv_roofline(prof, args, H, W, modules):
                     and tj.get("fused_bottleneck") == bool(getattr(modules, "FUSED_BOTTLENECK", False))
                     and tj.get("rpn_fused_heads") == bool(getattr(modules, "RPN_FUSED_HEADS", False))
                     and tj.get("winograd4") == bool(getattr(modules, "WINOGRAD4", False))
-                    and tj.get("winograd4_trunk") == bool(getattr(modules, "WINOGRAD4_TRUNK", False)))
+                    and tj.get("winograd4_trunk") == bool(getattr(modules, "WINOGRAD4_TRUNK", False))
+                    # the byte counts are only this run's if the kernels are the ones that were profiled
+                    and tj.get("kernel_source_sha16") == kernel_source_sha16())
             k = tj.get("per_kernel", {}).get(kernel_of.get(dominant, dominant))
             if same and k and k.get("launches_per_step") == dom["launches_per_step"]:
                 traffic = k["hbm_bytes_per_step"]
-                traffic_src = "profiles/r02_hbm_traffic.json"
+                traffic_src = "profiles/" + TRAFFIC_PROFILE
         except (OSError, ValueError, KeyError):
             traffic = None
     return {"bound": "mfma", "kernel": kernel_of.get(dominant, dominant),
@@ -146,9 +164,10 @@ def conv_roofline(prof, args, H, W, modules):
             "avg_launch_us": dom["avg_launch_us"],
             "algorithmic_tflops": dom["algorithmic_tflops"],
             "algorithmic_speedup": round(dom["algorithmic_tflops"] / dom["executed_tflops"], 3),
-            "traffic": traffic, "traffic_source": traffic_src,
-            "traffic_note": "HBM bytes of this kernel's launches of one step (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, "
-                            "separate passes; null when the committed profile was taken in another mode)",
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_this_run": False,
+            "traffic_note": "fabric bytes of this kernel's launches of one step from the committed rocprofv3 passes (--pmc "
+                            "FETCH_SIZE x2 + WRITE_SIZE, separate passes of tools/profile_step.py): NOT measured in this run; "
+                            "null unless the profile's mode flags, launch count and csrc/ source hash equal this run's",
             "algorithmic_bytes": dom["algorithmic_bytes_per_step"],
             "conv_path": dict(whole, conv_gflop_per_image=round(sum(r[2] for r in prof) / steps / args.batch / 1e9, 1)),
             "by_kernel": by_tag}
@@ -157,17 +176,32 @@ def conv_roofline(prof, args, H, W, modules):
 def op_rooflines(dev, ops):
     """The two non-conv hot ops, HIP-event timed on the launch stream after the timed region:
     RoIAlign is HBM-bound (compulsory bytes = output + every touched map once + boxes), NMS latency-bound."""
-    def timeit(fn, iters=30, warm=5):
-        for _ in range(warm):
+    def timeit(fn, iters=20, reps=3):
+        """Device time per call, us: `iters` calls captured in a hipGraph and replayed (the Python + ctypes cost of a call,
+        ~20 us, would otherwise bound a 20-30 us kernel); best of `reps` replays, HIP events on the launch stream."""
+        for _ in range(3):
             fn()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
             fn()
-        e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters * 1e3  # us
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(iters):
+                fn()
+        graph.replay()
+        torch.cuda.synchronize()
+        best = 1e30
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / iters * 1e3)
+        del graph
+        return best
 
     out = []
     g = torch.Generator().manual_seed(1234)
@@ -180,9 +214,20 @@ def op_rooflines(dev, ops):
     algo = 256 * 256 * 14 * 14 * 4 + fm.numel() * 4 + 256 * 20
     us = timeit(lambda: ops.crop(fm, boxes, ind, 0.0, 14, 14))
     out.append({"op": "crop_forward_nchw (configs[1]: 256 RoIs x 256 ch x 14x14 on P2)", "bound": "hbm",
-                "us": round(us, 2), "algorithmic_bytes": algo, "achieved": round(algo / us / 1e3, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / us / 1e3 / HBM_PEAK_GBS, 4)})
+                "kernel": "crop_forward_nchw_staged", "us": round(us, 2), "algorithmic_bytes": algo,
+                "achieved": round(algo / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(algo / us / 1e3 / HBM_PEAK_GBS, 4),
+                "timing": "device time per call, 20 calls replayed from a hipGraph (includes the ~1.5 us kernel boundary)"})
     del fm
+    # the same call on the P3..P5 map sizes
+    for hl in (128, 64, 32):
+        fm = torch.randn(1, 256, hl, hl, generator=g).to(dev)
+        algo_l = 256 * 256 * 14 * 14 * 4 + fm.numel() * 4 + 256 * 20
+        us = timeit(lambda: ops.crop(fm, boxes, ind, 0.0, 14, 14))
+        out.append({"op": f"crop_forward_nchw (256 RoIs x 256 ch x 14x14 on a {hl}x{hl} map)", "bound": "hbm",
+                    "us": round(us, 2), "algorithmic_bytes": algo_l, "achieved": round(algo_l / us / 1e3, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo_l / us / 1e3 / HBM_PEAK_GBS, 4)})
+        del fm
     # the pipeline's classifier-head call: 8 images x 1000 RoIs x 7x7 over the four NHWC levels, one launch
     fms = [torch.randn(8, 1024 // s, 1024 // s, 256, generator=g).to(dev) for s in (4, 8, 16, 32)]
     c = torch.rand(8000, 2, generator=g)
@@ -229,6 +274,7 @@ def cpu_baseline(sd, cfg, n_images, seed):
             times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / max(1, len(times) - 1)
     return {"value": 1.0 / t, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "seconds_per_image": [round(x, 3) for x in times[1:]], "warmup_image_seconds": round(times[0], 3),
             "sample": f"{n_images} image(s) of the same workload, batch 1, oracle.predict "
                       f"(torch-CPU fp32 convs + C nms/crop), {t:.2f} s/image, host cpus={os.cpu_count()}"}
 
@@ -238,6 +284,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=3, help="timed repetitions of --steps steps; value = the median one")
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (configs[2]: 8)")
     ap.add_argument("--arch", default="resnet50")
     ap.add_argument("--size", type=int, default=1024, help="square image side (BASELINE metric: 1024)")
@@ -252,6 +299,8 @@ def main():
     ap.add_argument("--alt-precision", default="f16x3", choices=["none", "f32", "f16x3", "f16"],
                     help="also time this mode after the headline (reported under alt_precision)")
     ap.add_argument("--dump-conv", default=None, help="write per-launch conv (M,N,K,ms,TFLOP/s) JSON here")
+    ap.add_argument("--alt-config5", type=int, default=1,
+                    help="also time BASELINE configs[4]'s geometry (R101-FPN, 832x1344, fp16 MFMA path) on this GPU, N=1 only")
     args = ap.parse_args()
 
     from maskrcnn_amd import dist as mdist
@@ -305,18 +354,25 @@ def main():
 
     for _ in range(args.warmup):
         out = runner()
-    mdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = runner()
-    torch.cuda.synchronize()
-    mdist.barrier()
-    elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+    # Three timed repetitions of EXACTLY --steps steps, each bracketed by a barrier + synchronize on both sides and reduced
+    # with MAX over ranks; `value` is the MEDIAN repetition (run-to-run spread of one repetition on this pool: ~4 %), the
+    # fastest and slowest are reported beside it.
+    reps = []
+    for _ in range(max(1, args.reps)):
+        mdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = runner()
+        torch.cuda.synchronize()
+        mdist.barrier()
+        reps.append(mdist.max_over_ranks(time.perf_counter() - t0, dev))
+    elapsed = sorted(reps)[len(reps) // 2]
     (gathered, gcounts), det = out
     n_images = world * args.batch * args.steps
     value = n_images / elapsed
 
+    mean_valid = round(float(net_last_counts(net, images, windows)), 1)
     # ---- roofline pass: per-launch HIP events around every conv launch (same stream) ----------------
     roofline = None
     roofline_ops = None
@@ -364,6 +420,18 @@ def main():
             alt["conv_ms_per_step"] = round(ms / args.roofline_steps, 3)
         del net_alt
 
+    # ---- BASELINE configs[4] geometry on this GPU (ResNet-101-FPN, 832 x 1344 = 1333 x 800 padded to /64, plain-fp16 MFMA
+    # path with fp16 activations in HBM), after the headline and never part of `value` -------------------------------
+    alt_configs = None
+    if rank == 0 and world == 1 and args.alt_config5:
+        del net
+        torch.cuda.empty_cache()
+        try:
+            alt_configs = [config5_entry(dev, args, ops, modules, InferenceConfig, MaskRCNNInference)]
+        except Exception as e:
+            log(f"[bench] ERROR: alt_configs failed: {e!r}")
+            alt_configs = [{"config": "configs[4] geometry", "error": repr(e)}]
+
     cpu, cpu_failed = None, False
     if rank == 0 and world == 1 and args.cpu_images > 0:
         try:
@@ -379,6 +447,9 @@ def main():
             "metric": f"images/sec at {H}x{W}, {args.proposals} proposals/img (Mask R-CNN inference hot path)",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "timed_repetitions": {"count": len(reps), "steps_each": args.steps, "value_is": "median",
+                                  "images_per_s": [round(n_images / t, 2) for t in reps],
+                                  "min": round(n_images / max(reps), 2), "max": round(n_images / min(reps), 2)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "f16x3": "f16x3 split operands, f32 accumulate",
                       "f16": "f16 operands, f32 accumulate"}[args.precision],
@@ -396,15 +467,54 @@ def main():
                                     + ", F(2x2,3x3) elsewhere; fp32 arithmetic on the fp32 MFMA"
                                     if modules.WINOGRAD4 else "winograd F(2x2,3x3), fp32 arithmetic on the fp32 MFMA")
                                    if (args.precision == "f32" and modules.WINOGRAD) else "direct implicit GEMM"),
-                       "mean_valid_proposals": round(float(net_last_counts(net, images, windows)), 1),
+                       "mean_valid_proposals": mean_valid,
                        "mean_detections": round(float(det.counts.float().mean().item()), 1)},
             "roofline": roofline, "roofline_ops": roofline_ops, "cpu_baseline": cpu, "alt_precision": alt,
+            "alt_configs": alt_configs,
         }
         print(json.dumps(line), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     if cpu_failed:
         raise SystemExit(3)
+
+
+def config5_entry(dev, args, ops, modules, InferenceConfig, MaskRCNNInference):
+    """BASELINE configs[4] on ONE GPU: ResNet-101-FPN, 832 x 1344, batch 8, precision "f16" (fp16 operands and fp16
+    activations in HBM, fp32 accumulate; parity bar of this mode: 2e-2 of the activation range, tests/test_gpu_fullsize.py
+    ::test_config5_*). Same timing discipline as the headline (warm-up, --steps steps between synchronisations)."""
+    H, W, batch = 832, 1344, 8
+    cfg = InferenceConfig(image_height=H, image_width=W, backbone="resnet101", pre_nms_limit=args.proposals,
+                          proposal_count=args.proposals)
+    sd = modules.synthetic_state_dict("resnet101", seed=0, bn_seed=1)
+    mean = torch.tensor(cfg.mean_pixel)
+    g = torch.Generator().manual_seed(5)
+    images = (torch.randint(0, 256, (batch, H, W, 3), generator=g).float() - mean).permute(0, 3, 1, 2).contiguous().to(dev)
+    windows = torch.tensor([[0.0, 0.0, float(H), float(W)]] * batch, device=dev)
+    net = calibrate_heads_(sd, lambda s_: MaskRCNNInference(s_, cfg, dev, precision="f16"), images, windows)
+    for _ in range(args.warmup):
+        net.predict(images, windows, with_masks=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        det = net.predict(images, windows, with_masks=True)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ops.CONV_PROFILE = []
+    for _ in range(max(1, args.roofline_steps)):
+        net.predict(images, windows, with_masks=True)
+    torch.cuda.synchronize()
+    prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+    ms = sum(r[0].elapsed_time(r[1]) for r in prof) / max(1, args.roofline_steps)
+    fl = sum(r[2] for r in prof) / max(1, args.roofline_steps)
+    return {"config": "BASELINE configs[4] geometry on 1 GPU: ResNet-101-FPN, 832x1344 (1333x800 padded to /64), batch 8, "
+                      f"{args.proposals} proposals/img, fp16 MFMA path (fp16 operands + fp16 activations in HBM, fp32 accumulate)",
+            "precision": "f16", "value": round(batch * args.steps / el, 2), "unit": "images/s",
+            "ms_per_step": round(el / args.steps * 1e3, 3), "steps": args.steps,
+            "tolerance": "2e-2 of the activation range vs the fp32 oracle (tests/test_gpu_fullsize.py), not the 1e-4 bar",
+            "conv_ms_per_step": round(ms, 3), "conv_algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 1),
+            "conv_frac_of_f16_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4),
+            "mean_detections": round(float(det.counts.float().mean().item()), 1)}
 
 
 def net_last_counts(net, images, windows):

@@ -68,6 +68,18 @@ int mrcnn_nms_batched_f32(const float* dets, int32_t num_segments, int64_t n_max
                           int32_t* counts_out, void* workspace, size_t workspace_bytes,
                           mrcnn_stream_t stream);
 
+/* The rest of the reference's nms surface: ANY number of boxes, and float64 boxes (cpu/nms_cpu.cpp:73-79 dispatches over the
+ * floating types; nms.h:15 takes a float threshold either way). One segment; arithmetic in the boxes' own type; the same
+ * visiting order (descending score, ties by ascending index) and `>=` rule → the same keep set as the CPU path. No O(N^2)
+ * memory: radix sort (hipCUB), then one launch per 64-box chunk of the order (csrc/nms_general.hip).
+ *   dets        dtype 0: float32, 1: float64; box r = (y1,x1,y2,x2,score) at dets[r*row_stride + c*col_stride] (elements)
+ *   keep_out    int64[n]: first *count_out entries = kept input indices ascending, rest = -1;  count_out: int64[1] (device)
+ *   workspace   >= mrcnn_nms_general_workspace_bytes(n, dtype) bytes, 256-byte aligned.   1 <= n <= 2^31 - 65. */
+size_t mrcnn_nms_general_workspace_bytes(int64_t n, int32_t dtype);
+int mrcnn_nms_general(const void* dets, int32_t dtype, int64_t n, int64_t row_stride, int64_t col_stride, float threshold,
+                      int64_t* keep_out, int64_t* count_out, void* workspace, size_t workspace_bytes,
+                      mrcnn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * crop_and_resize ("RoIAlign") forward — replaces
  *   void crop_forward(image, boxes, box_index, extrapolation_value, crop_height, crop_width, crops)

@@ -23,6 +23,8 @@ _SIGS = {
     "mrcnn_nms_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i64]),
     "mrcnn_nms_batched_f32": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp,
                                                c_f32, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "mrcnn_nms_general_workspace_bytes": (ctypes.c_size_t, [c_i64, c_i32]),
+    "mrcnn_nms_general": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "mrcnn_crop_forward_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32,
                                                 c_f32, c_i32, c_i32, c_vp, c_vp]),
     "mrcnn_crop_backward_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,

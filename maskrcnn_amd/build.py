@@ -24,6 +24,7 @@ ARCH = "gfx950"
 SOURCES = {
     "common.hip": [],
     "nms.hip": ["-ffp-contract=off"],
+    "nms_general.hip": ["-ffp-contract=off"],
     "crop.hip": ["-ffp-contract=off"] + (["-DMRCNN_CROP_STAMPS"] if os.environ.get("MRCNN_CROP_STAMPS") else []),
     "conv.hip": [],
     "conv_f16.hip": [],

@@ -13,7 +13,12 @@ constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond every buffer descri
 // row offset + column offset where either may be OOB: a saturating add (one v_add_u32 ... clamp) keeps the sum out of range
 // — the or / compare / add / select it replaces are VALU instructions of an epilogue that runs beside the other workgroup's
 // MFMAs on the same SIMD, and VALU work does not co-execute with this MFMA.
-__device__ __forceinline__ unsigned oob_add(unsigned a, unsigned b) { return __builtin_elementwise_add_sat(a, b); }
+// The saturated sum 0xFFFFFFFF is clamped back to OOB (0xFFFFFFF0): 8-byte accesses add their size to the offset in the range
+// check, and offset + 8 must not wrap past 2^32 into the buffer (one v_min_u32; the 4-byte paths are unaffected either way).
+__device__ __forceinline__ unsigned oob_add(unsigned a, unsigned b) {
+    const unsigned s = __builtin_elementwise_add_sat(a, b);
+    return s < OOB ? s : OOB;
+}
 
 // Everything about the convolution that does not depend on how the weights are stored.
 struct ConvCommon {

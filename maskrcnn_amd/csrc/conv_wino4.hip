@@ -69,6 +69,7 @@ struct Wino4Params {
 };
 
 constexpr int W4_N = 64;                              // output channels per workgroup
+constexpr int W4_WALK_SHIFT = 4;                      // HEADS: runs of 16 consecutive M tiles start their N-tile walk together
 constexpr int W4_TSLOT = 6;                           // MFMA slot of the k loop that carries the input transform
 constexpr int W4_RW = 40;                             // channel pairs per raw row in LDS (34 used; == 0 mod 8)
 constexpr int W4_RPLANE = 18 * W4_RW + 8;             // pairs per (buffer, channel pair) plane, rotation included
@@ -240,17 +241,28 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
             seq = tile >> 3;
         }
         const int mt_lo = (xcd * p.tiles_m) >> 3, mt_hi = ((xcd + 1) * p.tiles_m) >> 3;
-        const int mt = mt_lo + seq / p.tiles_n;
+        int mt = mt_lo + seq / p.tiles_n;
         if (mt >= mt_hi) continue;  // uniform
+        if constexpr (HEADS) {
+            // XCD x walks its M range from an offset of x runs: the eight XCDs are then on different N-tile slices of U at any
+            // time (which M tile a workgroup takes when has no bearing on the numbers)
+            const int span = mt_hi - mt_lo;
+            int o = (mt - mt_lo) + (xcd << W4_WALK_SHIFT);
+            while (o >= span) o -= span;
+            mt = mt_lo + o;
+        }
         const int per_img = p.tyb * p.txb;
         const int b = mt / per_img, trem = mt - b * per_img;
         const int tby = trem / p.txb, tbx = trem - tby * p.txb;
         // HEADS: step `walk` of the M tile's N-tile walk. The walk starts at an N tile that depends on the M tile's place IN ITS
         // IMAGE (never on the batch: image i alone == slice i of a batch, bit for bit): with every workgroup on the same N
         // tile at the same time all 256 stream the same 36 KB of U per k tile and the loop runs 10 % slower (3 200 against
-        // 2 900 cycles per k tile, in-kernel stamps) than when the eight slices are in use side by side
+        // 2 900 cycles per k tile, in-kernel stamps) than when the eight slices are in use side by side. Round 3: runs of
+        // 2^W4_WALK_SHIFT consecutive M tiles — which an XCD works on at the same time — start at the SAME N tile, so an XCD's L2
+        // fetches a slice of U once for all of them instead of all eight slices per step (fabric reads of the heads launches:
+        // profiles/r03_hbm_traffic.json)
         const int walk = seq % p.tiles_n;
-        const int nt = HEADS ? (walk + trem) % p.tiles_n : walk;
+        const int nt = HEADS ? (walk + (trem >> W4_WALK_SHIFT)) % p.tiles_n : walk;
         const int n0 = nt * W4_N;
         const int TY0 = tby * 4, TX0 = tbx * 8;          // first tile position of the block
         const int iy0 = 4 * TY0 - 1, ix0 = 4 * TX0 - 1;  // first raw input pixel (may be -1: zero padding)
@@ -434,7 +446,10 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
             ktile(std::integral_constant<int, 0>{}, kt);
             ktile(std::integral_constant<int, 1>{}, kt + 1);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The MFMAs are inline asm: the compiler's hazard recogniser does not see them. Guarantee — rather than rely on the
+        // instructions that happen to sit in between — the wait states a 16-pass MFMA needs before its accumulator is read
+        // (18 for a VALU / vector-memory read of the result): 20 here, once per tile.
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 3" ::: "memory");
         STAMP();  // 3: k loop done
 
         // ---- epilogue: four rounds of 8 positions (accumulator registers 4g..4g+3 of both lane halves)
@@ -692,7 +707,10 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
     p.u_bytes = static_cast<unsigned>(4LL * 36 * cin * cout);
     p.y_bytes = static_cast<unsigned>(4LL * px * cout);
     p.w_head = nullptr; p.head_part = nullptr; p.head_bytes = 0;
+    p.debug = 0;
+#ifdef MRCNN_W4_ABLATIONS
     p.debug = getenv("MRCNN_W4_DEBUG") ? atoi(getenv("MRCNN_W4_DEBUG")) : 0;
+#endif
     const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
     MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd4: grid too large");
     void (*kern)(const Wino4Params) = activation ? conv3x3_wino4_f32<0, false, true> : conv3x3_wino4_f32<0, false, false>;
@@ -753,7 +771,10 @@ extern "C" int mrcnn_conv3x3_winograd4_heads_f32(const float* x_kblocked, int32_
     p.y_bytes = 0;
     p.w_head = w_head32; p.head_part = head_part;
     p.head_bytes = static_cast<unsigned>(4LL * rows * 32);
+    p.debug = 0;
+#ifdef MRCNN_W4_ABLATIONS
     p.debug = getenv("MRCNN_W4_DEBUG") ? atoi(getenv("MRCNN_W4_DEBUG")) : 0;
+#endif
     void (*kern)(const Wino4Params) = activation ? conv3x3_wino4_f32<0, true, true> : conv3x3_wino4_f32<0, true, false>;
 #ifdef MRCNN_W4_ABLATIONS
     switch (p.debug) {

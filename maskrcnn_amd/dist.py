@@ -58,19 +58,49 @@ def all_gather_detections(packed: torch.Tensor, counts: torch.Tensor, global_bat
         sizes = [b] * world
     else:
         sizes = [hi - lo for lo, hi in (shard_range(global_batch, r, world) for r in range(world))]
-    if sizes[rank] != b or counts.numel() != b or packed.size(2) != 6:
-        raise RuntimeError(f"all_gather_detections: rank {rank} holds {b} images (counts {counts.numel()}), "
-                           f"shard_range({global_batch}, {rank}, {world}) says {sizes[rank]}")
     b_max = max(sizes)
+    # A rank whose shard disagrees with shard_range must not raise BEFORE the collective — the other ranks would sit in
+    # all_gather_into_tensor until the backend's timeout. It sends a poisoned block instead (count row = -1, the shape
+    # every rank expects) and EVERY rank raises after the gather: the failure is loud on all of them.
+    ok = sizes[rank] == b and counts.numel() == b and packed.dim() == 3 and packed.size(2) == 6
     block = packed.new_zeros(b_max, d + 1, 6)
-    block[:b, :d] = packed
-    block[:b, d, 0] = counts.to(packed.dtype)
+    if ok:
+        block[:b, :d] = packed
+        block[:b, d, 0] = counts.to(packed.dtype)
+    else:
+        block[:, d, 0] = -1.0
     out = packed.new_empty(world * b_max, d + 1, 6)
     dist.all_gather_into_tensor(out, block)
-    if min(sizes) != b_max:  # strip the padding rows (host-side index list: no device synchronisation)
-        rows = [r * b_max + i for r in range(world) for i in range(sizes[r])]
-        out = out.index_select(0, torch.tensor(rows, dtype=torch.int64, device=out.device))
+    if not ok:
+        raise RuntimeError(f"all_gather_detections: rank {rank} holds {b} images (counts {counts.numel()}), "
+                           f"shard_range({global_batch}, {rank}, {world}) says {sizes[rank]}")
+    # The healthy ranks learn of it from the gathered count rows. Looking at them is a device-to-host read, so it is done on
+    # the FIRST step of every sharding layout (set-up-time validation: a layout that was right once stays right) and not in
+    # the steady state, which stays free of host synchronisation; the poisoned counts (-1) travel on to the caller anyway.
+    layout = (tuple(sizes), d, str(out.device))
+    if layout not in _VALIDATED:
+        neg = (out[:, d, 0] < 0).nonzero().flatten().tolist()
+        if neg:
+            bad = sorted({int(i) // b_max for i in neg})
+            raise RuntimeError(f"all_gather_detections: rank(s) {bad} hold a shard that disagrees with "
+                               f"shard_range({global_batch}, r, {world})")
+        _VALIDATED.add(layout)
+    if min(sizes) != b_max:  # strip the padding rows (index list cached per layout: no per-step host-to-device copy)
+        out = out.index_select(0, _strip_index(tuple(sizes), b_max, out.device))
     return out[:, :d].contiguous(), out[:, d, 0].to(torch.int32)
+
+
+_VALIDATED: set = set()
+_STRIP_CACHE: dict = {}
+
+
+def _strip_index(sizes: tuple, b_max: int, device) -> torch.Tensor:
+    key = (sizes, b_max, str(device))
+    idx = _STRIP_CACHE.get(key)
+    if idx is None:
+        rows = [r * b_max + i for r in range(len(sizes)) for i in range(sizes[r])]
+        idx = _STRIP_CACHE[key] = torch.tensor(rows, dtype=torch.int64, device=device)
+    return idx
 
 
 def _collectives_on() -> bool:

@@ -100,16 +100,42 @@ def nms_batched(dets: torch.Tensor, threshold: float, seg_counts: torch.Tensor |
     return keep, counts
 
 
+NMS_MAX_BOXES = int(lib.mrcnn_nms_max_boxes())   # per segment on the fp32 LDS / pair-mask paths (csrc/nms.hip)
+
+
+@_on_device
+def nms_general(dets: torch.Tensor, threshold: float):
+    """dets [N, >=5] float32 or float64, any strides, any N → (keep int64 [N] ascending input indices padded with -1, count
+    int64 [1]); arithmetic in dets' own type (cpu/nms_cpu.cpp:73-79). csrc/nms_general.hip; no host synchronisation."""
+    _need_gpu(dets)
+    if dets.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f'"nms" not implemented for {dets.dtype}')   # AT_DISPATCH_FLOATING_TYPES
+    assert dets.dim() == 2 and dets.size(1) >= 5
+    n = dets.size(0)
+    dt = 0 if dets.dtype == torch.float32 else 1
+    keep = torch.empty(n, dtype=torch.int64, device=dets.device)
+    count = torch.empty(1, dtype=torch.int64, device=dets.device)
+    nbytes = int(lib.mrcnn_nms_general_workspace_bytes(n, dt))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dets.device)
+    check(lib.mrcnn_nms_general(dets.data_ptr(), dt, n, dets.stride(0), dets.stride(1), float(threshold), keep.data_ptr(),
+                                count.data_ptr(), ws.data_ptr(), nbytes, _stream()))
+    return keep, count
+
+
 def _nms(dets: torch.Tensor, threshold: float) -> torch.Tensor:
-    """Reference call shape: [N,5] → int64 [K] ascending input indices on dets.device.
-    (The data-dependent output length costs one 4-byte D2H read; use nms_batched to stay async.)"""
+    """Reference call shape: [N,5] → int64 [K] ascending input indices on dets.device; float32 or float64 boxes, any N
+    (nms.h:15-30, cpu/nms_cpu.cpp:73-79). fp32 with N <= 16384 — everything model.py asks for — runs csrc/nms.hip, the
+    rest csrc/nms_general.hip. (The data-dependent output length costs one D2H read; use nms_batched to stay async.)"""
     _need_gpu(dets)
     if dets.numel() == 0:  # nms.h:20-21
         return torch.empty(0, dtype=torch.int64, device=dets.device)
     if dets.dim() != 2 or dets.size(1) < 5:
         raise RuntimeError("nms: dets must be [N, 5]")
-    keep, counts = nms_batched(dets.unsqueeze(0), threshold)
-    return keep[0, :int(counts.item())]
+    if dets.dtype == torch.float32 and dets.size(0) <= NMS_MAX_BOXES:
+        keep, counts = nms_batched(dets.unsqueeze(0), threshold)
+        return keep[0, :int(counts.item())]
+    keep, count = nms_general(dets, threshold)
+    return keep[:int(count.item())]
 
 
 _LIB.define("nms(Tensor dets, float threshold) -> Tensor")
@@ -226,7 +252,7 @@ def roi_align_pyramid(feature_maps, rois: torch.Tensor, pool: int, image_area: f
     return (out, levels) if return_levels else out
 
 
-__all__ = ["nms_batched", "crop", "roi_align_pyramid", "MaskrcnnHipError"]
+__all__ = ["nms_batched", "nms_general", "crop", "roi_align_pyramid", "MaskrcnnHipError"]
 
 
 # --------------------------------------------------------------------------------------------------

@@ -40,11 +40,7 @@ def test_nms_golden(dev):
     import maskrcnn
     z = load_golden("nms")
     for i, tag in _cases(z):
-        dets = torch.from_numpy(z[f"c{i}_dets"])
-        if dets.dtype == torch.float64:
-            with pytest.raises(RuntimeError):
-                maskrcnn.nms(dets.to(dev), float(z[f"c{i}_thr"]))
-            continue
+        dets = torch.from_numpy(z[f"c{i}_dets"])   # one case is float64: the reference dispatches over the floating types
         keep = maskrcnn.nms(dets.to(dev), float(z[f"c{i}_thr"]))
         assert keep.dtype == torch.int64 and keep.device.type == "cuda"
         assert np.array_equal(keep.cpu().numpy(), z[f"c{i}_keep"]), tag
@@ -69,9 +65,42 @@ def test_nms_random_vs_oracle(dev, oracle):
                 keep, cnt = ops.nms_batched(d.to(dev).unsqueeze(0), thr, use_workspace=ws)
                 assert torch.equal(keep[0, :int(cnt[0])].cpu(), want), (n, thr, ws)
     with pytest.raises(RuntimeError):
-        maskrcnn.nms(_rand_dets(g, 16385).to(dev), 0.5)  # beyond the workspace path: loud, not wrong
-    with pytest.raises(RuntimeError):
         ops.nms_batched(_rand_dets(g, 5000).to(dev).unsqueeze(0), 0.5, use_workspace=False)
+
+
+def test_nms_any_size_and_float64(dev, oracle):
+    """The rest of the reference's nms surface (nms.h:15-30, cpu/nms_cpu.cpp:73-79): more boxes than the fp32 pair-mask
+    path takes (16384), and float64 boxes at any size — csrc/nms_general.hip, bit-exact keep indices vs the CPU oracle (whose
+    f64 instantiation is pinned by the reference-generated float64 golden case)."""
+    import maskrcnn
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(70)
+    for n, thr in ((16385, 0.5), (20000, 0.7), (40000, 0.3)):
+        d = _rand_dets(g, n, extent=4096.0)
+        assert torch.equal(maskrcnn.nms(d.to(dev), thr).cpu(), oracle.nms(d, thr)), (n, thr)
+    for n, thr in ((1, 0.5), (63, 0.5), (64, 0.3), (65, 0.7), (150, 0.7), (1000, 0.5), (5000, 0.7), (17000, 0.5)):
+        d = _rand_dets(g, n).double()
+        d[:, :4] += torch.rand(n, 4, generator=g, dtype=torch.float64) * 1e-9   # bits a float cannot hold
+        want = oracle.nms(d, thr)
+        assert torch.equal(maskrcnn.nms(d.to(dev), thr).cpu(), want), (n, thr)
+        if n >= 1000:   # differs from what the same boxes rounded to float32 give? then the f64 arithmetic mattered
+            keep, cnt = ops.nms_general(d.to(dev), thr)
+            assert torch.equal(keep[:int(cnt)].cpu(), want) and bool((keep[int(cnt):] == -1).all())
+    # the general path on float32 boxes equals the pair-mask path (same order, same arithmetic)
+    d = _rand_dets(g, 3000)
+    keep, cnt = ops.nms_general(d.to(dev), 0.6)
+    assert torch.equal(keep[:int(cnt)].cpu(), oracle.nms(d, 0.6))
+    # ties, NaN / inf / signed-zero scores, a NaN coordinate, strided rows: the same order rules as the fp32 kernels
+    d = _rand_dets(g, 300).double()
+    d[:, 4] = torch.randint(0, 5, (300,), generator=g).double() / 4
+    d[7, 4], d[9, 4], d[11, 4], d[12, 4] = float("nan"), float("inf"), -0.0, 0.0
+    d[21, 0] = float("nan")
+    assert torch.equal(maskrcnn.nms(d.to(dev), 0.5).cpu(), oracle.nms(d, 0.5))
+    wide = torch.randn(200, 9, generator=g, dtype=torch.float64)
+    wide[:, 1:6] = _rand_dets(g, 200).double()
+    assert torch.equal(maskrcnn.nms(wide.to(dev)[:, 1:6], 0.6).cpu(), oracle.nms(wide[:, 1:6], 0.6))
+    with pytest.raises(RuntimeError):
+        maskrcnn.nms(_rand_dets(g, 10).half().to(dev), 0.5)
 
 
 def test_nms_ties_and_specials(dev, oracle):

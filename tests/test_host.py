@@ -127,10 +127,19 @@ def _gather_worker(rank, world, port, q, global_batch):
                                     global_batch=global_batch)
     except RuntimeError as e:
         bad = str(e)
+    # ONE rank with a wrong shard (a layout not seen before): that rank raises after the collective, and the healthy rank
+    # raises too, from the poisoned count rows — nobody is left waiting inside the collective
+    one_sided = None
+    extra = 1 if r == w - 1 else 0
+    try:
+        mdist.all_gather_detections(torch.zeros(b_local + extra, 49, 6), torch.zeros(b_local + extra, dtype=torch.int32),
+                                    global_batch=global_batch)
+    except RuntimeError as e:
+        one_sided = str(e)
     mdist.barrier()
     t = mdist.max_over_ranks(float(r + 1), "cpu")
     q.put((r, tuple(gp.shape), gp[:, 0, 0].tolist(), gp[:, 3, 5].tolist(), gc.tolist(), str(gc.dtype), t, len(calls),
-           bad is not None))
+           bad is not None and one_sided is not None))
     torch.distributed.destroy_process_group()
 
 

@@ -63,7 +63,9 @@ def main():
             "fused_bottleneck": bool(getattr(modules, "FUSED_BOTTLENECK", False)),
             "rpn_fused_heads": bool(getattr(modules, "RPN_FUSED_HEADS", False)),
             "winograd4": bool(getattr(modules, "WINOGRAD4", False)),
-            "winograd4_trunk": bool(getattr(modules, "WINOGRAD4_TRUNK", False))}
+            "winograd4_trunk": bool(getattr(modules, "WINOGRAD4_TRUNK", False)),
+            # bench.py reports these byte counts only for a run of the SAME kernel sources
+            "kernel_source_sha16": bench.kernel_source_sha16()}
     if args.meta:
         with open(args.meta, "w") as fh:
             json.dump(meta, fh)
