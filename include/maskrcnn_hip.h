@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 10
+#define MRCNN_ABI_VERSION 11
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -228,22 +228,6 @@ int mrcnn_maxpool_f32(const float* x, int32_t batch, int32_t height, int32_t wid
                       int32_t stride, int32_t pad_top, int32_t pad_left, int32_t pad_bottom, int32_t pad_right, float* y,
                       int32_t y_layout, mrcnn_stream_t stream);
 
-/* One RPN level in two launches — RPN.forward (model.py:609-649) without ever writing the 512-channel shared
- * activation to HBM: SamePad + conv_shared 3x3 (cin -> cout) + bias + ReLU, then BOTH 1x1 heads (conv_class 6 +
- * conv_bbox 12 = head_n 18 channels) applied to the tile while it is still on chip (transposed through LDS); each
- * 128-channel slice of the shared conv writes a partial [M][head_n] to `workspace`, and a small second kernel adds
- * the cout/128 partials in fixed order (deterministic) plus the head bias.
- *   x [batch][H][W][cin] NHWC;  w_shared fp32 [cout][3][3][cin];  b_shared [cout];
- *   w_head32 fp32 [32][cout]: rows 0..head_n-1 = the 1x1 head weights (class rows first), remaining rows zero;
- *   b_head [head_n];  y [batch][H][W][head_n] — the layout mrcnn_rpn_scores_deltas_f32 consumes.
- *   cin % 32 == 0, cout % 128 == 0, head_n <= 32; workspace >= mrcnn_rpn_level_workspace_bytes(...). */
-size_t mrcnn_rpn_level_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t cout,
-                                       int32_t head_n);
-int mrcnn_rpn_level_fused_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin,
-                              const float* w_shared, int32_t cout, const float* b_shared, const float* w_head32,
-                              const float* b_head, int32_t head_n, void* workspace, size_t workspace_bytes, float* y,
-                              mrcnn_stream_t stream);
-
 /* RPN glue, two launches.
  * mrcnn_rpn_scores_deltas_f32 — replaces the per-level permute/view/softmax/cat of RPN.forward + rpn_detect
  *   (model.py:627-641,1294-1304): heads[l] = fused head output of level l, NHWC [batch][H_l][W_l][18]
@@ -307,11 +291,12 @@ int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int32_t batch, 
  * mrcnn_conv3x3_winograd_f32 (model.py:154-157, :605,624).
  *   mrcnn_winograd4_weights_f32   w_ohwi [Cout][3][3][Cin] -> u = G g G^T in the kernel's order [Cin/4][36][2][Cout][2]
  *                                 (36 * Cout * Cin floats; evaluated in double); Cin % 4 == 0
- *   mrcnn_conv3x3_winograd4_supported   1 when H % 4 == 0, W % 4 == 0, Cin % 8 == 0, Cout % 64 == 0
+ *   mrcnn_conv3x3_winograd4_supported   1 when H % 4 == 0, W % 4 == 0, Cin % 8 == 0, Cout % 64 == 0 and the tensors stay
+ *                                 inside the kernel's 32-bit byte offsets (B*H*W*Cin, B*H*W*Cout < 2^30 elements)
  *   mrcnn_conv3x3_winograd4_f32   x k-blocked [Cin/8][B*H*W][8] -> relu?(conv * scale + shift) as NHWC and/or k-blocked
  *                                 [Cout/8][B*H*W][8] (either output pointer may be null, not both) */
 int mrcnn_winograd4_weights_f32(const float* w_ohwi, int32_t cout, int32_t cin, float* u, mrcnn_stream_t stream);
-int32_t mrcnn_conv3x3_winograd4_supported(int32_t height, int32_t width, int32_t cin, int32_t cout);
+int32_t mrcnn_conv3x3_winograd4_supported(int32_t batch, int32_t height, int32_t width, int32_t cin, int32_t cout);
 int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width, int32_t cin,
                                 const float* u, int32_t cout, const float* scale, const float* shift, int32_t activation,
                                 float* y_nhwc, float* y_kblocked, mrcnn_stream_t stream);

@@ -57,15 +57,12 @@ _SIGS = {
                                                                c_vp, c_i32, c_i32, c_vp, c_vp]),
     "mrcnn_maxpool_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                                 c_i32, c_i32, c_i32, c_vp, c_vp]),
-    "mrcnn_rpn_level_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32, c_i32]),
-    "mrcnn_rpn_level_fused_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp,
-                                                   c_i32, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "mrcnn_rpn_scores_deltas_f32": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), c_i32, c_vp,
                                                      c_vp, c_vp]),
     "mrcnn_rpn_scores_deltas_v2_f32": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                                         ctypes.POINTER(c_i32), c_vp, c_i32, c_vp, c_vp, c_vp]),
     "mrcnn_winograd4_weights_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
-    "mrcnn_conv3x3_winograd4_supported": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
+    "mrcnn_conv3x3_winograd4_supported": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "mrcnn_conv3x3_winograd4_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32,
                                                      c_vp, c_vp, c_vp]),
     "mrcnn_conv3x3_winograd4_heads_rows": (c_i64, [c_i32, c_i32, c_i32]),
@@ -110,6 +107,14 @@ _SIGS = {
                                              ctypes.POINTER(ctypes.c_double), c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "mrcnn_paste_masks_u8": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp,
                                               c_i32, c_i32, c_i32, c_vp, c_vp]),
+}
+
+
+# Entry points of MRCNN_ABLATIONS builds only (include/maskrcnn_hip_ablations.h): bound when the loaded library has them.
+_ABLATION_SIGS = {
+    "mrcnn_rpn_level_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "mrcnn_rpn_level_fused_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp,
+                                                   c_i32, c_vp, ctypes.c_size_t, c_vp, c_vp]),
 }
 
 
@@ -175,6 +180,10 @@ def _load() -> ctypes.CDLL:
         fn.restype, fn.argtypes = res, args
     # a stale .so with the same symbol names but older argument lists would be called with mismatched ctypes
     # arguments (memory corruption / GPU fault): MRCNN_ABI_VERSION is bumped on every signature change
+    for name, (res, args) in _ABLATION_SIGS.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype, fn.argtypes = res, args
     built, want = int(lib.mrcnn_abi_version()), header_abi_version()
     if built != want:
         raise ImportError(f"{LIB_PATH} was built for ABI version {built}, include/maskrcnn_hip.h declares {want}: "

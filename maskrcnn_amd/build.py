@@ -19,6 +19,9 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libmaskrcnn_hip.so")
 ARCH = "gfx950"
 
+# MRCNN_ABLATIONS=1: also build the kernels that lost their A/B measurements (four-wave F(2x2) Winograd kernel, linear-tile
+# heads variant, direct-kernel fused RPN level: include/maskrcnn_hip_ablations.h) and the F(4x4) kernel's timing variants
+ABL = ["-DMRCNN_ABLATIONS"] if os.environ.get("MRCNN_ABLATIONS") else []
 # per-source extra flags. nms/crop reproduce the reference's separately-rounded fp32 arithmetic:
 # never let the compiler contract a*b+c into an FMA there.
 SOURCES = {
@@ -26,10 +29,10 @@ SOURCES = {
     "nms.hip": ["-ffp-contract=off"],
     "nms_general.hip": ["-ffp-contract=off"],
     "crop.hip": ["-ffp-contract=off"] + (["-DMRCNN_CROP_STAMPS"] if os.environ.get("MRCNN_CROP_STAMPS") else []),
-    "conv.hip": [],
+    "conv.hip": ABL,
     "conv_f16.hip": [],
-    "conv_wino.hip": [],
-    "conv_wino4.hip": (["-DMRCNN_W4_ABLATIONS"] if os.environ.get("MRCNN_W4_ABLATIONS") else []),
+    "conv_wino.hip": ABL,
+    "conv_wino4.hip": (["-DMRCNN_W4_ABLATIONS"] if (os.environ.get("MRCNN_W4_ABLATIONS") or os.environ.get("MRCNN_ABLATIONS")) else []),
     "stem.hip": [],
     "bottleneck.hip": [],
     "misc.hip": ["-ffp-contract=off"],

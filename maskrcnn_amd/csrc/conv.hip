@@ -354,6 +354,7 @@ int launch_conv(ConvParams p, int mode, hipStream_t stream) {  // mode: 0 aligne
         return MRCNN_OK;
     };
     int rc;
+#ifdef MRCNN_ABLATIONS
     if constexpr (BM == 128 && BN == 128 && WM == 2 && WN == 2 && BK == 32) {
         if (res == 5) {
             if (generic) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: fused heads need Cin %% 32 == 0");
@@ -361,7 +362,10 @@ int launch_conv(ConvParams p, int mode, hipStream_t stream) {  // mode: 0 aligne
             return mrcnn::check_launch("conv_igemm_f32<heads>");
         }
     }
-    if (res == 5) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: fused heads need the 128x128 tile");
+#else
+    (void)generic;
+#endif
+    if (res == 5) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: the fused-heads epilogue exists in MRCNN_ABLATIONS builds only");
     auto by_res = [&](auto mode_tag) -> int {
         constexpr int MD = decltype(mode_tag)::value;
         return res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, MD, 0>)
@@ -453,6 +457,7 @@ extern "C" int mrcnn_deconv2x2_bias_act_nhwc_f32(const float* x, int32_t batch, 
                         activation, 1, y, stream);
 }
 
+#ifdef MRCNN_ABLATIONS   // the direct-kernel fused RPN level (round 1; the default path fuses the heads into the Winograd kernels)
 namespace {
 // y[m][c] = bias[c] + sum over N tiles (fixed order: deterministic) of partial[t][m][c]
 __global__ __launch_bounds__(256) void heads_reduce(const float* __restrict__ partial, const float* __restrict__ bias,
@@ -511,3 +516,4 @@ extern "C" int mrcnn_rpn_level_fused_f32(const float* x, int32_t batch, int32_t 
                        static_cast<const float*>(workspace), b_head, MC, head_n, tiles_n, y);
     return mrcnn::check_launch("heads_reduce");
 }
+#endif  // MRCNN_ABLATIONS

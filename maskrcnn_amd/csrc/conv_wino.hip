@@ -76,6 +76,7 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
     return r;
 }
 
+#ifdef MRCNN_ABLATIONS   // the four-wave kernel of round 1 (one wave per SIMD): an ablation build only (MRCNN_WINO_WAVES=4)
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Vs = smem;                    // [2 buffers][16 components][2 quads][WT][4]
@@ -327,6 +328,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32(const WinoParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+#endif  // MRCNN_ABLATIONS
+
 // Eight-wave variant: the same workgroup tile (64 positions x 64 channels, 128 KB of LDS) and k-blocked operands, but
 // 512 threads — wave w owns TWO components (2w, 2w+1) for the whole tile: 128 accumulator registers, so TWO waves per
 // SIMD. With one wave per SIMD every LDS / VMEM / scalar instruction and every wait sits on the MFMA critical path
@@ -1140,8 +1143,8 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
     p.y_bytes = static_cast<unsigned>(4LL * px * cout);
     const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
     MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd: grid too large");
-    for (const void* f : {reinterpret_cast<const void*>(conv3x3_wino_f32), reinterpret_cast<const void*>(conv3x3_wino8_f32<false>)})
-        if (int rc = mrcnn::ensure_dynamic_lds(f, WINO_LDS, "conv3x3_winograd")) return rc;
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wino8_f32<false>), WINO_LDS, "conv3x3_winograd"))
+        return rc;
     // spatial-tile kernel (8 x 8 position blocks of one image) for maps of at least 8 x 8 positions — the default;
     // MRCNN_WINO_SPATIAL=0 (or mrcnn_winograd_set_spatial(0)) keeps the linear-tile kernel everywhere. Same results bit for bit.
     if (g_spatial < 0) g_spatial = (getenv("MRCNN_WINO_SPATIAL") && atoi(getenv("MRCNN_WINO_SPATIAL")) == 0) ? 0 : 1;
@@ -1162,10 +1165,16 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
         hipLaunchKernelGGL(conv3x3_wino8s_f32<false>, dim3(static_cast<unsigned>(launch)), dim3(512), WINOS_LDS, st, q);
         return mrcnn::check_launch("conv3x3_wino8s_f32");
     }
+#ifdef MRCNN_ABLATIONS
     static const bool four_waves = getenv("MRCNN_WINO_WAVES") && atoi(getenv("MRCNN_WINO_WAVES")) == 4;
-    if (four_waves)
+    if (four_waves) {
+        if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wino_f32), WINO_LDS, "conv3x3_winograd"))
+            return rc;
         hipLaunchKernelGGL(conv3x3_wino_f32, dim3(static_cast<unsigned>(grid)), dim3(256), WINO_LDS, st, p);
-    else {
+        return mrcnn::check_launch("conv3x3_wino_f32");
+    }
+#endif
+    {
         const int cus = mrcnn::device_cu_count();
         if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd: cannot query the device");
         const int num_cu = cus >= 8 ? (cus / 8) * 8 : 8;
@@ -1200,8 +1209,13 @@ extern "C" int mrcnn_conv3x3_winograd_heads_f32(const float* x_kblocked, int32_t
     MRCNN_REQUIRE(cin >= 8 && cin % 8 == 0 && cout >= WN && cout % WN == 0,
                   "conv3x3_winograd_heads: Cin=%d (%% 8 == 0) Cout=%d (%% 64 == 0) required", cin, cout);
     MRCNN_REQUIRE(activation == 0 || activation == 1, "conv3x3_winograd_heads: activation must be 0 or 1");
+#ifdef MRCNN_ABLATIONS
     MRCNN_REQUIRE(tile_mode == 1 || (tile_mode == 2 && height / 2 >= 8 && width / 2 >= 8),
                   "conv3x3_winograd_heads: tile_mode must be 1, or 2 on maps of at least 8 x 8 tile positions");
+#else   // the linear-tile heads variant (tile_mode 1) exists in MRCNN_ABLATIONS builds only: same numbers, slower
+    MRCNN_REQUIRE(tile_mode == 2 && height / 2 >= 8 && width / 2 >= 8,
+                  "conv3x3_winograd_heads: tile_mode must be 2 (8 x 8 position blocks), on maps of at least 8 x 8 tile positions");
+#endif
     const long long px = 1LL * batch * height * width;
     const long long rows = mrcnn_conv3x3_winograd_heads_rows(batch, height, width, tile_mode);
     MRCNN_REQUIRE(px * cin < (1LL << 30) && 16LL * cin * cout < (1LL << 30) && 2 * rows * 32 < (1LL << 30),
@@ -1220,21 +1234,26 @@ extern "C" int mrcnn_conv3x3_winograd_heads_f32(const float* x_kblocked, int32_t
     p.yk_plane = 0; p.y_bytes = 0;
     p.w_head = w_head32; p.head_part = head_part;
     p.head_bytes = static_cast<unsigned>(4LL * 2 * rows * 32);
-    const void* kern = tile_mode == 2 ? reinterpret_cast<const void*>(conv3x3_wino8s_f32<true>)
-                                      : reinterpret_cast<const void*>(conv3x3_wino8_f32<true>);
+    const void* kern = reinterpret_cast<const void*>(conv3x3_wino8s_f32<true>);
+#ifdef MRCNN_ABLATIONS
+    if (tile_mode != 2) kern = reinterpret_cast<const void*>(conv3x3_wino8_f32<true>);
+#endif
     if (int rc = mrcnn::ensure_dynamic_lds(kern, WINO_HEADS_LDS, "conv3x3_winograd_heads")) return rc;
     const int cus = mrcnn::device_cu_count();
     if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd_heads: cannot query the device");
     const int num_cu = cus >= 8 ? (cus / 8) * 8 : 8;
     const long long units = 8LL * ((p.tiles_m + 7) / 8);  // M-tile units; a workgroup walks the N tiles of its units
     const long long launch = units < num_cu ? units : num_cu;
-    if (tile_mode == 2)
-        hipLaunchKernelGGL(conv3x3_wino8s_f32<true>, dim3(static_cast<unsigned>(launch)), dim3(512), WINO_HEADS_LDS,
-                           mrcnn::as_stream(stream), p);
-    else
+#ifdef MRCNN_ABLATIONS
+    if (tile_mode != 2) {
         hipLaunchKernelGGL(conv3x3_wino8_f32<true>, dim3(static_cast<unsigned>(launch)), dim3(512), WINO_HEADS_LDS,
                            mrcnn::as_stream(stream), static_cast<const WinoParams&>(p));
-    return mrcnn::check_launch("conv3x3_wino8_f32<heads>");
+        return mrcnn::check_launch("conv3x3_wino8_f32<heads>");
+    }
+#endif
+    hipLaunchKernelGGL(conv3x3_wino8s_f32<true>, dim3(static_cast<unsigned>(launch)), dim3(512), WINO_HEADS_LDS,
+                       mrcnn::as_stream(stream), p);
+    return mrcnn::check_launch("conv3x3_wino8s_f32<heads>");
 }
 
 extern "C" int mrcnn_conv3x3_winograd_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,

@@ -676,9 +676,15 @@ extern "C" int mrcnn_winograd4_weights_f32(const float* w_ohwi, int32_t cout, in
     return mrcnn::check_launch("wino4_weights_kernel");
 }
 
-extern "C" int32_t mrcnn_conv3x3_winograd4_supported(int32_t height, int32_t width, int32_t cin, int32_t cout) {
-    return height >= 4 && width >= 4 && height % 4 == 0 && width % 4 == 0 && cin >= 8 && cin % 8 == 0 && cout >= W4_N &&
-           cout % W4_N == 0;
+// shapes the kernel takes, the 32-bit byte-offset limits included (B*H*W*Cin, B*H*W*Cout < 2^30 elements): a caller that
+// asks first can fall back to the F(2x2) or the direct kernel instead of being refused by the launch
+extern "C" int32_t mrcnn_conv3x3_winograd4_supported(int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                                     int32_t cout) {
+    if (!(batch >= 1 && height >= 4 && width >= 4 && height % 4 == 0 && width % 4 == 0 && cin >= 8 && cin % 8 == 0 &&
+          cout >= W4_N && cout % W4_N == 0))
+        return 0;
+    const long long px = 1LL * batch * height * width;
+    return px * cin < (1LL << 30) && px * cout < (1LL << 30) && 36LL * cin * cout < (1LL << 30);
 }
 
 extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width,
@@ -686,9 +692,9 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
                                            const float* shift, int32_t activation, float* y_nhwc, float* y_kblocked,
                                            mrcnn_stream_t stream) {
     MRCNN_REQUIRE(x_kblocked && u && (y_nhwc || y_kblocked), "conv3x3_winograd4: null pointer");
-    MRCNN_REQUIRE(batch >= 1 && mrcnn_conv3x3_winograd4_supported(height, width, cin, cout),
-                  "conv3x3_winograd4: B=%d H=%d W=%d (%% 4 == 0) Cin=%d (%% 8 == 0) Cout=%d (%% 64 == 0) required", batch,
-                  height, width, cin, cout);
+    MRCNN_REQUIRE(batch >= 1 && mrcnn_conv3x3_winograd4_supported(batch, height, width, cin, cout),
+                  "conv3x3_winograd4: B=%d H=%d W=%d (%% 4 == 0) Cin=%d (%% 8 == 0) Cout=%d (%% 64 == 0), B*H*W*C < 2^30 required",
+                  batch, height, width, cin, cout);
     MRCNN_REQUIRE(activation == 0 || activation == 1, "conv3x3_winograd4: activation must be 0 or 1");
     const long long px = 1LL * batch * height * width;
     MRCNN_REQUIRE(px * cin < (1LL << 30) && px * cout < (1LL << 30) && 36LL * cin * cout < (1LL << 30),
@@ -748,9 +754,9 @@ extern "C" int mrcnn_conv3x3_winograd4_heads_f32(const float* x_kblocked, int32_
                                                  const float* shift, int32_t activation, const float* w_head32,
                                                  float* head_part, mrcnn_stream_t stream) {
     MRCNN_REQUIRE(x_kblocked && u && w_head32 && head_part, "conv3x3_winograd4_heads: null pointer");
-    MRCNN_REQUIRE(batch >= 1 && mrcnn_conv3x3_winograd4_supported(height, width, cin, cout),
-                  "conv3x3_winograd4_heads: B=%d H=%d W=%d (%% 4 == 0) Cin=%d (%% 8 == 0) Cout=%d (%% 64 == 0) required",
-                  batch, height, width, cin, cout);
+    MRCNN_REQUIRE(batch >= 1 && mrcnn_conv3x3_winograd4_supported(batch, height, width, cin, cout),
+                  "conv3x3_winograd4_heads: B=%d H=%d W=%d (%% 4 == 0) Cin=%d (%% 8 == 0) Cout=%d (%% 64 == 0), B*H*W*C < 2^30 "
+                  "required", batch, height, width, cin, cout);
     MRCNN_REQUIRE(activation == 0 || activation == 1, "conv3x3_winograd4_heads: activation must be 0 or 1");
     const long long px = 1LL * batch * height * width;
     const long long rows = mrcnn_conv3x3_winograd4_heads_rows(batch, height, width);

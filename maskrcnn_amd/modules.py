@@ -230,10 +230,12 @@ class ConvWeight:
         return (self.u is not None and stride == 1 and tuple(pad) == (1, 1, 1, 1) and residual is None
                 and relu in (False, True, 0, 1) and h % 2 == 0 and w % 2 == 0)
 
-    def takes_winograd4(self, h, w, stride=1, pad=(1, 1, 1, 1), residual=None, relu=False):
-        """Would conv() run the F(4x4) kernel for a K-BLOCKED [., h, w, .] input with these arguments?"""
+    def takes_winograd4(self, h, w, stride=1, pad=(1, 1, 1, 1), residual=None, relu=False, batch=1):
+        """Would conv() run the F(4x4) kernel for a K-BLOCKED [., batch, h, w, .] input with these arguments? (`batch` only
+        enters through the kernel's 32-bit offset limit — past it the layer falls back to F(2x2) —, never through the
+        tile-count rule: image i alone == slice i of a batch.)"""
         return (self.u4 is not None and self.takes_winograd(h, w, stride, pad, residual, relu)
-                and ops.conv3x3_winograd4_supported(h, w, self.shape[3], self.shape[0])
+                and ops.conv3x3_winograd4_supported(h, w, self.shape[3], self.shape[0], batch)
                 and winograd4_tiles_per_image(h, w) >= WINOGRAD4_MIN_TILES)
 
     def conv(self, x, scale, shift, stride=1, pad=(0, 0, 0, 0), relu=False, residual=None, res_div=1,
@@ -242,7 +244,7 @@ class ConvWeight:
         Winograd conv reads. x may itself be k-blocked (5-d) when this conv takes the Winograd kernel."""
         if self.precision == "f32":
             hh, ww = (x.size(2), x.size(3)) if x.dim() == 5 else (x.size(1), x.size(2))
-            if x.dim() == 5 and self.takes_winograd4(hh, ww, stride, pad, residual, relu):
+            if x.dim() == 5 and self.takes_winograd4(hh, ww, stride, pad, residual, relu, x.size(1)):
                 return ops.conv3x3_winograd4(x, self.u4, scale, shift, bool(relu), algo_cin, out)
             if self.takes_winograd(hh, ww, stride, pad, residual, relu):
                 return ops.conv3x3_winograd(x, self.u, scale, shift, bool(relu), algo_cin, out)
@@ -437,7 +439,8 @@ class FusedRPN:
         w = torch.cat([sd[prefix + "conv_class.weight"], sd[prefix + "conv_bbox.weight"]], 0)
         self.b_head = torch.cat([sd[prefix + "conv_class.bias"], sd[prefix + "conv_bbox.bias"]]).float() \
             .contiguous().to(device)
-        self.fused_level = precision == "f32" and not WINOGRAD
+        # MRCNN_WINOGRAD=0 in an MRCNN_ABLATIONS build: the direct-kernel fused level; otherwise separate launches
+        self.fused_level = precision == "f32" and not WINOGRAD and ops.HAVE_ABLATIONS
         if self.fused_level:
             # fused level kernel: the 512-channel shared activation never leaves the chip (ops.rpn_level_fused)
             self.w_shared = pack_weight(sd[prefix + "conv_shared.weight"], device)
@@ -463,13 +466,14 @@ class FusedRPN:
             b, h, w = p.size(0), p.size(1), p.size(2)
             sw = self.shared.w
             if (RPN_FUSED_HEADS and getattr(self, "w_head32", None) is not None
-                    and sw.takes_winograd4(h, w, 1, (1, 1, 1, 1), None, True)
+                    and sw.takes_winograd4(h, w, 1, (1, 1, 1, 1), None, True, b)
                     and winograd4_tiles_per_image(h, w) >= WINOGRAD4_HEADS_MIN_TILES):
                 return ops.conv3x3_winograd4_heads(p_kblocked, sw.u4, self.shared.scale, self.shared.shift,
                                                    self.w_head32, True, self.shared.algo_cin)
             if (RPN_FUSED_HEADS and getattr(self, "w_head32", None) is not None
-                    and not sw.takes_winograd4(h, w, 1, (1, 1, 1, 1), None, True)
-                    and -(-((h // 2) * (w // 2)) // 64) >= RPN_HEADS_MIN_TILES and self.shared.w.shape[0] % 64 == 0):
+                    and not sw.takes_winograd4(h, w, 1, (1, 1, 1, 1), None, True, b)
+                    and -(-((h // 2) * (w // 2)) // 64) >= RPN_HEADS_MIN_TILES and self.shared.w.shape[0] % 64 == 0
+                    and (min(h, w) >= 16 or ops.HAVE_ABLATIONS)):
                 return ops.conv3x3_winograd_heads(p_kblocked, self.shared.w.u, self.shared.scale, self.shared.shift,
                                                   self.w_head32, True, self.shared.algo_cin)
             p = p_kblocked

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes
 import functools
+import os
 
 import torch
 
@@ -487,14 +488,33 @@ def bottleneck_fused(x, w1, s1, t1, u2, s2, t2, w3, s3, t3) -> torch.Tensor:
     return y
 
 
+# torch.ops.maskrcnn.bottleneck_forward sends eligible blocks to the whole-block kernel (whose conv2 is Winograd F(2x2)) only
+# when BOTH switches say so — MRCNN_FUSED_BOTTLENECK=1 and Winograd not disabled (MRCNN_WINOGRAD=0 promises "every conv on the
+# direct kernel, bitwise an fmaf chain"); otherwise the op is the exact three/four-launch composite. modules.py keeps this in
+# step with its own flags.
+BOTTLENECK_OP_FUSED = (os.environ.get("MRCNN_FUSED_BOTTLENECK", "0") == "1" and os.environ.get("MRCNN_WINOGRAD", "1") != "0")
+_U2_CACHE: dict = {}   # conv2 weight (storage, version) -> its Winograd transform: not recomputed per call
+
+
+def _cached_winograd_weights(w2: torch.Tensor) -> torch.Tensor:
+    key = (w2.data_ptr(), w2._version, tuple(w2.shape), str(w2.device))
+    u = _U2_CACHE.get(key)
+    if u is None:
+        if len(_U2_CACHE) > 256:
+            _U2_CACHE.clear()
+        u = _U2_CACHE[key] = winograd_weights(w2)
+    return u
+
+
 def bottleneck_forward(x, w1, s1, t1, w2, s2, t2, w3, s3, t3, wd, sd, td, stride: int):
     """Bottleneck.forward (model.py:190-211) on NHWC: conv1 1x1 (stride) + BN + ReLU, SamePad(3,1) + conv2 3x3 + BN +
-    ReLU, conv3 1x1 + BN, + residual (identity or 1x1-stride downsample + BN), ReLU.
-    Stride-1 identity blocks with planes = 64 (the shapes of bottleneck_fused_supported) run as ONE launch of the
-    whole-block kernel; every other block as three or four fused conv launches. BN/bias are (scale, shift) epilogues."""
-    if (wd is None and int(stride) == 1 and x.is_cuda and x.dim() == 4 and tuple(w2.shape[1:3]) == (3, 3)
+    ReLU, conv3 1x1 + BN, + residual (identity or 1x1-stride downsample + BN), ReLU. BN/bias are (scale, shift) epilogues.
+    Three or four fused conv launches on the exact direct kernel; with BOTTLENECK_OP_FUSED (above) the stride-1 identity
+    blocks with planes = 64 (bottleneck_fused_supported) run as ONE launch of the whole-block kernel instead."""
+    if (BOTTLENECK_OP_FUSED and wd is None and int(stride) == 1 and x.is_cuda and x.dim() == 4
+            and tuple(w2.shape[1:3]) == (3, 3)
             and bottleneck_fused_supported(x.size(1), x.size(2), x.size(3), w1.size(0)) and w3.size(0) == x.size(3)):
-        return bottleneck_fused(x, w1, s1, t1, winograd_weights(w2), s2, t2, w3, s3, t3)
+        return bottleneck_fused(x, w1, s1, t1, _cached_winograd_weights(w2), s2, t2, w3, s3, t3)
     h = conv_bn_act(x, w1, s1, t1, stride=stride, relu=True)
     pad = same_pad(h.size(1), h.size(2), 3, 1)
     h = conv_bn_act(h, w2, s2, t2, stride=1, pad=pad, relu=True)
@@ -550,6 +570,9 @@ def conv3x3_winograd_heads(x_kblocked: torch.Tensor, u: torch.Tensor, scale, shi
     cin, cout = g * 8, u.size(1)
     assert u.is_contiguous() and u.size(2) == cin and w_head32.is_contiguous() and tuple(w_head32.shape) == (32, cout)
     mode = int(lib.mrcnn_conv3x3_winograd_heads_tile_mode(h, w)) if tile_mode is None else int(tile_mode)
+    if mode != 2 and not HAVE_ABLATIONS:
+        raise RuntimeError("conv3x3_winograd_heads: maps of at least 16 x 16 pixels (8 x 8 tile positions) and the spatial-tile "
+                           "kernel are required; the linear-tile heads variant is an MRCNN_ABLATIONS build")
     rows = int(lib.mrcnn_conv3x3_winograd_heads_rows(b, h, w, mode))
     part = torch.empty(2, rows, 32, dtype=torch.float32, device=x_kblocked.device)
     prof = CONV_PROFILE
@@ -737,10 +760,16 @@ def deconv2x2(x: torch.Tensor, w, bias4: torch.Tensor, activation: int = 0, prod
 __all__ += ["deconv2x2"]
 
 
+HAVE_ABLATIONS = hasattr(lib, "mrcnn_rpn_level_fused_f32")   # an MRCNN_ABLATIONS build of the library is loaded
+
+
 @_on_device
 def rpn_level_fused(x, w_shared, b_shared, w_head32, b_head, head_n: int = 18) -> torch.Tensor:
     """RPN.forward on one level (model.py:609-649) with the shared 512-channel activation kept on chip:
-    x [B,H,W,Cin] NHWC → [B,H,W,head_n] (class logits then box deltas). fp32 MFMA path."""
+    x [B,H,W,Cin] NHWC → [B,H,W,head_n] (class logits then box deltas). fp32 MFMA path, direct kernel. MRCNN_ABLATIONS
+    builds only (the default library fuses the heads into the Winograd kernels instead)."""
+    if not HAVE_ABLATIONS:
+        raise RuntimeError("rpn_level_fused: built only with MRCNN_ABLATIONS=1 python maskrcnn_amd/build.py")
     _need_gpu(x, w_shared, b_shared, w_head32, b_head)
     assert x.is_contiguous() and w_shared.is_contiguous() and w_head32.is_contiguous()
     b, h, wd, cin = x.shape
@@ -930,8 +959,9 @@ def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, scale, shift, relu: bool 
 # --------------------------------------------------------------------------------------------------
 # Winograd F(4x4,3x3) 3x3 stride-1 SAME conv (csrc/conv_wino4.hip): maps with H % 4 == W % 4 == 0, Cout % 64 == 0
 # --------------------------------------------------------------------------------------------------
-def conv3x3_winograd4_supported(h: int, w: int, cin: int, cout: int) -> bool:
-    return bool(lib.mrcnn_conv3x3_winograd4_supported(int(h), int(w), int(cin), int(cout)))
+def conv3x3_winograd4_supported(h: int, w: int, cin: int, cout: int, batch: int = 1) -> bool:
+    """Shapes the F(4x4) kernel takes — its 32-bit offset limits (batch * h * w * channels < 2^30) included."""
+    return bool(lib.mrcnn_conv3x3_winograd4_supported(int(batch), int(h), int(w), int(cin), int(cout)))
 
 
 @_on_device
@@ -956,7 +986,7 @@ def conv3x3_winograd4(x_kblocked: torch.Tensor, u4: torch.Tensor, scale, shift, 
     assert u4.is_contiguous() and out in ("nhwc", "kblocked", "both")
     g, b, h, w, _ = x_kblocked.shape
     cin, cout = g * 8, u4.size(3)
-    assert u4.size(0) * 4 == cin and conv3x3_winograd4_supported(h, w, cin, cout), (h, w, cin, cout)
+    assert u4.size(0) * 4 == cin and conv3x3_winograd4_supported(h, w, cin, cout, b), (b, h, w, cin, cout)
     y = torch.empty(b, h, w, cout, dtype=torch.float32, device=x_kblocked.device) if out != "kblocked" else None
     yk = torch.empty(cout // 8, b, h, w, 8, dtype=torch.float32, device=x_kblocked.device) if out != "nhwc" else None
     prof = CONV_PROFILE
@@ -983,7 +1013,7 @@ def conv3x3_winograd4_heads(x_kblocked: torch.Tensor, u4: torch.Tensor, scale, s
     assert x_kblocked.dim() == 5 and x_kblocked.is_contiguous() and x_kblocked.dtype == torch.float32
     g, b, h, w, _ = x_kblocked.shape
     cin, cout = g * 8, u4.size(3)
-    assert u4.is_contiguous() and u4.size(0) * 4 == cin and conv3x3_winograd4_supported(h, w, cin, cout)
+    assert u4.is_contiguous() and u4.size(0) * 4 == cin and conv3x3_winograd4_supported(h, w, cin, cout, b)
     assert w_head32.is_contiguous() and tuple(w_head32.shape) == (32, cout)
     rows = int(lib.mrcnn_conv3x3_winograd4_heads_rows(b, h, w))
     part = torch.empty(rows, 32, dtype=torch.float32, device=x_kblocked.device)

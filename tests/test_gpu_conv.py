@@ -214,8 +214,14 @@ def test_bottleneck_module_dropin(dev):
 
 
 def test_rpn_level_fused_vs_torch_cpu(dev):
-    """3x3 shared conv + ReLU + both 1x1 heads in one pass (shared activation kept on chip) vs torch CPU."""
+    """3x3 shared conv + ReLU + both 1x1 heads in one pass (shared activation kept on chip) vs torch CPU. The direct-kernel
+    form of it is an MRCNN_ABLATIONS build (include/maskrcnn_hip_ablations.h); the default library refuses loudly."""
     from maskrcnn_amd import ops
+    if not ops.HAVE_ABLATIONS:
+        with pytest.raises(RuntimeError, match="MRCNN_ABLATIONS"):
+            ops.rpn_level_fused(torch.zeros(1, 4, 4, 256, device=dev), torch.zeros(512, 3, 3, 256, device=dev),
+                                torch.zeros(512, device=dev), torch.zeros(32, 512, device=dev), torch.zeros(18, device=dev))
+        return
     g = torch.Generator().manual_seed(12)
     for (b, h, w) in [(2, 16, 12), (1, 5, 7), (1, 32, 32)]:
         x = torch.randn(b, 256, h, w, generator=g)
@@ -483,10 +489,22 @@ def test_bottleneck_fused_whole_block(dev, shape):
         modules.FUSED_BOTTLENECK = saved
     err4 = (got4.permute(0, 3, 1, 2).cpu() - want).abs().max().item()
     assert err4 <= TOL, f"F(4x4): max abs err {err4:.3e} (|ref|max {want.abs().max().item():.2f})"
-    # the registered op with the reference-shaped argument list routes to the same launch
-    y = torch.ops.maskrcnn.bottleneck_forward(xd, c1.w.w, c1.scale, c1.shift, c2.w.w, c2.scale, c2.shift, c3.w.w,
-                                              c3.scale, c3.shift, None, None, None, 1)
-    assert torch.equal(y, fused)
+    # the registered op with the reference-shaped argument list: the exact direct-kernel composite by default (it must not
+    # slip a Winograd conv2 into the "every conv on the direct kernel" mode), the whole-block launch only when switched on
+    args = (xd, c1.w.w, c1.scale, c1.shift, c2.w.w, c2.scale, c2.shift, c3.w.w, c3.scale, c3.shift, None, None, None, 1)
+    saved_op = ops.BOTTLENECK_OP_FUSED
+    try:
+        ops.BOTTLENECK_OP_FUSED = False
+        y = torch.ops.maskrcnn.bottleneck_forward(*args)
+        h1 = ops.conv_bn_act(xd, c1.w.w, c1.scale, c1.shift, relu=True)
+        h2 = ops.conv_bn_act(h1, c2.w.w, c2.scale, c2.shift, pad=(1, 1, 1, 1), relu=True)
+        direct = ops.conv_bn_act(h2, c3.w.w, c3.scale, c3.shift, relu=True, residual=xd)
+        assert torch.equal(y, direct)
+        ops.BOTTLENECK_OP_FUSED = True
+        assert torch.equal(torch.ops.maskrcnn.bottleneck_forward(*args), fused)
+        assert torch.equal(torch.ops.maskrcnn.bottleneck_forward(*args), fused)      # second call: cached conv2 transform
+    finally:
+        ops.BOTTLENECK_OP_FUSED = saved_op
 
 
 def test_bottleneck_fused_rejects_other_shapes(dev):
@@ -506,6 +524,18 @@ def test_bottleneck_fused_rejects_other_shapes(dev):
 @pytest.mark.parametrize("shape", [(1, 16, 16, 64, 128), (2, 32, 48, 256, 512), (3, 14, 18, 32, 64), (1, 128, 128, 256, 512)],
                          ids=lambda s: "x".join(str(v) for v in s))
 def test_winograd_fused_rpn_heads(dev, shape):
+    from maskrcnn_amd import ops as _ops
+    if min(shape[1], shape[2]) < 16 and not _ops.HAVE_ABLATIONS:
+        # maps under 8 x 8 tile positions would need the linear-tile heads variant: an MRCNN_ABLATIONS build
+        xk = torch.zeros(shape[3] // 8, shape[0], shape[1], shape[2], 8, device=dev)
+        u = _ops.winograd_weights(torch.zeros(shape[4], 3, 3, shape[3], device=dev))
+        with pytest.raises(RuntimeError, match="MRCNN_ABLATIONS"):
+            _ops.conv3x3_winograd_heads(xk, u, None, None, torch.zeros(32, shape[4], device=dev), True)
+        return
+    _winograd_fused_rpn_heads(dev, shape)
+
+
+def _winograd_fused_rpn_heads(dev, shape):
     """RPN.forward on one level (model.py:609-649) with the heads inside the Winograd kernel: relu(conv_shared) is
     never stored; the head sums come back in position-major order. Against torch-CPU (1e-4 abs, unit-scale data) and
     against the unfused path (Winograd conv + 18-channel 1x1 conv), incl. ragged last M tiles and several N tiles."""
@@ -535,8 +565,9 @@ def test_winograd_fused_rpn_heads(dev, shape):
     again = ops.conv3x3_winograd_heads(xk, u, None, bs.to(dev), w32.to(dev), True)
     assert torch.equal(again.to_nhwc(bh.to(dev)).cpu(), got)                          # deterministic
     # both tile shapes give the same sums bit for bit (same transforms, MFMA order and head accumulation order)
-    lin = ops.conv3x3_winograd_heads(xk, u, None, bs.to(dev), w32.to(dev), True, tile_mode=1)
-    assert torch.equal(lin.to_nhwc(bh.to(dev)).cpu(), got)
+    if ops.HAVE_ABLATIONS:
+        lin = ops.conv3x3_winograd_heads(xk, u, None, bs.to(dev), w32.to(dev), True, tile_mode=1)
+        assert torch.equal(lin.to_nhwc(bh.to(dev)).cpu(), got)
     # the consumer: scores / deltas from head sums == from NHWC heads of the same values
     lv = [got.to(dev)] + [torch.randn(b, max(h >> i, 1), max(w >> i, 1), 18, generator=g).to(dev) for i in (1, 2, 3, 4)]
     s0, d0 = ops.rpn_scores_deltas(lv)
