@@ -493,16 +493,20 @@ def bottleneck_fused(x, w1, s1, t1, u2, s2, t2, w3, s3, t3) -> torch.Tensor:
 # direct kernel, bitwise an fmaf chain"); otherwise the op is the exact three/four-launch composite. modules.py keeps this in
 # step with its own flags.
 BOTTLENECK_OP_FUSED = (os.environ.get("MRCNN_FUSED_BOTTLENECK", "0") == "1" and os.environ.get("MRCNN_WINOGRAD", "1") != "0")
-_U2_CACHE: dict = {}   # conv2 weight (storage, version) -> its Winograd transform: not recomputed per call
+_U2_CACHE: dict = {}   # data_ptr -> (weakref to the conv2 weight tensor, its version, its Winograd transform)
 
 
 def _cached_winograd_weights(w2: torch.Tensor) -> torch.Tensor:
-    key = (w2.data_ptr(), w2._version, tuple(w2.shape), str(w2.device))
-    u = _U2_CACHE.get(key)
-    if u is None:
-        if len(_U2_CACHE) > 256:
-            _U2_CACHE.clear()
-        u = _U2_CACHE[key] = winograd_weights(w2)
+    """The transform of a conv2 weight is computed once per weight tensor, not per call. An entry is valid only for the SAME
+    tensor object at the same version: an address alone is reused by the allocator for other weights."""
+    import weakref
+    e = _U2_CACHE.get(w2.data_ptr())
+    if e is not None and e[0]() is w2 and e[1] == w2._version:
+        return e[2]
+    if len(_U2_CACHE) > 256:
+        _U2_CACHE.clear()
+    u = winograd_weights(w2)
+    _U2_CACHE[w2.data_ptr()] = (weakref.ref(w2), w2._version, u)
     return u
 
 

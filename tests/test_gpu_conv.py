@@ -643,6 +643,47 @@ def test_maxpool_and_deconv_f16(dev):
     assert bool((err <= 2e-4 + 2.0 ** -11 * want.abs()).all()), err.max().item()
 
 
+def test_deconv_scatter_ragged_tiles_keep_their_guard_bands(dev):
+    """The 2x2 transposed-conv epilogue stores 8-byte channel pairs through a buffer descriptor and drops out-of-range rows /
+    channels by pushing their offset past the descriptor's range (conv_common.hpp oob_add). Tiles ragged in BOTH M (105 and
+    78400 input pixels: not multiples of 128) and N (4 * 24 = 96 and 4 * 6 = 24 columns of a 128-wide tile), called through
+    the C ABI on an output that sits between guard bands: the result equals torch-CPU and no byte of either band changes —
+    a dropped store whose offset + 8 wrapped would land inside the buffer or the band."""
+    from maskrcnn_amd import ops
+    from maskrcnn_amd._lib import check, lib
+    g = torch.Generator().manual_seed(171)
+    for (b, h, w, cin, cout, f16) in ((3, 5, 7, 32, 24, False), (1, 7, 15, 16, 6, False), (3, 5, 7, 32, 24, True),
+                                      (400, 14, 14, 8, 6, False)):
+        xi = torch.randn(b, cin, h, w, generator=g)
+        wt = torch.randn(cin, cout, 2, 2, generator=g) * 0.2
+        bias = torch.randn(cout, generator=g) * 0.1
+        w4 = wt.permute(2, 3, 1, 0).reshape(4 * cout, 1, 1, cin).contiguous().to(dev)
+        b4 = bias.repeat(4).contiguous().to(dev)
+        n_out = b * 2 * h * 2 * w * cout
+        band = 4096
+        if f16:
+            x = xi.half().permute(0, 2, 3, 1).contiguous().to(dev)
+            w_hi, _ = ops.split_f16(w4)
+            buf = torch.full((n_out + 2 * band,), 7.0, dtype=torch.float16, device=dev)
+            y = buf[band:band + n_out]
+            check(lib.mrcnn_deconv2x2_bias_act_nhwc_f16io(x.data_ptr(), b, h, w, cin, w_hi.data_ptr(), cout, b4.data_ptr(), 1,
+                                                          y.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            want = F.relu(F.conv_transpose2d(xi.half().float(), wt.half().float(), bias, stride=2))
+            tol = 2e-4 + 2.0 ** -11 * want.abs()
+        else:
+            x = xi.permute(0, 2, 3, 1).contiguous().to(dev)
+            buf = torch.full((n_out + 2 * band,), 7.0, dtype=torch.float32, device=dev)
+            y = buf[band:band + n_out]
+            check(lib.mrcnn_deconv2x2_bias_act_nhwc_f32(x.data_ptr(), b, h, w, cin, w4.data_ptr(), cout, b4.data_ptr(), 1,
+                                                        y.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            want = F.relu(F.conv_transpose2d(xi, wt, bias, stride=2))
+            tol = torch.full_like(want, 1e-4)
+        torch.cuda.synchronize()
+        got = y.view(b, 2 * h, 2 * w, cout).float().permute(0, 3, 1, 2).cpu()
+        assert bool(((got - want).abs() <= tol).all()), (b, h, w, cin, cout, f16, (got - want).abs().max().item())
+        assert bool((buf[:band] == 7.0).all()) and bool((buf[band + n_out:] == 7.0).all()), (b, h, w, cin, cout, f16)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Winograd F(4x4,3x3) (conv3x3_wino4_f32) against torch-CPU, absolute 1e-4 at unit scale
 # ---------------------------------------------------------------------------------------------------------------------
