@@ -296,8 +296,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3", "f16"],
                     help="contraction mode of the headline number (default: exact-fp32 MFMA)")
-    ap.add_argument("--alt-precision", default="f16x3", choices=["none", "f32", "f16x3", "f16"],
-                    help="also time this mode after the headline (reported under alt_precision)")
+    ap.add_argument("--alt-precision", default="f16x3,f32+f16x3",
+                    help="comma-separated contraction modes also timed after the headline (none | f32 | f16x3 | f16 | f32+f16x3); "
+                         "the first is reported under alt_precision, all of them under alt_precisions")
     ap.add_argument("--dump-conv", default=None, help="write per-launch conv (M,N,K,ms,TFLOP/s) JSON here")
     ap.add_argument("--alt-config5", type=int, default=1,
                     help="also time BASELINE configs[4]'s geometry (R101-FPN, 832x1344, fp16 MFMA path) on this GPU, N=1 only")
@@ -385,10 +386,16 @@ def main():
         roofline = conv_roofline(prof, args, H, W, modules)
         roofline_ops = op_rooflines(dev, ops)
 
-    # ---- optional second contraction mode, same weights/inputs/steps (every rank takes part) ----------
-    alt = None
-    if args.alt_precision not in ("none", args.precision):
-        net_alt = make_net(sd, args.alt_precision)
+    # ---- other contraction modes, same weights/inputs/steps (every rank takes part) --------------------
+    alts = []
+    notes = {"f16x3": "fp16-operand MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate), error-compensated 3-product split for "
+                      "every conv (no Winograd): fp32-grade, held to the same 1e-4 parity bar as f32 (tests/test_gpu_*.py)",
+             "f32+f16x3": "the f32 mode's Winograd / stem / k-blocked layers unchanged (exact-fp32 MFMA); the long-K GEMM-shaped "
+                          "layers (Bottleneck conv3 of C4/C5, downsample convs, classifier GEMMs, mask deconv + conv5) on the "
+                          "fp16x3 split: same 1e-4 parity bar (tests/test_gpu_pipeline.py, test_gpu_fullsize.py)",
+             "f16": "plain fp16 operands and fp16 activations in HBM (the fp16 MFMA path of BASELINE configs[4]); 2e-2 of range"}
+    for mode in [m.strip() for m in args.alt_precision.split(",") if m.strip() not in ("", "none", args.precision)]:
+        net_alt = make_net(sd, mode)
 
         def step_alt():
             d = net_alt.predict(images, windows, with_masks=True)
@@ -403,11 +410,9 @@ def main():
         torch.cuda.synchronize()
         mdist.barrier()
         el_alt = mdist.max_over_ranks(time.perf_counter() - t1, dev)
-        alt = {"precision": args.alt_precision, "value": round(n_images / el_alt, 3), "unit": "images/s",
+        alt = {"precision": mode, "value": round(n_images / el_alt, 3), "unit": "images/s",
                "ms_per_step": round(el_alt / args.steps * 1e3, 3),
-               "note": "fp16-operand MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate); f16x3 = error-compensated "
-                       "3-product split, held to the same 1e-4 parity bar as f32 (tests/test_gpu_*.py); "
-                       "reported for information, not the headline"}
+               "note": notes.get(mode, "") + "; reported for information, not the headline"}
         if rank == 0 and args.roofline_steps > 0:
             ops.CONV_PROFILE = []
             for _ in range(args.roofline_steps):
@@ -418,7 +423,9 @@ def main():
             fl = sum(r[2] for r in prof)
             alt["conv_algorithmic_tflops"] = round(fl / (ms * 1e-3) / 1e12, 1)
             alt["conv_ms_per_step"] = round(ms / args.roofline_steps, 3)
+        alts.append(alt)
         del net_alt
+    alt = alts[0] if alts else None
 
     # ---- BASELINE configs[4] geometry on this GPU (ResNet-101-FPN, 832 x 1344 = 1333 x 800 padded to /64, plain-fp16 MFMA
     # path with fp16 activations in HBM), after the headline and never part of `value` -------------------------------
@@ -470,6 +477,7 @@ def main():
                        "mean_valid_proposals": mean_valid,
                        "mean_detections": round(float(det.counts.float().mean().item()), 1)},
             "roofline": roofline, "roofline_ops": roofline_ops, "cpu_baseline": cpu, "alt_precision": alt,
+            "alt_precisions": alts,
             "alt_configs": alt_configs,
         }
         print(json.dumps(line), flush=True)

@@ -32,7 +32,8 @@ SOURCES = {
     "conv.hip": ABL,
     "conv_f16.hip": [],
     "conv_wino.hip": ABL,
-    "conv_wino4.hip": (["-DMRCNN_W4_ABLATIONS"] if (os.environ.get("MRCNN_W4_ABLATIONS") or os.environ.get("MRCNN_ABLATIONS")) else []),
+    "conv_wino4.hip": (["-DMRCNN_W4_ABLATIONS"] if (os.environ.get("MRCNN_W4_ABLATIONS") or os.environ.get("MRCNN_ABLATIONS")) else [])
+                      + ([f"-DMRCNN_W4_WALK_SHIFT={int(os.environ['MRCNN_W4_WALK_SHIFT'])}"] if os.environ.get("MRCNN_W4_WALK_SHIFT") else []),
     "stem.hip": [],
     "bottleneck.hip": [],
     "misc.hip": ["-ffp-contract=off"],

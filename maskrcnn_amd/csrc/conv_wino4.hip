@@ -69,7 +69,10 @@ struct Wino4Params {
 };
 
 constexpr int W4_N = 64;                              // output channels per workgroup
-constexpr int W4_WALK_SHIFT = 4;                      // HEADS: runs of 16 consecutive M tiles start their N-tile walk together
+#ifndef MRCNN_W4_WALK_SHIFT
+#define MRCNN_W4_WALK_SHIFT 4
+#endif
+constexpr int W4_WALK_SHIFT = MRCNN_W4_WALK_SHIFT;    // HEADS: runs of 16 consecutive M tiles start their N-tile walk together
 constexpr int W4_TSLOT = 6;                           // MFMA slot of the k loop that carries the input transform
 constexpr int W4_RW = 40;                             // channel pairs per raw row in LDS (34 used; == 0 mod 8)
 constexpr int W4_RPLANE = 18 * W4_RW + 8;             // pairs per (buffer, channel pair) plane, rotation included

@@ -149,6 +149,21 @@ def pack_weight(w_oihw: torch.Tensor, device, cin_pad: int | None = None) -> tor
 
 
 PRECISIONS = ("f32", "f16x3", "f16")
+# "f32+f16x3": every 3x3 stride-1 conv, the stem and every layer that writes a k-blocked tensor stay on the exact-fp32 MFMA
+# kernels (Winograd / stem / direct) exactly as in "f32"; the GEMM-shaped layers with K >= MIX_MIN_K whose output is plain
+# NHWC — Bottleneck conv3 of C4 / C5, the downsample convs, the classifier's three GEMMs, the mask head's transposed conv and
+# 1x1 conv — take the error-compensated fp16x3 split (fp32-grade: it passes the same 1e-4 tests; 5x fewer MFMA cycles per
+# multiply-add than v_mfma_f32_32x32x2_f32). The short-K expansion layers of C2 / C3 are HBM-bound and stay f32. Activations
+# are fp32 in HBM everywhere. Reported by bench.py as an alt_precision, never as the headline.
+MIXED = "f32+f16x3"
+MIX_MIN_K = 256
+
+
+def layer_precision(precision: str, k: int, gemm_out_nhwc: bool = True) -> str:
+    """The contraction mode of ONE layer under a pipeline-level precision."""
+    if precision != MIXED:
+        return precision
+    return "f16x3" if (gemm_out_nhwc and k >= MIX_MIN_K) else "f32"
 
 
 # f32 mode: 3x3 stride-1 SAME convs run the fused Winograd F(2x2,3x3) kernel (fp32 MFMA, 2.25x fewer multiply-adds;
@@ -199,7 +214,7 @@ class ConvWeight:
        f16    fp16-operand MFMA, plain (BASELINE config 5's fp16 MFMA path) — ~2^-11 per term"""
 
     def __init__(self, w_ohwi: torch.Tensor, precision: str = "f32", winograd4: bool = False):
-        assert precision in PRECISIONS, precision
+        assert precision in PRECISIONS, precision   # one layer's mode: "f32+f16x3" is resolved per layer (layer_precision)
         self.precision = precision
         self.shape = tuple(w_ohwi.shape)
         self.u = None
@@ -294,15 +309,17 @@ class FusedBottleneck:
     def from_state_dict(cls, sd, prefix, stride, device, precision="f32"):
         pre = (prefix + ".") if prefix and not prefix.endswith(".") else prefix
         if precision != "f32" or WINOGRAD:
-            c1 = FusedConv(sd, pre + "conv1", pre + "bn1", device, stride=stride, relu=True, precision=precision)
+            p12 = layer_precision(precision, 0, False)      # conv1 writes k-blocked for conv2's Winograd kernel: f32 in "f32+f16x3"
+            c1 = FusedConv(sd, pre + "conv1", pre + "bn1", device, stride=stride, relu=True, precision=p12)
             c2 = FusedConv(sd, pre + "conv2", pre + "bn2", device, relu=True, same_pad_kernel=3,
-                           precision=precision, winograd4=WINOGRAD4_TRUNK)
-            c3 = FusedConv(sd, pre + "conv3", pre + "bn3", device, relu=True, precision=precision)
+                           precision=p12, winograd4=WINOGRAD4_TRUNK)
+            c3 = FusedConv(sd, pre + "conv3", pre + "bn3", device, relu=True,
+                           precision=layer_precision(precision, sd[pre + "conv3.weight"].size(1)))
             cd = None
             if (pre + "downsample.0.weight") in sd:
                 cd = FusedConv(sd, pre + "downsample.0", pre + "downsample.1", device, stride=stride,
-                               precision=precision)
-            return cls(None, precision, (c1, c2, c3, cd))
+                               precision=layer_precision(precision, sd[pre + "downsample.0.weight"].size(1)))
+            return cls(None, "f32" if precision == MIXED else precision, (c1, c2, c3, cd))
         w1 = pack_weight(sd[pre + "conv1.weight"], device)
         s1, t1 = fold_bn(sd, pre + "conv1", pre + "bn1", device)
         w2 = pack_weight(sd[pre + "conv2.weight"], device)
@@ -369,13 +386,15 @@ class FusedBackbone:
     def __init__(self, sd, arch, device, prefix="fpn.", precision="f32"):
         l = LAYERS[arch]
         self.device = device
+        block_precision = precision
+        precision = layer_precision(precision, 0, False)   # "f32+f16x3": stem, laterals (k-blocked out) and smoothing are f32
         self.cin_pad = 4 if precision == "f32" else 8   # 16-byte pixels (fp32 path) / 8-half chunks (fp16 path)
         self.stem = FusedConv(sd, prefix + "C1.0", prefix + "C1.1", device, stride=2, relu=True,
                               pad=(3, 3, 3, 3), cin_pad=self.cin_pad, precision=precision)
         self.stages = []
         for name, n, stride in (("C2", l[0], 1), ("C3", l[1], 2), ("C4", l[2], 2), ("C5", l[3], 2)):
             self.stages.append([FusedBottleneck.from_state_dict(sd, f"{prefix}{name}.{i}",
-                                                                stride if i == 0 else 1, device, precision)
+                                                                stride if i == 0 else 1, device, block_precision)
                                 for i in range(n)])
         self.lateral = {k: FusedConv(sd, f"{prefix}P{k}_conv1", None, device, precision=precision)
                         for k in (5, 4, 3, 2)}
@@ -435,6 +454,7 @@ class FusedRPN:
     18-channel GEMM. Returns NHWC [B,H,W,18]: channels 0-5 = (bg,fg) logits x 3 anchors, 6-17 = deltas."""
 
     def __init__(self, sd, device, prefix="rpn.", precision="f32"):
+        precision = layer_precision(precision, 0, False)   # "f32+f16x3": the RPN is Winograd + small head convs: f32
         self.precision = precision
         w = torch.cat([sd[prefix + "conv_class.weight"], sd[prefix + "conv_bbox.weight"]], 0)
         self.b_head = torch.cat([sd[prefix + "conv_class.bias"], sd[prefix + "conv_bbox.bias"]]).float() \
@@ -485,6 +505,7 @@ class FusedClassifier:
     conv is one GEMM with K = 7*7*256 (OHWI weight flattening == NHWC crop flattening)."""
 
     def __init__(self, sd, device, prefix="classifier.", precision="f32"):
+        precision = layer_precision(precision, 1024)           # "f32+f16x3": three GEMMs with K = 12544 / 1024 / 1024
         w1 = pack_weight(sd[prefix + "conv1.weight"], device)  # [1024,7,7,256]
         self.pool = w1.size(1)
         self.w1 = ConvWeight(w1.view(w1.size(0), 1, 1, -1), precision)
@@ -513,7 +534,8 @@ class FusedMask:
 
     def __init__(self, sd, device, prefix="mask.", precision="f32"):
         self.convs = [FusedConv(sd, f"{prefix}conv{i}", f"{prefix}bn{i}", device, relu=True,
-                                same_pad_kernel=3, precision=precision) for i in (1, 2, 3, 4)]
+                                same_pad_kernel=3, precision=layer_precision(precision, 0, False)) for i in (1, 2, 3, 4)]
+        precision = layer_precision(precision, sd[prefix + "deconv.weight"].size(0))   # deconv and conv5: K = 256
         wt = sd[prefix + "deconv.weight"].float()  # [Cin, Cout, 2, 2]
         cin, cout = wt.size(0), wt.size(1)
         # GEMM output channel = (dy*2 + dx)*Cout + co

@@ -44,7 +44,9 @@ class MaskRCNNInference:
                  precision: str = "f32"):
         """precision: contraction mode of every conv/GEMM (modules.ConvWeight): "f32" exact-fp32 MFMA (default,
         the parity mode), "f16x3" fp16-operand MFMA with the error-compensated 3-product split (fp32-grade),
-        "f16" plain fp16 operands (BASELINE config 5). Activations are fp32 in HBM in every mode."""
+        "f16" plain fp16 operands (BASELINE config 5); "f32+f16x3" (modules.MIXED): fp32 Winograd / stem / k-blocked layers as in
+        "f32", fp16x3 split for the long-K GEMM-shaped layers. Activations are fp32 in HBM in every mode but "f16"."""
+        assert precision in modules.PRECISIONS + (modules.MIXED,), precision
         self.cfg = cfg or InferenceConfig()
         self.precision = precision
         self.device = torch.device(device)

@@ -192,8 +192,10 @@ def _calibrated(cfg, sd, images, windows, dev, precision="f32"):
     return net, det, mid
 
 
-@pytest.fixture(scope="module")
-def full(dev):
+@pytest.fixture(scope="module", params=["f32", "f32+f16x3"])
+def full(dev, request):
+    """Both modes are held to the same bars: "f32" (the default and the headline) and "f32+f16x3" (bench.py's alt mode: the
+    long-K GEMM-shaped layers on the error-compensated fp16x3 split)."""
     from maskrcnn_amd import modules
     from maskrcnn_amd.config import InferenceConfig
     cfg = InferenceConfig(image_height=1024, image_width=1024, backbone="resnet50", pre_nms_limit=1000,
@@ -209,8 +211,9 @@ def full(dev):
     images = torch.randint(0, 256, (b, 1024, 1024, 3), generator=g0).float() - torch.tensor(cfg.mean_pixel)
     images = images.permute(0, 3, 1, 2).contiguous()
     windows = torch.tensor([[0., 0., 1024., 1024.], [192., 0., 832., 1024.]])   # full frame; config 1's window
-    net, det, mid = _calibrated(cfg, sd, images, windows, dev)
-    return dict(cfg=cfg, sd=sd, net=net, images=images, windows=windows, det=det, mid=mid, b=b)
+    net, det, mid = _calibrated(cfg, sd, images, windows, dev, request.param)
+    return dict(cfg=cfg, sd=sd, net=net, images=images, windows=windows, det=det, mid=mid, b=b, precision=request.param,
+                tag="config3" if request.param == "f32" else "config3[" + request.param + "]")
 
 
 def _ocfg(oracle, cfg):
@@ -227,12 +230,12 @@ def test_full_size_trunk_and_rpn(full, oracle):
         assert [tuple(f.shape) for f in fms] == [(1, 256, 256, 256), (1, 256, 128, 128), (1, 256, 64, 64),
                                                  (1, 256, 32, 32), (1, 256, 16, 16)]   # model.py:165-166
         for lvl, (want, got) in enumerate(zip(fms, s["mid"]["feature_maps"])):
-            _record(f"config3/img{b}/P{lvl + 2}", got[b].permute(2, 0, 1).cpu(), want[0])
+            _record(f"{s['tag']}/img{b}/P{lvl + 2}", got[b].permute(2, 0, 1).cpu(), want[0])
         _, rpn_class, rpn_bbox = oracle.rpn_detect(fms, s["sd"])
         assert rpn_class.shape[1] == s["mid"]["rpn_scores"].shape[1] == 261888       # utils.py:288
-        err, _ = _record(f"config3/img{b}/rpn_fg_score", s["mid"]["rpn_scores"][b].cpu(), rpn_class[0, :, 1])
+        err, _ = _record(f"{s['tag']}/img{b}/rpn_fg_score", s["mid"]["rpn_scores"][b].cpu(), rpn_class[0, :, 1])
         assert err <= 1e-4
-        _record(f"config3/img{b}/rpn_deltas", s["mid"]["rpn_deltas"][b].cpu(), rpn_bbox[0])
+        _record(f"{s['tag']}/img{b}/rpn_deltas", s["mid"]["rpn_deltas"][b].cpu(), rpn_bbox[0])
 
 
 def test_full_size_trunk_unit_scale_input(full, oracle):
@@ -245,7 +248,7 @@ def test_full_size_trunk_unit_scale_input(full, oracle):
     torch.cuda.synchronize()
     want = oracle.fpn_forward(x, s["sd"], "resnet50")
     for lvl, (w_, g_) in enumerate(zip(want, got)):
-        _record(f"config3/unit_scale_input/P{lvl + 2}", g_[0].permute(2, 0, 1).cpu(), w_[0])
+        _record(f"{s['tag']}/unit_scale_input/P{lvl + 2}", g_[0].permute(2, 0, 1).cpu(), w_[0])
 
 
 def test_full_size_proposals(full, oracle):
@@ -271,7 +274,7 @@ def test_full_size_proposals(full, oracle):
             return torch.from_numpy(a[np.lexsort((a[:, 3], a[:, 2], a[:, 1], a[:, 0], -a[:, 4]))])
         ties = int(1000 - torch.unique(dets[:, 4]).numel())
         d = (canon(got_dets)[:, :4] - canon(dets)[:, :4]).abs()
-        REPORT[f"config3/img{b}/proposal_boxes"] = {"max_abs_err_px": d.max().item(), "tied_scores": ties,
+        REPORT[f"{s['tag']}/img{b}/proposal_boxes"] = {"max_abs_err_px": d.max().item(), "tied_scores": ties,
                                                     "boxes_not_bit_identical": int((d.max(1).values > 0).sum())}
         assert d.max().item() <= 1e-3                                        # pixels; exp() ulp differences only
         keep = oracle.nms(got_dets, ocfg.RPN_NMS_THRESHOLD)[:ocfg.RPN_NMS_MAX_ROIS_NUM]
@@ -280,7 +283,7 @@ def test_full_size_proposals(full, oracle):
         want = got_dets[keep, :4] / torch.tensor([1024., 1024., 1024., 1024.])
         assert torch.equal(s["mid"]["rois"][b, :n].cpu(), want)
         assert bool((s["mid"]["rois"][b, n:] == 0).all())
-        REPORT[f"config3/img{b}/proposals_kept"] = n
+        REPORT[f"{s['tag']}/img{b}/proposals_kept"] = n
 
 
 def test_full_size_classifier_and_detections(full, oracle):
@@ -297,8 +300,8 @@ def test_full_size_classifier_and_detections(full, oracle):
         logits, probs, bbox = oracle.classifier_forward(fms, rois, s["sd"], ocfg)
         got_logits = s["mid"]["logits"][b * p:b * p + n].cpu()
         got_bbox = s["mid"]["bbox"][b * p:b * p + n].cpu()
-        _record(f"config3/img{b}/classifier_logits", got_logits, logits)
-        _record(f"config3/img{b}/classifier_bbox", got_bbox, bbox)
+        _record(f"{s['tag']}/img{b}/classifier_logits", got_logits, logits)
+        _record(f"{s['tag']}/img{b}/classifier_bbox", got_bbox, bbox)
         gp = torch.softmax(got_logits, dim=1)
         cls, sc, bx = oracle.mrn_refine(rois, gp, got_bbox, tuple(s["windows"][b].tolist()), ocfg)
         k = int(s["det"].counts[b])
@@ -309,7 +312,7 @@ def test_full_size_classifier_and_detections(full, oracle):
         total += k
         assert torch.equal(s["det"].class_ids[b, :k].cpu(), cls[0])
         same = (s["det"].boxes[b, :k].cpu() == bx[0]).all(1)
-        REPORT[f"config3/img{b}/detections"] = {"count": k, "boxes_identical": int(same.sum()),
+        REPORT[f"{s['tag']}/img{b}/detections"] = {"count": k, "boxes_identical": int(same.sum()),
                                                 "max_box_diff_px": (s["det"].boxes[b, :k].cpu() - bx[0]).abs().max().item()}
         assert torch.equal(s["det"].boxes[b, :k].cpu(), bx[0])
         assert torch.allclose(s["det"].scores[b, :k].cpu(), sc[0], rtol=0, atol=1e-6)
@@ -329,7 +332,7 @@ def test_full_size_masks(full, oracle):
         boxes = s["det"].boxes[b, :k].cpu()
         want = oracle.mask_forward(fms, boxes / 1024.0, s["sd"], ocfg)        # [k,81,28,28]
         got = s["det"].masks[b, :k].permute(0, 3, 1, 2).cpu()
-        err, _ = _record(f"config3/img{b}/masks", got, want)
+        err, _ = _record(f"{s['tag']}/img{b}/masks", got, want)
         assert err <= 1e-4
 
 
@@ -355,7 +358,7 @@ def test_full_size_batch8_independence(full):
         assert torch.equal(det1.class_ids[0], det8.class_ids[i]) and torch.equal(det1.boxes[0], det8.boxes[i])
         assert torch.equal(det1.scores[0], det8.scores[i]) and int(det1.counts[0]) == int(det8.counts[i])
         assert torch.equal(det1.masks[0], det8.masks[i])
-    REPORT["config3/batch8_independence"] = "bit-identical (images 0 and 5; trunk, RPN, proposals, classifier, detections, masks)"
+    REPORT[s["tag"] + "/batch8_independence"] = "bit-identical (images 0 and 5; trunk, RPN, proposals, classifier, detections, masks)"
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -378,7 +381,7 @@ def test_config5_full_size_r101_832x1344(dev, oracle):
     want = oracle.fpn_forward(images, sd, "resnet101")
     assert [tuple(f.shape[2:]) for f in want] == [(208, 336), (104, 168), (52, 84), (26, 42), (13, 21)]
     f32_maps = None
-    for precision, rel in (("f32", 1e-4), ("f16x3", 1e-4), ("f16", 2e-2)):
+    for precision, rel in (("f32", 1e-4), ("f16x3", 1e-4), ("f32+f16x3", 1e-4), ("f16", 2e-2)):
         net = MaskRCNNInference(sd, cfg, dev, precision=precision)
         det, mid = net.predict(images.to(dev), windows, return_intermediates=True)
         torch.cuda.synchronize()
