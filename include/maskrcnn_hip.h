@@ -300,6 +300,17 @@ int32_t mrcnn_conv3x3_winograd4_supported(int32_t batch, int32_t height, int32_t
 int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width, int32_t cin,
                                 const float* u, int32_t cout, const float* scale, const float* shift, int32_t activation,
                                 float* y_nhwc, float* y_kblocked, mrcnn_stream_t stream);
+/* conv2 + conv3 of a ResNet Bottleneck in one launch (model.py:197-209): relu(scale * conv3x3_same(x) + shift) with 64 output
+ * channels stays on chip (the F(4x4) kernel's epilogue) and is multiplied by the 1x1 expansion's weights there:
+ *     y = relu(scale3 * (that W3^T) + shift3 + residual)
+ *   x k-blocked [Cin/8][B*H*W][8]; u = mrcnn_winograd4_weights_f32 of the [64][3][3][Cin] conv2 weight; w3 fp32 [c3][64]
+ *   (OHWI of the 1x1 conv), c3 % 32 == 0; residual and y NHWC [B][H][W][c3], residual != y. The conv3 part runs the
+ *   direct kernel's k order and epilogue expression: equal bit for bit to mrcnn_conv3x3_winograd4_f32 followed by
+ *   mrcnn_conv_bn_act_f32 with the same residual. Same shape limits as mrcnn_conv3x3_winograd4_f32 with Cout = 64. */
+int mrcnn_conv3x3_winograd4_conv3_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                      const float* u, const float* scale, const float* shift, const float* w3, int32_t c3,
+                                      const float* scale3, const float* shift3, const float* residual, float* y,
+                                      mrcnn_stream_t stream);
 /* The F(4x4) form of mrcnn_conv3x3_winograd_heads_f32 (RPN shared conv + its two 1x1 heads, model.py:605-641, in one
  * launch): head_part fp32 [rows][32], rows = mrcnn_conv3x3_winograd4_heads_rows(batch, H, W); row of pixel (b,y,x) =
  * mt*512 + ((y/4 & 3)*8 + (x/4 & 7))*16 + (y&3)*4 + (x&3), mt = (b*ceil(H/16) + y/16)*ceil(W/32) + x/32; the sums over

@@ -65,6 +65,8 @@ _SIGS = {
     "mrcnn_conv3x3_winograd4_supported": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32]),
     "mrcnn_conv3x3_winograd4_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32,
                                                      c_vp, c_vp, c_vp]),
+    "mrcnn_conv3x3_winograd4_conv3_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
+                                                           c_vp, c_vp, c_vp, c_vp]),
     "mrcnn_conv3x3_winograd4_heads_rows": (c_i64, [c_i32, c_i32, c_i32]),
     "mrcnn_conv3x3_winograd4_heads_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32,
                                                            c_vp, c_vp, c_vp]),

@@ -65,6 +65,15 @@ struct Wino4Params {
     const float* w_head;
     float* head_part;
     unsigned head_bytes;
+    // fused 1x1 expansion (CONV3; Cout == 64): w3 [C3][64] (OHWI of a 1x1 conv), scale3 / shift3 [C3] or null, residual and
+    // y3 NHWC [B][H][W][C3]: y3 = relu(scale3 * (relu(scale * conv3x3 + shift) W3^T) + shift3 + residual)
+    const float* w3;
+    const float* scale3;
+    const float* shift3;
+    const float* res3;
+    float* y3;
+    int C3;
+    unsigned w3_bytes, y3_bytes;
     int debug;  // MRCNN_W4_DEBUG: timing ablations (wrong results): 1 no DMA, 2 no transform, 4 no patch reads, 8 no B reads, 16 no raw staging
 };
 
@@ -91,6 +100,14 @@ constexpr int W4_WH_OFF = W4_T_OFF + W4_T_FLOATS;
 constexpr int W4_H_OFF = W4_WH_OFF + W4_WH_FLOATS;
 constexpr size_t WINO4_HEADS_LDS = sizeof(float) * (W4_H_OFF + 512 * W4_HP);
 static_assert(W4_H_OFF >= W4_RS_FLOATS + 2 * W4_UBUF && WINO4_HEADS_LDS <= 160 * 1024, "HEADS LDS map");
+// CONV3: the 1x1 expansion's weights W3 [<= 256][64] stay in LDS for the workgroup's whole life, ABOVE the staging area (the
+// k loop never touches them), as 64 B-operand pieces [column block][j][lane][4]; the epilogue's transposed tile T has no
+// room of its own then — it ALIASES Z: row (position p8, pixel r) of T lies in Z's chunk (component r, position p8), which
+// only the half-wave that owns position p8 reads (all 36 of its chunks, into registers) before it writes T there
+constexpr int W4_W3_OFF = W4_RS_FLOATS + 2 * W4_UBUF;
+constexpr int W4_W3_FLOATS = 256 * W4_N;
+constexpr size_t WINO4_CONV3_LDS = sizeof(float) * (W4_W3_OFF + W4_W3_FLOATS);
+static_assert(WINO4_CONV3_LDS <= 160 * 1024 && W4_Z_FLOATS <= W4_W3_OFF, "CONV3 LDS map");
 static_assert(W4_Z_FLOATS <= W4_RS_FLOATS + 2 * W4_UBUF, "the exchange buffer aliases the staging buffers");
 
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
@@ -209,8 +226,9 @@ __device__ __forceinline__ void at4p(const f32x2 m0, const f32x2 m1, const f32x2
 // head sums, which stay in LDS until the last N tile writes them out.
 // DBG: compile-time tuning variants (MRCNN_W4_ABLATIONS builds): bits 1..1024 leave parts out (wrong results, timing only),
 // 2048 records s_memtime stamps of a tile's phases (tools/w4_stamp.py). DBG = 0 is the product.
-template <int QA, int QB, int DBG, bool HEADS, bool ACT>
+template <int QA, int QB, int DBG, bool HEADS, bool ACT, bool CONV3 = false>
 __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) {
+    static_assert(!(HEADS && CONV3), "one fused consumer at a time");
     lds_f32x2* Rs = (lds_f32x2*)smem;            // [2][2][W4_RPLANE] channel pairs
     lds_f32* Us = smem + W4_RS_FLOATS;           // [2][36][2][64][2]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -225,6 +243,20 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
     unsigned long long stamp[16];
     int nstamp = 0;
     auto STAMP = [&]() { if constexpr ((DBG & 2048) != 0) { if (nstamp < 16) stamp[nstamp++] = __builtin_readcyclecounter(); } };
+    if constexpr (CONV3) {
+        // W3 → LDS once per workgroup, as B-operand pieces: piece (cb, j) = what lane (column ln of block cb, half lh) multiplies
+        // in k steps 4 j .. 4 j + 3, i.e. W3[cb * 32 + ln][8 j + 4 lh .. + 3]; wave w moves pieces 16 w .. 16 w + 15. The wait
+        // is the vmcnt(0) behind the first tile's k loop.
+        const __amdgpu_buffer_rsrc_t w3_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w3), 0, p.w3_bytes, 0x00020000);
+        const int npieces = (p.C3 >> 5) * 8;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int piece = wave * 16 + q, cb = piece >> 3, j = piece & 7;
+            if (piece < npieces)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w3_rsrc, smem + W4_W3_OFF + piece * 256, 16,
+                                                         static_cast<int>(((cb * 32 + ln) * W4_N + lh * 4) * 4), j * 32, 0, 0);
+        }
+    }
     for (int it = 0;; ++it) {
         if ((DBG & 2048) && it == 1) nstamp = 0;
         STAMP();  // 0: tile start
@@ -477,6 +509,11 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         const unsigned kcol = static_cast<unsigned>(ng >> 3) * p.yk_plane + static_cast<unsigned>(ng & 7) * 4u;
         // HEADS: the round's 128 pixels x 64 channels, [pixel][channel ^ swizzle], behind the exchange buffer
         lds_f32* Tt = smem + W4_T_OFF;
+        // row pxl (= position * 16 + pixel of the 4 x 4 tile) of the round's transposed tile
+        auto t_row = [&](int pxl) -> lds_f32* {
+            if constexpr (CONV3) return Z + ((pxl & 15) * 8 + (pxl >> 4)) * 64;   // inside Z: see W4_W3_OFF
+            else return Tt + pxl * W4_N;
+        };
         // the N tile's head weights: piece j = what lane (head ln, half lh) multiplies in k steps 4j..4j+3 (channels
         // n0 + 8 j + 4 lh + e), by LDS-DMA behind T — in registers they are 32 VGPRs the transform below has not got
         lds_f32* Wh = smem + W4_WH_OFF;
@@ -539,11 +576,11 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                         asm("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1" : "+v"(yv[i].x), "+v"(yv[i].y));
                 }
                 if (DBG & 32) { if (yv[0].x == 12345.678f) p.y[0] = yv[0].x; continue; }
-                if constexpr (HEADS) {
+                if constexpr (HEADS || CONV3) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {  // pixel row of the round: position p8, pixel i * 4 + j
                         const int pxl = p8 * 16 + i * 4 + j;
-                        *(lds_f32x2*)(Tt + pxl * W4_N + (n ^ ((pxl & 15) << 2))) = yv[i];
+                        *(lds_f32x2*)(t_row(pxl) + (n ^ ((pxl & 15) << 2))) = yv[i];
                     }
                 } else {
                     if (p.y) {
@@ -607,6 +644,70 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                 if (g == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (g == 0 || g == 1) STAMP();  // after the heads block
             }
+            if constexpr (CONV3) {
+                // The Bottleneck's 1x1 expansion on the round's 128 pixels while they are on chip (model.py:203-209: conv3 +
+                // bn3 + residual + ReLU): wave w takes pixels 32 w .. 32 w + 31 x all C3 output channels, 32 at a time:
+                // A = the transposed tile T (k = the 64 channels of conv2), B = the W3 pieces resident in LDS, the same k
+                // order and the same epilogue expression as the direct kernel runs for this layer (conv.hip /
+                // conv_common.hpp): equal bit for bit. Only the residual loads and the stores are vector-memory traffic; the
+                // residual of column block cb + 1 is in flight while block cb is multiplied and stored (one wave per SIMD:
+                // nobody else covers its latency).
+                const __amdgpu_buffer_rsrc_t r3_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res3), 0, p.y3_bytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t y3_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y3, 0, p.y3_bytes, 0x00020000);
+                const int pxl = wave * 32 + ln;
+                const lds_f32* trow = t_row(pxl);
+                const int swz = (pxl & 15) << 2;
+                const lds_f32* W3s = smem + W4_W3_OFF + lane * 4;
+                unsigned rowoff[16];   // byte offset of output pixel (row r of the MFMA tile) in y3 / the residual, or OOB
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;      // pixel of the round: position pr >> 4, (i, j)
+                    const int TY = TY0 + g, TX = TX0 + (pr >> 4);
+                    const bool ok = TY < p.TH && TX < p.TW;
+                    const unsigned pix = static_cast<unsigned>((b * p.H + 4 * TY + ((pr >> 2) & 3)) * p.W + 4 * TX + (pr & 3));
+                    rowoff[r] = ok ? pix * static_cast<unsigned>(p.C3) * 4u : OOB;
+                }
+                const int ncb = p.C3 >> 5;
+                auto fetch_res = [&](int cb, float (&res)[16]) {
+                    const unsigned ccol = static_cast<unsigned>(cb * 32 + ln) * 4u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        res[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r3_rsrc, static_cast<int>(oob_add(rowoff[r], ccol)), 0, 0));
+                };
+                auto block = [&](int cb, const float (&res)[16], float (&res_next)[16]) {
+                    const unsigned ccol = static_cast<unsigned>(cb * 32 + ln) * 4u;
+                    const float sc3 = p.scale3 ? p.scale3[cb * 32 + ln] : 1.0f, sh3 = p.shift3 ? p.shift3[cb * 32 + ln] : 0.0f;
+                    if (cb + 1 < ncb) fetch_res(cb + 1, res_next);
+                    f32x16 hacc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const f32x4 a4 = *(const lds_f32x4*)(trow + ((j * 8 + lh * 4) ^ swz));
+                        const f32x4 b4 = *(const lds_f32x4*)(W3s + (cb * 8 + j) * 256);
+                        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, hacc, 0, 0, 0);
+                        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, hacc, 0, 0, 0);
+                        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, hacc, 0, 0, 0);
+                        hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, hacc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = hacc[r] * sc3 + sh3;
+                        v += res[r];
+                        asm("v_max_f32 %0, 0, %0" : "+v"(v));
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y3_rsrc, static_cast<int>(oob_add(rowoff[r], ccol)), 0, 0);
+                    }
+                };
+                float r0[16], r1[16];
+                fetch_res(0, r0);
+                for (int cb = 0; cb < ncb; cb += 2) {
+                    block(cb, r0, r1);
+                    if (cb + 1 < ncb) block(cb + 1, r1, r0);
+                }
+                // T lies inside Z: the next round's Z writes (and, after the last round, the next tile's prologue) must not
+                // start before every wave has read its rows
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
         }
         if constexpr ((DBG & 2048) != 0) {
             // plain: into the (second) output tensor; HEADS: over the shift vector (a tuning build: results are void anyway)
@@ -619,15 +720,15 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
 
 // DBG: timing ablations for tuning (wrong results): 1 no DMA, 2 no transform, 4 no patch reads, 8 no B reads, 16 no raw
 // staging. Only DBG = 0 is built unless MRCNN_W4_ABLATIONS is defined.
-template <int DBG, bool HEADS, bool ACT = true>
+template <int DBG, bool HEADS, bool ACT = true, bool CONV3 = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino4_f32(const Wino4Params p) {
     extern __shared__ __attribute__((aligned(1024))) float smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     lds_f32* lds = (lds_f32*)smem;
-    if (wave == 0) wino4_wave<0, 0, DBG, HEADS, ACT>(p, lds);
-    else if (wave == 1) wino4_wave<0, 1, DBG, HEADS, ACT>(p, lds);
-    else if (wave == 2) wino4_wave<1, 0, DBG, HEADS, ACT>(p, lds);
-    else wino4_wave<1, 1, DBG, HEADS, ACT>(p, lds);
+    if (wave == 0) wino4_wave<0, 0, DBG, HEADS, ACT, CONV3>(p, lds);
+    else if (wave == 1) wino4_wave<0, 1, DBG, HEADS, ACT, CONV3>(p, lds);
+    else if (wave == 2) wino4_wave<1, 0, DBG, HEADS, ACT, CONV3>(p, lds);
+    else wino4_wave<1, 1, DBG, HEADS, ACT, CONV3>(p, lds);
 }
 
 // G g G^T in double, stored as the kernel's [Cin/4][36][2][Cout][2]. G (6 x 3): row of point p = [1 p p^2] / N_p, N_p the
@@ -716,6 +817,7 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
     p.u_bytes = static_cast<unsigned>(4LL * 36 * cin * cout);
     p.y_bytes = static_cast<unsigned>(4LL * px * cout);
     p.w_head = nullptr; p.head_part = nullptr; p.head_bytes = 0;
+    p.w3 = nullptr; p.scale3 = nullptr; p.shift3 = nullptr; p.res3 = nullptr; p.y3 = nullptr; p.C3 = 0; p.w3_bytes = 0; p.y3_bytes = 0;
     p.debug = 0;
 #ifdef MRCNN_W4_ABLATIONS
     p.debug = getenv("MRCNN_W4_DEBUG") ? atoi(getenv("MRCNN_W4_DEBUG")) : 0;
@@ -780,6 +882,7 @@ extern "C" int mrcnn_conv3x3_winograd4_heads_f32(const float* x_kblocked, int32_
     p.y_bytes = 0;
     p.w_head = w_head32; p.head_part = head_part;
     p.head_bytes = static_cast<unsigned>(4LL * rows * 32);
+    p.w3 = nullptr; p.scale3 = nullptr; p.shift3 = nullptr; p.res3 = nullptr; p.y3 = nullptr; p.C3 = 0; p.w3_bytes = 0; p.y3_bytes = 0;
     p.debug = 0;
 #ifdef MRCNN_W4_ABLATIONS
     p.debug = getenv("MRCNN_W4_DEBUG") ? atoi(getenv("MRCNN_W4_DEBUG")) : 0;
@@ -807,4 +910,48 @@ extern "C" int mrcnn_conv3x3_winograd4_heads_f32(const float* x_kblocked, int32_
     const long long launch = units < ncu ? units : ncu;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(launch)), dim3(256), WINO4_HEADS_LDS, mrcnn::as_stream(stream), p);
     return mrcnn::check_launch("conv3x3_wino4_f32<heads>");
+}
+
+// conv2 (3x3, planes -> planes = 64) + BN + ReLU, then conv3 (1x1, 64 -> c3) + BN + residual + ReLU of a ResNet Bottleneck
+// (model.py:197-209) in ONE launch: the 64-channel map between them never reaches HBM.
+extern "C" int mrcnn_conv3x3_winograd4_conv3_f32(const float* x_kblocked, int32_t batch, int32_t height, int32_t width,
+                                                 int32_t cin, const float* u, const float* scale, const float* shift,
+                                                 const float* w3, int32_t c3, const float* scale3, const float* shift3,
+                                                 const float* residual, float* y, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x_kblocked && u && w3 && residual && y, "conv3x3_winograd4_conv3: null pointer");
+    MRCNN_REQUIRE(batch >= 1 && mrcnn_conv3x3_winograd4_supported(batch, height, width, cin, W4_N),
+                  "conv3x3_winograd4_conv3: B=%d H=%d W=%d (%% 4 == 0) Cin=%d (%% 8 == 0), B*H*W*C < 2^30 required", batch,
+                  height, width, cin);
+    MRCNN_REQUIRE(c3 >= 32 && c3 % 32 == 0 && c3 <= 256, "conv3x3_winograd4_conv3: c3=%d must be a multiple of 32, at most 256", c3);
+    MRCNN_REQUIRE(residual != y, "conv3x3_winograd4_conv3: in-place operation is not supported");
+    const long long px = 1LL * batch * height * width;
+    MRCNN_REQUIRE(px * c3 < (1LL << 30), "conv3x3_winograd4_conv3: tensor too large (32-bit buffer byte offsets)");
+    Wino4Params p;
+    p.x = x_kblocked; p.u = u; p.scale = scale; p.shift = shift; p.y = nullptr; p.yk = nullptr;
+    p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = W4_N;
+    p.TH = height / 4; p.TW = width / 4; p.act = 1;
+    p.tyb = (p.TH + 3) / 4; p.txb = (p.TW + 7) / 8;
+    p.tiles_m = batch * p.tyb * p.txb;
+    p.tiles_n = 1;
+    p.x_plane = static_cast<unsigned>(4LL * px * 8);
+    p.u_ktile = static_cast<unsigned>(4LL * 36 * 4 * W4_N);
+    p.yk_plane = 0;
+    p.x_bytes = static_cast<unsigned>(4LL * px * cin);
+    p.u_bytes = static_cast<unsigned>(4LL * 36 * cin * W4_N);
+    p.y_bytes = 0;
+    p.w_head = nullptr; p.head_part = nullptr; p.head_bytes = 0;
+    p.w3 = w3; p.scale3 = scale3; p.shift3 = shift3; p.res3 = residual; p.y3 = y; p.C3 = c3;
+    p.w3_bytes = static_cast<unsigned>(4LL * c3 * W4_N);
+    p.y3_bytes = static_cast<unsigned>(4LL * px * c3);
+    p.debug = 0;
+    void (*kern)(const Wino4Params) = conv3x3_wino4_f32<0, false, true, true>;
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), WINO4_CONV3_LDS, "conv3x3_winograd4_conv3"))
+        return rc;
+    const int cus = mrcnn::device_cu_count();
+    if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd4_conv3: cannot query the device");
+    const int ncu = cus >= 8 ? (cus / 8) * 8 : 8;
+    const long long grid = 8LL * ((p.tiles_m + 7) / 8);
+    const long long launch = grid > ncu ? ncu : grid;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(launch)), dim3(256), WINO4_CONV3_LDS, mrcnn::as_stream(stream), p);
+    return mrcnn::check_launch("conv3x3_wino4_f32<conv3>");
 }

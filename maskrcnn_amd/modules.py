@@ -196,6 +196,10 @@ WINOGRAD4 = os.environ.get("MRCNN_WINOGRAD4", "1") != "0"
 WINOGRAD4_TRUNK = os.environ.get("MRCNN_WINOGRAD4_TRUNK", "1") != "0"   # also the Bottleneck conv2 layers (C2-C4 sizes)
 WINOGRAD4_MIN_TILES = 8
 WINOGRAD4_HEADS_MIN_TILES = 32
+# Bottlenecks with planes = 64 (ResNet C2) whose conv2 takes the F(4x4) kernel: conv3 (1x1 expansion + BN + residual + ReLU)
+# runs inside that kernel's epilogue (ops.conv3x3_winograd4_conv3) — the 64-channel map between them never reaches HBM and
+# one launch per block is gone; bit-identical to the two launches it replaces. MRCNN_FUSED_CONV3=0 keeps them apart.
+FUSED_CONV3 = os.environ.get("MRCNN_FUSED_CONV3", "1") != "0"
 
 
 def winograd4_tiles_per_image(h: int, w: int) -> int:
@@ -345,6 +349,10 @@ class FusedBottleneck:
         oh, ow = -(-x.size(1) // c1.stride), -(-x.size(2) // c1.stride)
         # conv1's output only feeds conv2: written directly in the layout the Winograd kernel reads
         h = c1(x, out="kblocked" if (self.precision == "f32" and c2.takes_winograd(oh, ow)) else "nhwc")
+        if (FUSED_CONV3 and h.dim() == 5 and c2.w.precision == "f32" and c3.w.precision == "f32" and c2.w.shape[0] == 64
+                and c3.w.shape[1:3] == (1, 1) and c3.w.shape[0] % 32 == 0 and c2.relu and c3.relu
+                and c2.w.takes_winograd4(oh, ow, 1, (1, 1, 1, 1), None, True, h.size(1))):
+            return ops.conv3x3_winograd4_conv3(h, c2.w.u4, c2.scale, c2.shift, c3.w.w, c3.scale, c3.shift, res, c2.algo_cin)
         return c3(c2(h), residual=res)
 
 

@@ -1009,6 +1009,37 @@ def conv3x3_winograd4(x_kblocked: torch.Tensor, u4: torch.Tensor, scale, shift, 
 
 
 @_on_device
+def conv3x3_winograd4_conv3(x_kblocked: torch.Tensor, u4: torch.Tensor, scale, shift, w3: torch.Tensor, scale3, shift3,
+                            residual: torch.Tensor, algo_cin=None) -> torch.Tensor:
+    """conv2 + conv3 of a Bottleneck in one launch (model.py:197-209): relu(conv3x3_same(x) * scale + shift) — 64 channels,
+    never written — times the 1x1 expansion w3 [C3,1,1,64], affine (scale3, shift3), + residual [B,H,W,C3], ReLU.
+    x k-blocked [Cin/8,B,H,W,8]; u4 = winograd4_weights of the [64,3,3,Cin] conv2 weight. Equals conv3x3_winograd4 followed
+    by conv_bn_act(..., residual=...) bit for bit."""
+    _need_gpu(x_kblocked, u4, scale, shift, w3, scale3, shift3, residual)
+    assert x_kblocked.dim() == 5 and x_kblocked.is_contiguous() and x_kblocked.dtype == torch.float32
+    g, b, h, w, _ = x_kblocked.shape
+    cin, c3 = g * 8, w3.size(0)
+    assert u4.is_contiguous() and u4.size(0) * 4 == cin and u4.size(3) == 64 and conv3x3_winograd4_supported(h, w, cin, 64, b)
+    assert w3.is_contiguous() and w3.numel() == c3 * 64 and c3 % 32 == 0
+    assert residual.is_contiguous() and tuple(residual.shape) == (b, h, w, c3) and residual.dtype == torch.float32
+    y = torch.empty(b, h, w, c3, dtype=torch.float32, device=x_kblocked.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mrcnn_conv3x3_winograd4_conv3_f32(x_kblocked.data_ptr(), b, h, w, cin, u4.data_ptr(), _ptr(scale), _ptr(shift),
+                                                w3.data_ptr(), c3, _ptr(scale3), _ptr(shift3), residual.data_ptr(),
+                                                y.data_ptr(), _stream()))
+    if prof is not None:
+        e1.record()
+        m, k = b * h * w, 9 * (algo_cin or cin)
+        algo = 2.0 * m * (64 * k + 64 * c3)
+        prof.append((e0, e1, algo, (m, c3, k + 64), 4.0 * (m * cin + 2 * m * c3 + 4 * 64 * k + 64 * c3), "winograd4",
+                     2.0 * m * (64 * k / 4.0 + 64 * c3)))
+    return y
+
+
+@_on_device
 def conv3x3_winograd4_heads(x_kblocked: torch.Tensor, u4: torch.Tensor, scale, shift, w_head32: torch.Tensor,
                             relu: bool = True, algo_cin=None) -> HeadSums:
     """The RPN level in one launch on the F(4x4) kernel: relu(conv3x3_same(x)*scale+shift) and its two 1x1 heads

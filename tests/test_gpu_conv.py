@@ -748,3 +748,37 @@ def test_winograd4_fused_rpn_heads(dev, b, h, w, cout):
     s_a, d_a = ops.rpn_scores_deltas([sums] + small, bh.to(dev))
     s_b, d_b = ops.rpn_scores_deltas([got.to(dev)] + small, bh.to(dev))
     assert torch.equal(s_a, s_b) and torch.equal(d_a, d_b)
+
+
+@pytest.mark.parametrize("b,h,w,cin,c3", [(1, 16, 32, 64, 256), (2, 32, 64, 64, 256), (1, 20, 44, 32, 96), (3, 64, 64, 64, 256),
+                                          (1, 256, 256, 64, 256)])
+def test_winograd4_fused_conv3(dev, b, h, w, cin, c3):
+    """conv2 (F(4x4) Winograd, 64 output channels) + conv3 (1x1 expansion + affine + residual + ReLU) in one launch
+    (model.py:197-209): the 64-channel map stays in the kernel's epilogue. Bit-identical to conv3x3_winograd4 followed by
+    the direct kernel's conv_bn_act with the same residual — one M tile, ragged position blocks (20 x 44), several images,
+    the full C2 size — and within 1e-4 abs of torch-CPU; run to run identical."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(4000 + h + w + c3)
+    x = torch.randn(b, cin, h, w, generator=g)
+    w2 = torch.randn(64, cin, 3, 3, generator=g) * math.sqrt(2.0 / (9 * cin))
+    s2, t2 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    w3 = torch.randn(c3, 64, 1, 1, generator=g) * math.sqrt(2.0 / 64)
+    s3, t3 = torch.rand(c3, generator=g) + 0.5, torch.randn(c3, generator=g) * 0.1
+    res = torch.randn(b, c3, h, w, generator=g)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    xk = ops.nhwc_to_kblocked(nhwc(x))
+    u4 = ops.winograd4_weights(nhwc(w2))
+    w3d, resd = nhwc(w3), nhwc(res)
+    fused = ops.conv3x3_winograd4_conv3(xk, u4, s2.to(dev), t2.to(dev), w3d, s3.to(dev), t3.to(dev), resd)
+    mid = ops.conv3x3_winograd4(xk, u4, s2.to(dev), t2.to(dev), True)
+    two = ops.conv_bn_act(mid, w3d, s3.to(dev), t3.to(dev), relu=True, residual=resd)
+    assert torch.equal(fused, two), f"max diff {(fused - two).abs().max().item():.3e}"
+    assert torch.equal(fused, ops.conv3x3_winograd4_conv3(xk, u4, s2.to(dev), t2.to(dev), w3d, s3.to(dev), t3.to(dev), resd))
+    t = F.relu(F.conv2d(x, w2, padding=1) * s2.view(1, -1, 1, 1) + t2.view(1, -1, 1, 1))
+    want = F.relu(F.conv2d(t, w3) * s3.view(1, -1, 1, 1) + t3.view(1, -1, 1, 1) + res)
+    err = (fused.permute(0, 3, 1, 2).cpu() - want).abs().max().item()
+    assert err <= TOL, f"max abs err {err:.3e} (|ref|max {want.abs().max().item():.2f})"
+    # no scale / shift vectors
+    f0 = ops.conv3x3_winograd4_conv3(xk, u4, None, None, w3d, None, None, resd)
+    m0 = ops.conv3x3_winograd4(xk, u4, None, None, True)
+    assert torch.equal(f0, ops.conv_bn_act(m0, w3d, None, None, relu=True, residual=resd))
