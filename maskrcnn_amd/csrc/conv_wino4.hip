@@ -658,24 +658,34 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                 const lds_f32* trow = t_row(pxl);
                 const int swz = (pxl & 15) << 2;
                 const lds_f32* W3s = smem + W4_W3_OFF + lane * 4;
-                unsigned rowoff[16];   // byte offset of output pixel (row r of the MFMA tile) in y3 / the residual, or OOB
+                // 8-byte accesses on channel pairs (conv_common.hpp, epilogue_pairs): lanes 2c / 2c + 1 hold channels n, n + 1 of
+                // the same 16 rows; after one DPP swap per row pair the even lane owns both channels of rows 0..7 of the 16, the
+                // odd lane both of rows 8..15 — half the residual loads and stores. The value arithmetic is unchanged.
+                const int odd = ln & 1;
+                unsigned rowoff[8];   // byte offset of the lane's k-th output pixel in y3 / the residual, or OOB
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;      // pixel of the round: position pr >> 4, (i, j)
+                for (int k = 0; k < 8; ++k) {
+                    const int pr = wave * 32 + (k & 3) + 8 * (k >> 2) + 4 * lh + 16 * odd;   // pixel of the round: position pr >> 4, (i, j)
                     const int TY = TY0 + g, TX = TX0 + (pr >> 4);
                     const bool ok = TY < p.TH && TX < p.TW;
                     const unsigned pix = static_cast<unsigned>((b * p.H + 4 * TY + ((pr >> 2) & 3)) * p.W + 4 * TX + (pr & 3));
-                    rowoff[r] = ok ? pix * static_cast<unsigned>(p.C3) * 4u : OOB;
+                    rowoff[k] = ok ? pix * static_cast<unsigned>(p.C3) * 4u : OOB;
                 }
                 const int ncb = p.C3 >> 5;
-                auto fetch_res = [&](int cb, float (&res)[16]) {
-                    const unsigned ccol = static_cast<unsigned>(cb * 32 + ln) * 4u;
+                f32x4 afr[8];   // the wave's A fragments (its 32 pixels x all 64 k): read once per round, used by every column block
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        res[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r3_rsrc, static_cast<int>(oob_add(rowoff[r], ccol)), 0, 0));
+                for (int j = 0; j < 8; ++j) afr[j] = *(const lds_f32x4*)(trow + ((j * 8 + lh * 4) ^ swz));
+                auto fetch_res = [&](int cb, float (&res)[16]) {
+                    const unsigned ccol = static_cast<unsigned>(cb * 32 + (ln & ~1)) * 4u;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const auto w = __builtin_amdgcn_raw_buffer_load_b64(r3_rsrc, static_cast<int>(oob_add(rowoff[k], ccol)), 0, 0);
+                        res[2 * k] = __uint_as_float(w[0]);
+                        res[2 * k + 1] = __uint_as_float(w[1]);
+                    }
                 };
                 auto block = [&](int cb, const float (&res)[16], float (&res_next)[16]) {
-                    const unsigned ccol = static_cast<unsigned>(cb * 32 + ln) * 4u;
+                    const unsigned ccol = static_cast<unsigned>(cb * 32 + (ln & ~1)) * 4u;
                     const float sc3 = p.scale3 ? p.scale3[cb * 32 + ln] : 1.0f, sh3 = p.shift3 ? p.shift3[cb * 32 + ln] : 0.0f;
                     if (cb + 1 < ncb) fetch_res(cb + 1, res_next);
                     f32x16 hacc;
@@ -683,7 +693,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                     for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const f32x4 a4 = *(const lds_f32x4*)(trow + ((j * 8 + lh * 4) ^ swz));
+                        const f32x4 a4 = afr[j];
                         const f32x4 b4 = *(const lds_f32x4*)(W3s + (cb * 8 + j) * 256);
                         hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, hacc, 0, 0, 0);
                         hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, hacc, 0, 0, 0);
@@ -691,11 +701,17 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                         hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, hacc, 0, 0, 0);
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = hacc[r] * sc3 + sh3;
-                        v += res[r];
-                        asm("v_max_f32 %0, 0, %0" : "+v"(v));
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y3_rsrc, static_cast<int>(oob_add(rowoff[r], ccol)), 0, 0);
+                    for (int k = 0; k < 8; ++k) {
+                        const float va = hacc[k] * sc3 + sh3;          // own channel, row k
+                        const float vb = hacc[k + 8] * sc3 + sh3;      // own channel, row k + 8
+                        const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, odd ? va : vb),
+                                                                                                 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+                        float lo = odd ? got : va, hi = odd ? vb : got;   // channels n & ~1, (n & ~1) + 1 of the row this lane keeps
+                        lo += res[2 * k];
+                        hi += res[2 * k + 1];
+                        asm("v_max_f32 %0, 0, %0\n\tv_max_f32 %1, 0, %1" : "+v"(lo), "+v"(hi));
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(lo), __float_as_uint(hi)}, y3_rsrc,
+                                                              static_cast<int>(oob_add(rowoff[k], ccol)), 0, 0);
                     }
                 };
                 float r0[16], r1[16];
