@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 11
+#define MRCNN_ABI_VERSION 12
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -211,6 +211,20 @@ int mrcnn_conv_bn_act_nhwc_f16io(const void* x, int32_t x_is_f16, int32_t batch,
 int mrcnn_deconv2x2_bias_act_nhwc_f16io(const void* x_f16, int32_t batch, int32_t height, int32_t width, int32_t cin,
                                         const void* w_f16, int32_t cout, const float* bias4, int32_t activation,
                                         void* y_f16, mrcnn_stream_t stream);
+/* The pipelined form of the plain-fp16 conv for the LARGE layers of configs[4] (csrc/conv_f16p.hip: eight waves, LDS-DMA staging kept
+ * in flight across barriers, v_mfma_f32_16x16x32_f16). Stride 1, fp16 NHWC input, cin % 64 == 0, cout % 256 == 0, kh*kw <= 25,
+ * 0 <= pad_top < kh, 0 <= pad_left < kw; y = act(conv(x, w) * scale + shift + residual) with an optional fp16 residual of the output's
+ * shape, written as fp16 (y_f16) and / or fp32 (y_f32) NHWC — at least one of them non-null (the FPN smoothing convs write both:
+ * fp32 for RoIAlign, fp16 for the RPN). activation 0 none / 1 ReLU. tile_rows: 0 = chosen from (M, cout) and the CU count, or
+ * 128 / 160 / 192 / 256 pixels per workgroup tile (x 256 channels). The result meets conv_bn_act_nhwc_f16io's tolerance; the
+ * fp32 accumulation visits k in a different grouping, so the two are not bitwise equal.
+ * mrcnn_conv_f16_pipelined_supported: 1 when the shape is in range (incl. the 32-bit byte-offset limits), else 0. */
+int mrcnn_conv_f16_pipelined_supported(int32_t batch, int32_t height, int32_t width, int32_t cin, int32_t cout, int32_t kh,
+                                       int32_t kw, int32_t pad_top, int32_t pad_left, int32_t pad_bottom, int32_t pad_right);
+int mrcnn_conv_f16_pipelined(const void* x_f16, int32_t batch, int32_t height, int32_t width, int32_t cin, const void* w_f16,
+                             int32_t cout, int32_t kh, int32_t kw, int32_t pad_top, int32_t pad_left, int32_t pad_bottom,
+                             int32_t pad_right, const float* scale, const float* shift, const void* residual_f16,
+                             int32_t activation, void* y_f16, float* y_f32, int32_t tile_rows, mrcnn_stream_t stream);
 int mrcnn_maxpool_nhwc_f16(const void* x, int32_t batch, int32_t height, int32_t width, int32_t channels,
                            int32_t kernel, int32_t stride, int32_t pad_top, int32_t pad_left, int32_t pad_bottom,
                            int32_t pad_right, void* y, mrcnn_stream_t stream);

@@ -31,6 +31,7 @@ SOURCES = {
     "crop.hip": ["-ffp-contract=off"] + (["-DMRCNN_CROP_STAMPS"] if os.environ.get("MRCNN_CROP_STAMPS") else []),
     "conv.hip": ABL,
     "conv_f16.hip": [],
+    "conv_f16p.hip": [],
     "conv_wino.hip": ABL,
     "conv_wino4.hip": (["-DMRCNN_W4_ABLATIONS"] if (os.environ.get("MRCNN_W4_ABLATIONS") or os.environ.get("MRCNN_ABLATIONS")) else [])
                       + ([f"-DMRCNN_W4_WALK_SHIFT={int(os.environ['MRCNN_W4_WALK_SHIFT'])}"] if os.environ.get("MRCNN_W4_WALK_SHIFT") else []),

@@ -153,7 +153,7 @@ __device__ __forceinline__ void epilogue16(const ConvCommon& p, f32x16 (&acc)[TM
 }
 
 template <int BM, int BN, int WM, int WN, int PRODUCTS, bool GENERIC, int RES, bool IN16 = false, bool OUT16 = false>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f16(const ConvParamsH p) {
+__global__ __launch_bounds__(256, (BM * BN > 128 * 128) ? 1 : 2) void conv_igemm_f16(const ConvParamsH p) {
     static_assert(!(IN16 || OUT16) || PRODUCTS == 1, "fp16 storage is the plain-fp16 mode's");
     static_assert(!(IN16 && GENERIC), "an fp16 input has Cin % 32 == 0");
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -497,6 +497,9 @@ static int run_conv_f16io(const void* x, int32_t x_f16, int32_t batch, int32_t h
     const bool generic = (cin % BK) != 0;
     hipStream_t s = mrcnn::as_stream(stream);
     if (p.Cout <= 64) return launch16<256, 64, 4, 1>(p, generic, x_f16 != 0, y_f16 != 0, s);
+    static const int big = [] { const char* e = getenv("MRCNN_F16_BIG"); return e ? atoi(e) : 0; }();
+    if (big == 1 && p.Cout % 256 == 0 && p.K >= 1024) return launch16<256, 256, 2, 2>(p, generic, x_f16 != 0, y_f16 != 0, s);
+    if (big == 2 && p.Cout % 128 == 0 && p.K >= 1024) return launch16<256, 128, 2, 2>(p, generic, x_f16 != 0, y_f16 != 0, s);
     return launch16<128, 128, 2, 2>(p, generic, x_f16 != 0, y_f16 != 0, s);
 }
 

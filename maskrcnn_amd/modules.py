@@ -209,6 +209,10 @@ def winograd4_tiles_per_image(h: int, w: int) -> int:
 # operand it would have rounded an fp32 tensor to; residual adds, the stem max-pool and the stores see fp16.
 # MRCNN_F16_ACT=0 keeps every activation fp32 (round 1's form of the mode).
 F16_ACT = os.environ.get("MRCNN_F16_ACT", "1") != "0"
+# The large stride-1 layers of the "f16" mode (fp16 NHWC input, Cin % 64 == 0, Cout % 256 == 0) run the pipelined kernel
+# (csrc/conv_f16p.hip: eight waves, LDS-DMA in flight across barriers — 1.4-1.5x the 128x128-tile kernel on the 3x3 layers);
+# MRCNN_F16_PIPELINED=0 keeps them on conv_igemm_f16.
+F16_PIPELINED = os.environ.get("MRCNN_F16_PIPELINED", "1") != "0"
 
 
 class ConvWeight:
@@ -257,10 +261,22 @@ class ConvWeight:
                 and ops.conv3x3_winograd4_supported(h, w, self.shape[3], self.shape[0], batch)
                 and winograd4_tiles_per_image(h, w) >= WINOGRAD4_MIN_TILES)
 
+    def takes_pipelined(self, x, stride=1, pad=(0, 0, 0, 0), relu=False, residual=None, res_div=1, out_f16=False,
+                        out="nhwc"):
+        """Would conv() run the pipelined fp16 kernel (ops.conv_f16_pipelined) for this fp16 NHWC input?"""
+        if not (self.precision == "f16" and F16_PIPELINED and x.dim() == 4 and x.dtype == torch.float16 and stride == 1
+                and relu in (False, True, 0, 1) and out in ("nhwc", "f16+f32")):
+            return False
+        if residual is not None and not (res_div == 1 and residual.dtype == torch.float16 and out_f16 and out == "nhwc"):
+            return False
+        cout, kh, kw, cin = self.w_hi.shape
+        return x.size(3) == cin and ops.conv_f16_pipelined_supported(x.size(0), x.size(1), x.size(2), cin, cout, kh, kw, pad)
+
     def conv(self, x, scale, shift, stride=1, pad=(0, 0, 0, 0), relu=False, residual=None, res_div=1,
              algo_cin=None, out="nhwc", out_f16=False):
         """out: "nhwc" (default), or for the f32 mode "kblocked" / "both" (ops.conv3x3_winograd): the layout the next
-        Winograd conv reads. x may itself be k-blocked (5-d) when this conv takes the Winograd kernel."""
+        Winograd conv reads. x may itself be k-blocked (5-d) when this conv takes the Winograd kernel. "f16" mode only:
+        out="f16+f32" returns the pair (fp16 copy, fp32 copy) of the same result."""
         if self.precision == "f32":
             hh, ww = (x.size(2), x.size(3)) if x.dim() == 5 else (x.size(1), x.size(2))
             if x.dim() == 5 and self.takes_winograd4(hh, ww, stride, pad, residual, relu, x.size(1)):
@@ -270,6 +286,13 @@ class ConvWeight:
             assert x.dim() == 4 and out in ("nhwc", "kblocked")
             return ops.conv_bn_act(x, self.w, scale, shift, stride, pad, relu, residual, res_div, None,
                                    algo_cin, out_kblocked=(out == "kblocked"))
+        if self.takes_pipelined(x, stride, pad, relu, residual, res_div, out_f16, out):
+            return ops.conv_f16_pipelined(x, self.w_hi, scale, shift, pad, bool(relu), residual,
+                                          out_f16=bool(out_f16) or out == "f16+f32", out_f32=(not out_f16) or out == "f16+f32",
+                                          algo_cin=algo_cin)
+        if out == "f16+f32":   # the two copies from one launch are the pipelined kernel's; otherwise one conv + a cast
+            y = self.conv(x, scale, shift, stride, pad, relu, residual, res_div, algo_cin, "nhwc", False)
+            return y.to(torch.float16), y
         assert out == "nhwc"
         return ops.conv_bn_act_f16mfma(x, self.w_hi, self.w_lo, scale, shift, stride, pad, relu, residual,
                                        res_div, 3 if self.precision == "f16x3" else 1, algo_cin,
@@ -442,6 +465,9 @@ class FusedBackbone:
             if sm.w.precision == "f32" and sm.takes_winograd(hh, ww) and sm.w.shape[0] % 8 == 0:
                 # the smoothed map is read by RoIAlign (NHWC) and by the RPN's 3x3 conv (Winograd: k-blocked)
                 y, yk = sm(p, out="both")
+            elif sm.w.precision == "f16" and p.dtype == torch.float16 and F16_PIPELINED:
+                # "f16" mode: RoIAlign reads fp32, the RPN's shared conv an fp16 copy (the operand it would round to anyway)
+                yk, y = sm(p, out="f16+f32")
             else:
                 y, yk = sm(p), None
             outs.append(y)
@@ -451,7 +477,8 @@ class FusedBackbone:
         # image) rather than running a layout pass over the NHWC copy
         p6 = outs[4]
         p6k = None
-        if self.kblocked[3] is not None and p6.size(1) % 2 == 0 and p6.size(2) % 2 == 0 and p6.size(3) % 8 == 0:
+        if (self.kblocked[3] is not None and self.kblocked[3].dim() == 5 and p6.size(1) % 2 == 0 and p6.size(2) % 2 == 0
+                and p6.size(3) % 8 == 0):
             p6k = ops.maxpool(outs[3], 1, 2, out_kblocked=True)
         self.kblocked.append(p6k)
         return outs
@@ -505,6 +532,8 @@ class FusedRPN:
                 return ops.conv3x3_winograd_heads(p_kblocked, self.shared.w.u, self.shared.scale, self.shared.shift,
                                                   self.w_head32, True, self.shared.algo_cin)
             p = p_kblocked
+        if p_kblocked is not None and p_kblocked.dtype == torch.float16 and self.precision == "f16":
+            p = p_kblocked   # "f16" mode: the producer's fp16 NHWC copy of the level
         return self.w_head.conv(self.shared(p), None, self.b_head)   # fp32 out (the shared activation may be fp16)
 
 

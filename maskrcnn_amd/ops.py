@@ -378,6 +378,50 @@ def conv_bn_act_f16mfma(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor 
     return out
 
 
+def conv_f16_pipelined_supported(b: int, h: int, w: int, cin: int, cout: int, kh: int, kw: int, pad=(0, 0, 0, 0)) -> bool:
+    """Shape gate of conv_f16_pipelined (stride 1, Cin % 64 == 0, Cout % 256 == 0, 32-bit byte offsets)."""
+    pt, pl, pb, pr = [int(v) for v in pad]
+    return bool(lib.mrcnn_conv_f16_pipelined_supported(int(b), int(h), int(w), int(cin), int(cout), int(kh), int(kw),
+                                                       pt, pl, pb, pr))
+
+
+@_on_device
+def conv_f16_pipelined(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None, shift: torch.Tensor | None,
+                       pad=(0, 0, 0, 0), relu: bool = False, residual: torch.Tensor | None = None,
+                       out_f16: bool = True, out_f32: bool = False, tile_rows: int = 0, algo_cin: int | None = None):
+    """The pipelined plain-fp16 conv (csrc/conv_f16p.hip) for the large layers of the fp16 path: x fp16 NHWC, w fp16 OHWI,
+    stride 1. Returns the fp16 output, the fp32 output, or the pair (fp16, fp32) when both are asked for."""
+    _need_gpu(x, w, scale, shift, residual)
+    assert x.dtype == torch.float16 and w.dtype == torch.float16 and x.is_contiguous() and w.is_contiguous()
+    assert out_f16 or out_f32
+    b, h, wd, cin = x.shape
+    cout, kh, kw, wcin = w.shape
+    if wcin != cin:
+        raise RuntimeError(f"conv_f16_pipelined: weight Cin {wcin} != input Cin {cin}")
+    pt, pl, pb, pr = [int(v) for v in pad]
+    oh, ow = h + pt + pb - kh + 1, wd + pl + pr - kw + 1
+    y16 = torch.empty(b, oh, ow, cout, dtype=torch.float16, device=x.device) if out_f16 else None
+    y32 = torch.empty(b, oh, ow, cout, dtype=torch.float32, device=x.device) if out_f32 else None
+    if residual is not None:
+        assert residual.dtype == torch.float16 and residual.is_contiguous() and tuple(residual.shape) == (b, oh, ow, cout)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mrcnn_conv_f16_pipelined(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout, kh, kw, pt, pl, pb, pr, _ptr(scale),
+                                       _ptr(shift), _ptr(residual), int(relu), _ptr(y16), _ptr(y32), int(tile_rows),
+                                       _stream()))
+    if prof is not None:
+        e1.record()
+        m, k = b * oh * ow, kh * kw * (algo_cin or cin)
+        nbytes = x.numel() * 2 + (y16.numel() * 2 if out_f16 else 0) + (y32.numel() * 4 if out_f32 else 0) + \
+            (residual.numel() * 2 if residual is not None else 0) + 2 * w.numel()
+        prof.append((e0, e1, 2.0 * m * k * cout, (m, cout, k), nbytes, "f16p"))
+    if out_f16 and out_f32:
+        return y16, y32
+    return y16 if out_f16 else y32
+
+
 def _conv_bn_act_op(x, w, scale, shift, stride, pad, relu, residual, res_div):
     return conv_bn_act(x, w, scale, shift, stride, pad, relu, residual, res_div)
 

@@ -594,6 +594,54 @@ F16IO_CASES = [
 ]
 
 
+F16P_CASES = [
+    # (B, H, W, Cin, Cout, k, pad, relu, residual, out16, out32, tile_rows)
+    (1, 16, 16, 64, 256, 1, (0, 0, 0, 0), True, False, True, False, 0),     # one k tile, M = one tile
+    (1, 16, 16, 128, 256, 1, (0, 0, 0, 0), True, True, True, False, 128),   # two k tiles + fp16 residual
+    (2, 13, 11, 64, 256, 3, (1, 1, 1, 1), True, False, True, True, 160),    # ragged M (286), both outputs, 9 taps
+    (1, 24, 40, 192, 512, 3, (1, 1, 1, 1), False, False, False, True, 192), # odd k-tile count (27), two N tiles, fp32 only
+    (2, 32, 32, 256, 256, 3, (1, 1, 1, 1), True, False, True, False, 256),  # FPN-smoothing shape, 8 M tiles
+    (3, 20, 28, 256, 1024, 1, (0, 0, 0, 0), True, True, True, False, 0),    # bottleneck conv3 shape: 4 N tiles + residual
+    (1, 9, 7, 64, 256, 3, (0, 0, 1, 1), False, False, True, False, 0),      # asymmetric SAME pad (0,0,1,1)
+    (1, 12, 12, 64, 256, 5, (2, 2, 2, 2), False, False, True, False, 0),    # 25 taps
+    (70, 1, 1, 3136, 1024, 1, (0, 0, 0, 0), True, False, True, False, 0),   # GEMM (classifier shape, K = 49 k tiles)
+]
+
+
+@pytest.mark.parametrize("case", F16P_CASES, ids=lambda c: "x".join(str(v) for v in c[:6]) + f"_t{c[-1]}")
+def test_conv_f16_pipelined_vs_torch_cpu(dev, case):
+    """csrc/conv_f16p.hip (eight waves, LDS-DMA across barriers) against an fp32 torch-CPU conv of the fp16-ROUNDED operands:
+    same bar as the fp16-storage kernel above (summation order + one rounding to fp16 for an fp16 output). Every tile height,
+    odd / even k-tile counts, padding taps, ragged M, several N tiles, both output types, and equality of the two outputs
+    up to the fp16 rounding when both are written."""
+    from maskrcnn_amd import ops
+    b, h, w, cin, cout, k, pad, relu, res, o16, o32, rows = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case[:6]) + rows)
+    x = torch.randn(b, cin, h, w, generator=g).half()
+    wt = (torch.randn(cout, cin, k, k, generator=g) * math.sqrt(2.0 / (cin * k * k))).half()
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    oh, ow = h + pad[0] + pad[2] - k + 1, w + pad[1] + pad[3] - k + 1
+    residual = torch.randn(b, cout, oh, ow, generator=g).half() if res else None
+    want = _ref_conv(x.float(), wt.float(), scale, shift, 1, pad, relu, None if residual is None else residual.float(), 1)
+    to_nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    assert ops.conv_f16_pipelined_supported(b, h, w, cin, cout, k, k, pad)
+    got = ops.conv_f16_pipelined(to_nhwc(x), to_nhwc(wt), scale.to(dev), shift.to(dev), pad, relu,
+                                 None if residual is None else to_nhwc(residual), out_f16=o16, out_f32=o32, tile_rows=rows)
+    outs = got if isinstance(got, tuple) else (got,)
+    for y in outs:
+        y16 = y.dtype == torch.float16
+        yc = y.float().permute(0, 3, 1, 2).cpu()
+        tol = 2e-4 + (2.0 ** -11) * want.abs() if y16 else torch.full_like(want, 2e-4)
+        bad = ((yc - want).abs() > tol).sum().item()
+        assert bad == 0, f"{bad} elements off ({y.dtype}); max abs err {(yc - want).abs().max().item():.3e}"
+    if len(outs) == 2:  # the fp16 output is the fp32 output rounded once
+        assert torch.equal(outs[0], outs[1].half())
+    # unsupported shapes are refused, not mis-computed
+    assert not ops.conv_f16_pipelined_supported(b, h, w, cin + 32, cout, k, k, pad)
+    assert not ops.conv_f16_pipelined_supported(b, h, w, cin, cout + 64, k, k, pad)
+
+
 @pytest.mark.parametrize("case", F16IO_CASES, ids=lambda c: "x".join(str(int(v)) for v in c))
 def test_conv_f16_activations_vs_torch_cpu(dev, case):
     """The reference computes in fp32; the fp16-storage path is held to fp16's own resolution: against an fp32 torch-CPU
