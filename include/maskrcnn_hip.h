@@ -126,12 +126,13 @@ int mrcnn_roi_align_pyramid_nhwc_f32(const float* const fm[4], const int32_t fm_
                                      const float* rois, const int32_t* roi_batch, int32_t num_rois,
                                      int32_t rois_per_image, int32_t pool, float image_area,
                                      float* out, int32_t* levels_out, mrcnn_stream_t stream);
-/* The same with a selectable output layout: out_layout = MRCNN_LAYOUT_NHWC (as above) or MRCNN_LAYOUT_KBLOCKED
+/* The same with a selectable output layout: out_layout = MRCNN_LAYOUT_NHWC (as above), MRCNN_LAYOUT_KBLOCKED
  * ([depth/8][num_rois*pool*pool][8], depth % 8 == 0 — what mrcnn_conv3x3_winograd_f32 reads: the mask head's first
- * conv then needs no layout pass). */
+ * conv then needs no layout pass), or MRCNN_LAYOUT_NHWC_F16 (NHWC, each value rounded to fp16 — `out` then points to
+ * fp16 storage: the "f16" mode's heads, whose first conv would round the fp32 values the same way). */
 int mrcnn_roi_align_pyramid_f32(const float* const fm[4], const int32_t fm_h[4], const int32_t fm_w[4], int32_t batch,
                                 int32_t depth, const float* rois, const int32_t* roi_batch, int32_t num_rois,
-                                int32_t rois_per_image, int32_t pool, float image_area, float* out, int32_t out_layout,
+                                int32_t rois_per_image, int32_t pool, float image_area, void* out, int32_t out_layout,
                                 int32_t* levels_out, mrcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -211,20 +212,25 @@ int mrcnn_conv_bn_act_nhwc_f16io(const void* x, int32_t x_is_f16, int32_t batch,
 int mrcnn_deconv2x2_bias_act_nhwc_f16io(const void* x_f16, int32_t batch, int32_t height, int32_t width, int32_t cin,
                                         const void* w_f16, int32_t cout, const float* bias4, int32_t activation,
                                         void* y_f16, mrcnn_stream_t stream);
-/* The pipelined form of the plain-fp16 conv for the LARGE layers of configs[4] (csrc/conv_f16p.hip: eight waves, LDS-DMA staging kept
- * in flight across barriers, v_mfma_f32_16x16x32_f16). Stride 1, fp16 NHWC input, cin % 64 == 0, cout % 256 == 0, kh*kw <= 25,
- * 0 <= pad_top < kh, 0 <= pad_left < kw; y = act(conv(x, w) * scale + shift + residual) with an optional fp16 residual of the output's
- * shape, written as fp16 (y_f16) and / or fp32 (y_f32) NHWC — at least one of them non-null (the FPN smoothing convs write both:
- * fp32 for RoIAlign, fp16 for the RPN). activation 0 none / 1 ReLU. tile_rows: 0 = chosen from (M, cout) and the CU count, or
- * 128 / 160 / 192 / 256 pixels per workgroup tile (x 256 channels). The result meets conv_bn_act_nhwc_f16io's tolerance; the
- * fp32 accumulation visits k in a different grouping, so the two are not bitwise equal.
+/* The pipelined form of the plain-fp16 conv (csrc/conv_f16p.hip: eight waves, LDS-DMA staging kept in flight across barriers,
+ * v_mfma_f32_16x16x32_f16) — what the "f16" mode runs wherever the shape allows. fp16 NHWC input, cin % 64 == 0, cout % 64 == 0,
+ * kh*kw <= 25, any stride, 0 <= pad_top < kh, 0 <= pad_left < kw;
+ *   y = act(conv(x, w) * scale + shift + residual)
+ * with an optional fp16 residual [batch][OH/res_div][OW/res_div][cout], res_div 1 or 2 (2 = FPN nearest-upsample-add, even OH / OW),
+ * written as fp16 (y_f16) and / or fp32 (y_f32) NHWC — at least one of them non-null (the FPN smoothing convs write both: fp32
+ * for RoIAlign, fp16 for the RPN). activation 0 none / 1 ReLU.
+ * tile_rows x tile_cols: 0 = automatic (from M, cout, K and the CU count), or 128 / 160 / 192 / 256 pixels x 256 channels (one
+ * workgroup per CU), or 128 / 256 pixels x 128 / 64 channels (128-pixel ones: two workgroups per CU).
+ * Same operands and k order per output element as mrcnn_conv_bn_act_nhwc_f16io.
  * mrcnn_conv_f16_pipelined_supported: 1 when the shape is in range (incl. the 32-bit byte-offset limits), else 0. */
 int mrcnn_conv_f16_pipelined_supported(int32_t batch, int32_t height, int32_t width, int32_t cin, int32_t cout, int32_t kh,
-                                       int32_t kw, int32_t pad_top, int32_t pad_left, int32_t pad_bottom, int32_t pad_right);
+                                       int32_t kw, int32_t stride, int32_t pad_top, int32_t pad_left, int32_t pad_bottom,
+                                       int32_t pad_right);
 int mrcnn_conv_f16_pipelined(const void* x_f16, int32_t batch, int32_t height, int32_t width, int32_t cin, const void* w_f16,
-                             int32_t cout, int32_t kh, int32_t kw, int32_t pad_top, int32_t pad_left, int32_t pad_bottom,
-                             int32_t pad_right, const float* scale, const float* shift, const void* residual_f16,
-                             int32_t activation, void* y_f16, float* y_f32, int32_t tile_rows, mrcnn_stream_t stream);
+                             int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad_top, int32_t pad_left,
+                             int32_t pad_bottom, int32_t pad_right, const float* scale, const float* shift,
+                             const void* residual_f16, int32_t res_div, int32_t activation, void* y_f16, float* y_f32,
+                             int32_t tile_rows, int32_t tile_cols, mrcnn_stream_t stream);
 int mrcnn_maxpool_nhwc_f16(const void* x, int32_t batch, int32_t height, int32_t width, int32_t channels,
                            int32_t kernel, int32_t stride, int32_t pad_top, int32_t pad_left, int32_t pad_bottom,
                            int32_t pad_right, void* y, mrcnn_stream_t stream);
@@ -295,6 +301,7 @@ int mrcnn_winograd_weights_f32(const float* w, int32_t cout, int32_t cin, float*
  * (a k-blocked output feeds a Winograd conv directly; the FPN laterals read their half-size residual k-blocked); mrcnn_nhwc_to_kblocked_f32 is the standalone transposition. */
 #define MRCNN_LAYOUT_NHWC 0
 #define MRCNN_LAYOUT_KBLOCKED 1
+#define MRCNN_LAYOUT_NHWC_F16 2 /* mrcnn_roi_align_pyramid_f32's output only */
 int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int32_t batch, int32_t height, int32_t width,
                                int32_t cin, const float* u, int32_t cout, const float* scale, const float* shift,
                                int32_t activation, float* y_nhwc, float* y_kblocked, void* workspace,

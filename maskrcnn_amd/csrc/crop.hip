@@ -545,9 +545,14 @@ __global__ __launch_bounds__(256) void roi_align_pyramid_nhwc(
                 v.z = bilerp(tl.z, tr.z, bl.z, br.z, X.lerp, Y.lerp);
                 v.w = bilerp(tl.w, tr.w, bl.w, br.w, X.lerp, Y.lerp);
             }
-            if (out_kblocked)  // [depth/8][num_rois*pool*pool][8]: what the Winograd kernel (mask head conv1) reads
+            if (out_kblocked == 1)  // [depth/8][num_rois*pool*pool][8]: what the Winograd kernel (mask head conv1) reads
                 *reinterpret_cast<float4*>(out + ((c >> 3) * out_pixels + static_cast<int64_t>(r) * points + pt) * 8 + (c & 7)) = v;
-            else
+            else if (out_kblocked == 2) {  // fp16 NHWC (the "f16" mode's heads): the rounding their first conv would apply
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 hv = {static_cast<_Float16>(v.x), static_cast<_Float16>(v.y), static_cast<_Float16>(v.z),
+                               static_cast<_Float16>(v.w)};
+                *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(out) + (static_cast<int64_t>(r) * points + pt) * depth + c) = hv;
+            } else
                 *reinterpret_cast<float4*>(o + static_cast<int64_t>(pt) * depth + c) = v;
         }
     }
@@ -649,13 +654,14 @@ extern "C" int mrcnn_crop_backward_f32(const float* grads, const float* boxes,
 extern "C" int mrcnn_roi_align_pyramid_f32(const float* const fm[4], const int32_t fm_h[4], const int32_t fm_w[4],
                                            int32_t batch, int32_t depth, const float* rois, const int32_t* roi_batch,
                                            int32_t num_rois, int32_t rois_per_image, int32_t pool, float image_area,
-                                           float* out, int32_t out_layout, int32_t* levels_out, mrcnn_stream_t stream) {
+                                           void* out, int32_t out_layout, int32_t* levels_out, mrcnn_stream_t stream) {
     MRCNN_REQUIRE(fm && fm_h && fm_w && rois && out, "roi_align_pyramid: null pointer");
     MRCNN_REQUIRE(batch >= 1 && depth >= 4 && depth % 4 == 0, "roi_align_pyramid: depth=%d must be a multiple of 4", depth);
     MRCNN_REQUIRE(pool >= 1 && pool <= 1024, "roi_align_pyramid: pool=%d", pool);
     MRCNN_REQUIRE(roi_batch || rois_per_image >= 1, "roi_align_pyramid: need roi_batch or rois_per_image");
-    MRCNN_REQUIRE(out_layout == MRCNN_LAYOUT_NHWC || (out_layout == MRCNN_LAYOUT_KBLOCKED && depth % 8 == 0),
-                  "roi_align_pyramid: out_layout must be NHWC, or k-blocked with depth %% 8 == 0");
+    MRCNN_REQUIRE(out_layout == MRCNN_LAYOUT_NHWC || out_layout == MRCNN_LAYOUT_NHWC_F16 ||
+                      (out_layout == MRCNN_LAYOUT_KBLOCKED && depth % 8 == 0),
+                  "roi_align_pyramid: out_layout must be NHWC, NHWC_F16, or k-blocked with depth %% 8 == 0");
     if (num_rois <= 0) return MRCNN_OK;
     PyramidArgs a;
     for (int l = 0; l < 4; ++l) {
@@ -667,7 +673,8 @@ extern "C" int mrcnn_roi_align_pyramid_f32(const float* const fm[4], const int32
     const size_t lds = sizeof(Sample) * 2 * pool;
     hipLaunchKernelGGL(roi_align_pyramid_nhwc, dim3(num_rois), dim3(256), lds,
                        mrcnn::as_stream(stream), a, batch, depth, rois, roi_batch, rois_per_image,
-                       pool, image_area, out, levels_out, out_layout == MRCNN_LAYOUT_KBLOCKED ? 1 : 0,
+                       pool, image_area, static_cast<float*>(out), levels_out,
+                       out_layout == MRCNN_LAYOUT_KBLOCKED ? 1 : out_layout == MRCNN_LAYOUT_NHWC_F16 ? 2 : 0,
                        static_cast<int64_t>(num_rois) * pool * pool);
     return mrcnn::check_launch("roi_align_pyramid_nhwc");
 }

@@ -264,13 +264,16 @@ class ConvWeight:
     def takes_pipelined(self, x, stride=1, pad=(0, 0, 0, 0), relu=False, residual=None, res_div=1, out_f16=False,
                         out="nhwc"):
         """Would conv() run the pipelined fp16 kernel (ops.conv_f16_pipelined) for this fp16 NHWC input?"""
-        if not (self.precision == "f16" and F16_PIPELINED and x.dim() == 4 and x.dtype == torch.float16 and stride == 1
+        if not (self.precision == "f16" and F16_PIPELINED and x.dim() == 4 and x.dtype == torch.float16
                 and relu in (False, True, 0, 1) and out in ("nhwc", "f16+f32")):
             return False
-        if residual is not None and not (res_div == 1 and residual.dtype == torch.float16 and out_f16 and out == "nhwc"):
+        if residual is not None and not (res_div in (1, 2) and residual.dtype == torch.float16 and out_f16 and out == "nhwc"):
             return False
         cout, kh, kw, cin = self.w_hi.shape
-        return x.size(3) == cin and ops.conv_f16_pipelined_supported(x.size(0), x.size(1), x.size(2), cin, cout, kh, kw, pad)
+        if cout < 128:   # the 64-channel layers (C2 conv1 / conv2) are faster on conv_igemm_f16's 256 x 64 tile (measured)
+            return False
+        return x.size(3) == cin and ops.conv_f16_pipelined_supported(x.size(0), x.size(1), x.size(2), cin, cout, kh, kw, pad,
+                                                                     stride)
 
     def conv(self, x, scale, shift, stride=1, pad=(0, 0, 0, 0), relu=False, residual=None, res_div=1,
              algo_cin=None, out="nhwc", out_f16=False):
@@ -289,7 +292,7 @@ class ConvWeight:
         if self.takes_pipelined(x, stride, pad, relu, residual, res_div, out_f16, out):
             return ops.conv_f16_pipelined(x, self.w_hi, scale, shift, pad, bool(relu), residual,
                                           out_f16=bool(out_f16) or out == "f16+f32", out_f32=(not out_f16) or out == "f16+f32",
-                                          algo_cin=algo_cin)
+                                          algo_cin=algo_cin, stride=stride, res_div=res_div)
         if out == "f16+f32":   # the two copies from one launch are the pipelined kernel's; otherwise one conv + a cast
             y = self.conv(x, scale, shift, stride, pad, relu, residual, res_div, algo_cin, "nhwc", False)
             return y.to(torch.float16), y
@@ -554,6 +557,10 @@ class FusedClassifier:
             .float().contiguous().to(device)
         self.num_classes = sd[prefix + "linear_class.weight"].size(0)
 
+    def wants_f16(self) -> bool:
+        """"f16" mode: RoIAlign may hand over fp16 crops (the rounding conv1 would apply to fp32 ones while staging them)."""
+        return self.w1.precision == "f16" and F16_ACT and F16_PIPELINED
+
     def __call__(self, pooled):
         r = pooled.size(0)
         x = self.w1.conv(pooled.view(r, 1, 1, -1), self.s1, self.t1, relu=True, out_f16=self.conv2.out_f16)
@@ -581,6 +588,10 @@ class FusedMask:
         self.b_de = sd[prefix + "deconv.bias"].float().repeat(4).contiguous().to(device)
         self.cout = cout
         self.conv5 = FusedConv(sd, prefix + "conv5", None, device, relu=2, precision=precision, out_f16=False)  # 2 = sigmoid
+
+    def wants_f16(self) -> bool:
+        """"f16" mode: RoIAlign may hand over fp16 crops (what conv1 would round fp32 ones to)."""
+        return self.convs[0].w.precision == "f16" and F16_ACT and F16_PIPELINED
 
     def wants_kblocked(self, pool: int) -> bool:
         """Would the four 3x3 convs run as a k-blocked Winograd chain on [R, pool, pool, 256] crops? Then RoIAlign can

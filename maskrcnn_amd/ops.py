@@ -223,12 +223,13 @@ _LIB.impl("crop", lambda image, *a: _need_gpu(image), "CPU")
 @_on_device
 def roi_align_pyramid(feature_maps, rois: torch.Tensor, pool: int, image_area: float,
                       rois_per_image: int | None = None, roi_batch: torch.Tensor | None = None,
-                      return_levels: bool = False, out_kblocked: bool = False):
+                      return_levels: bool = False, out_kblocked: bool = False, out_f16: bool = False):
     """model.py:276-393 in one launch on channels-last maps.
 
     feature_maps: [P2,P3,P4,P5], each a contiguous fp32 [B, H_l, W_l, C] (NHWC) tensor.
     rois [R,4] normalised. Returns [R, pool, pool, C] (NHWC) in roi order (+ int32 levels); out_kblocked=True returns
-    [C/8, R, pool, pool, 8] instead (the layout conv3x3_winograd reads: no layout pass before the mask head)."""
+    [C/8, R, pool, pool, 8] instead (the layout conv3x3_winograd reads: no layout pass before the mask head); out_f16=True
+    returns the NHWC result rounded to fp16 (the "f16" mode's heads: what their first conv would round the values to)."""
     assert len(feature_maps) == 4
     _need_gpu(rois, roi_batch, *feature_maps)
     rois = rois.contiguous()
@@ -237,8 +238,10 @@ def roi_align_pyramid(feature_maps, rois: torch.Tensor, pool: int, image_area: f
         assert fm.is_contiguous() and fm.dtype == torch.float32 and fm.size(0) == b and fm.size(3) == c
     r = rois.size(0)
     if out_kblocked:
-        assert c % 8 == 0
+        assert c % 8 == 0 and not out_f16
         out = torch.empty(c // 8, r, pool, pool, 8, dtype=torch.float32, device=rois.device)
+    elif out_f16:
+        out = torch.empty(r, pool, pool, c, dtype=torch.float16, device=rois.device)
     else:
         out = torch.empty(r, pool, pool, c, dtype=torch.float32, device=rois.device)
     levels = torch.empty(r, dtype=torch.int32, device=rois.device) if return_levels else None
@@ -249,7 +252,7 @@ def roi_align_pyramid(feature_maps, rois: torch.Tensor, pool: int, image_area: f
         assert roi_batch.dtype == torch.int32 and roi_batch.is_contiguous()
     check(lib.mrcnn_roi_align_pyramid_f32(ptrs, hs, ws, b, c, rois.data_ptr(), _ptr(roi_batch), r,
                                           int(rois_per_image or 0), int(pool), float(image_area), out.data_ptr(),
-                                          1 if out_kblocked else 0, _ptr(levels), _stream()))
+                                          1 if out_kblocked else 2 if out_f16 else 0, _ptr(levels), _stream()))
     return (out, levels) if return_levels else out
 
 
@@ -378,19 +381,21 @@ def conv_bn_act_f16mfma(x: torch.Tensor, w_hi: torch.Tensor, w_lo: torch.Tensor 
     return out
 
 
-def conv_f16_pipelined_supported(b: int, h: int, w: int, cin: int, cout: int, kh: int, kw: int, pad=(0, 0, 0, 0)) -> bool:
-    """Shape gate of conv_f16_pipelined (stride 1, Cin % 64 == 0, Cout % 256 == 0, 32-bit byte offsets)."""
+def conv_f16_pipelined_supported(b: int, h: int, w: int, cin: int, cout: int, kh: int, kw: int, pad=(0, 0, 0, 0),
+                                 stride: int = 1) -> bool:
+    """Shape gate of conv_f16_pipelined (Cin % 64 == 0, Cout % 64 == 0, <= 25 taps, 32-bit byte offsets)."""
     pt, pl, pb, pr = [int(v) for v in pad]
     return bool(lib.mrcnn_conv_f16_pipelined_supported(int(b), int(h), int(w), int(cin), int(cout), int(kh), int(kw),
-                                                       pt, pl, pb, pr))
+                                                       int(stride), pt, pl, pb, pr))
 
 
 @_on_device
 def conv_f16_pipelined(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None, shift: torch.Tensor | None,
                        pad=(0, 0, 0, 0), relu: bool = False, residual: torch.Tensor | None = None,
-                       out_f16: bool = True, out_f32: bool = False, tile_rows: int = 0, algo_cin: int | None = None):
-    """The pipelined plain-fp16 conv (csrc/conv_f16p.hip) for the large layers of the fp16 path: x fp16 NHWC, w fp16 OHWI,
-    stride 1. Returns the fp16 output, the fp32 output, or the pair (fp16, fp32) when both are asked for."""
+                       out_f16: bool = True, out_f32: bool = False, tile_rows: int = 0, algo_cin: int | None = None,
+                       stride: int = 1, res_div: int = 1, tile_cols: int = 0):
+    """The pipelined plain-fp16 conv (csrc/conv_f16p.hip): x fp16 NHWC, w fp16 OHWI, fp16 residual of the output's size
+    (res_div 1) or half of it (res_div 2). Returns the fp16 output, the fp32 output, or the pair (fp16, fp32)."""
     _need_gpu(x, w, scale, shift, residual)
     assert x.dtype == torch.float16 and w.dtype == torch.float16 and x.is_contiguous() and w.is_contiguous()
     assert out_f16 or out_f32
@@ -399,18 +404,19 @@ def conv_f16_pipelined(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | N
     if wcin != cin:
         raise RuntimeError(f"conv_f16_pipelined: weight Cin {wcin} != input Cin {cin}")
     pt, pl, pb, pr = [int(v) for v in pad]
-    oh, ow = h + pt + pb - kh + 1, wd + pl + pr - kw + 1
+    oh, ow = (h + pt + pb - kh) // stride + 1, (wd + pl + pr - kw) // stride + 1
     y16 = torch.empty(b, oh, ow, cout, dtype=torch.float16, device=x.device) if out_f16 else None
     y32 = torch.empty(b, oh, ow, cout, dtype=torch.float32, device=x.device) if out_f32 else None
     if residual is not None:
-        assert residual.dtype == torch.float16 and residual.is_contiguous() and tuple(residual.shape) == (b, oh, ow, cout)
+        assert residual.dtype == torch.float16 and residual.is_contiguous()
+        assert tuple(residual.shape) == (b, oh // res_div, ow // res_div, cout)
     prof = CONV_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.mrcnn_conv_f16_pipelined(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout, kh, kw, pt, pl, pb, pr, _ptr(scale),
-                                       _ptr(shift), _ptr(residual), int(relu), _ptr(y16), _ptr(y32), int(tile_rows),
-                                       _stream()))
+    check(lib.mrcnn_conv_f16_pipelined(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout, kh, kw, int(stride), pt, pl, pb, pr,
+                                       _ptr(scale), _ptr(shift), _ptr(residual), int(res_div), int(relu), _ptr(y16),
+                                       _ptr(y32), int(tile_rows), int(tile_cols), _stream()))
     if prof is not None:
         e1.record()
         m, k = b * oh * ow, kh * kw * (algo_cin or cin)

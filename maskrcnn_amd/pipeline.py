@@ -116,7 +116,8 @@ class MaskRCNNInference:
         rois, roi_counts, rpn_dets = self.proposals(scores, deltas)
         p = rois.size(1)
         flat = rois.reshape(-1, 4).contiguous()
-        pooled = ops.roi_align_pyramid(fms[:4], flat, c.pool_size, self.image_area, rois_per_image=p)
+        pooled = ops.roi_align_pyramid(fms[:4], flat, c.pool_size, self.image_area, rois_per_image=p,
+                                       out_f16=self.classifier.wants_f16())
         logits, bbox = self.classifier(pooled)
         ids, det_scores, boxes, mrois, counts = self.detections(rois, roi_counts, logits, bbox,
                                                                 windows.to(self.device))
@@ -126,7 +127,8 @@ class MaskRCNNInference:
             # the reference divides all four coordinates by h (model.py:1188), which is only right for
             # square inputs; here (y,x) are divided by (h,w)
             mp = ops.roi_align_pyramid(fms[:4], mrois.view(-1, 4), c.mask_pool_size, self.image_area,
-                                       rois_per_image=d, out_kblocked=self.mask.wants_kblocked(c.mask_pool_size))
+                                       rois_per_image=d, out_kblocked=self.mask.wants_kblocked(c.mask_pool_size),
+                                       out_f16=self.mask.wants_f16())
             m = self.mask(mp)
             masks = m.view(b, d, m.size(1), m.size(2), m.size(3))
         det = Detections(ids, det_scores, boxes, counts, masks)

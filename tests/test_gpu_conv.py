@@ -595,39 +595,49 @@ F16IO_CASES = [
 
 
 F16P_CASES = [
-    # (B, H, W, Cin, Cout, k, pad, relu, residual, out16, out32, tile_rows)
-    (1, 16, 16, 64, 256, 1, (0, 0, 0, 0), True, False, True, False, 0),     # one k tile, M = one tile
-    (1, 16, 16, 128, 256, 1, (0, 0, 0, 0), True, True, True, False, 128),   # two k tiles + fp16 residual
-    (2, 13, 11, 64, 256, 3, (1, 1, 1, 1), True, False, True, True, 160),    # ragged M (286), both outputs, 9 taps
-    (1, 24, 40, 192, 512, 3, (1, 1, 1, 1), False, False, False, True, 192), # odd k-tile count (27), two N tiles, fp32 only
-    (2, 32, 32, 256, 256, 3, (1, 1, 1, 1), True, False, True, False, 256),  # FPN-smoothing shape, 8 M tiles
-    (3, 20, 28, 256, 1024, 1, (0, 0, 0, 0), True, True, True, False, 0),    # bottleneck conv3 shape: 4 N tiles + residual
-    (1, 9, 7, 64, 256, 3, (0, 0, 1, 1), False, False, True, False, 0),      # asymmetric SAME pad (0,0,1,1)
-    (1, 12, 12, 64, 256, 5, (2, 2, 2, 2), False, False, True, False, 0),    # 25 taps
-    (70, 1, 1, 3136, 1024, 1, (0, 0, 0, 0), True, False, True, False, 0),   # GEMM (classifier shape, K = 49 k tiles)
+    # (B, H, W, Cin, Cout, k, stride, pad, relu, residual(0/1/2), out16, out32, tile_rows, tile_cols)
+    (1, 16, 16, 64, 256, 1, 1, (0, 0, 0, 0), True, 0, True, False, 0, 0),      # one k tile, M = one tile (auto: 128 x 128)
+    (1, 16, 16, 128, 256, 1, 1, (0, 0, 0, 0), True, 1, True, False, 128, 256), # two k tiles + fp16 residual
+    (2, 13, 11, 64, 256, 3, 1, (1, 1, 1, 1), True, 0, True, True, 160, 256),   # ragged M (286), both outputs, 9 taps
+    (1, 24, 40, 192, 512, 3, 1, (1, 1, 1, 1), False, 0, False, True, 192, 256),  # odd k-tile count (27), two N tiles, fp32 only
+    (2, 32, 32, 256, 256, 3, 1, (1, 1, 1, 1), True, 0, True, False, 256, 256), # FPN-smoothing shape, 8 M tiles
+    (3, 20, 28, 256, 1024, 1, 1, (0, 0, 0, 0), True, 1, True, False, 0, 0),    # bottleneck conv3 shape (K = 256: auto 128 x 128)
+    (3, 20, 28, 256, 1024, 1, 1, (0, 0, 0, 0), True, 1, True, False, 192, 256),  # the same on the large tile
+    (1, 9, 7, 64, 256, 3, 1, (0, 0, 1, 1), False, 0, True, False, 0, 0),       # asymmetric SAME pad (0,0,1,1)
+    (1, 12, 12, 64, 256, 5, 1, (2, 2, 2, 2), False, 0, True, False, 0, 0),     # 25 taps
+    (70, 1, 1, 3136, 1024, 1, 1, (0, 0, 0, 0), True, 0, True, False, 0, 0),    # GEMM (classifier shape, K = 49 k tiles)
+    (2, 26, 22, 256, 128, 1, 2, (0, 0, 0, 0), True, 0, True, False, 0, 0),     # stride 2 (C3 conv1 of a first block), 128 columns
+    (2, 26, 22, 256, 512, 1, 2, (0, 0, 0, 0), False, 0, True, False, 0, 0),    # stride-2 downsample
+    (1, 17, 15, 64, 64, 3, 1, (1, 1, 1, 1), True, 0, True, False, 0, 0),       # C2 conv2: 64 columns (8-byte stores)
+    (2, 12, 20, 128, 128, 3, 1, (1, 1, 1, 1), True, 0, True, False, 256, 128), # C3 conv2 on the 256 x 128 tile
+    (2, 12, 20, 128, 64, 1, 1, (0, 0, 0, 0), True, 1, True, True, 256, 64),    # 256 x 64 tile, residual, both outputs
+    (2, 16, 24, 512, 256, 1, 1, (0, 0, 0, 0), False, 2, True, False, 0, 0),    # FPN lateral + half-size residual
+    (1, 9, 7, 64, 128, 3, 2, (0, 0, 1, 1), True, 0, False, True, 0, 0),        # 3x3 stride 2 with SAME pad (0,0,1,1)
 ]
 
 
-@pytest.mark.parametrize("case", F16P_CASES, ids=lambda c: "x".join(str(v) for v in c[:6]) + f"_t{c[-1]}")
+@pytest.mark.parametrize("case", F16P_CASES, ids=lambda c: "x".join(str(v) for v in c[:7]) + f"_t{c[-2]}x{c[-1]}")
 def test_conv_f16_pipelined_vs_torch_cpu(dev, case):
     """csrc/conv_f16p.hip (eight waves, LDS-DMA across barriers) against an fp32 torch-CPU conv of the fp16-ROUNDED operands:
-    same bar as the fp16-storage kernel above (summation order + one rounding to fp16 for an fp16 output). Every tile height,
-    odd / even k-tile counts, padding taps, ragged M, several N tiles, both output types, and equality of the two outputs
-    up to the fp16 rounding when both are written."""
+    same bar as the fp16-storage kernel below (summation order + one rounding to fp16 for an fp16 output). Every tile shape,
+    odd / even k-tile counts, padding taps, strides, ragged M, several N tiles, both residual forms, both output types, and
+    equality of the two outputs up to the fp16 rounding when both are written."""
     from maskrcnn_amd import ops
-    b, h, w, cin, cout, k, pad, relu, res, o16, o32, rows = case
-    g = torch.Generator().manual_seed(sum(int(v) for v in case[:6]) + rows)
+    b, h, w, cin, cout, k, stride, pad, relu, res, o16, o32, rows, cols = case
+    g = torch.Generator().manual_seed(sum(int(v) for v in case[:7]) + rows + cols)
     x = torch.randn(b, cin, h, w, generator=g).half()
     wt = (torch.randn(cout, cin, k, k, generator=g) * math.sqrt(2.0 / (cin * k * k))).half()
     scale = torch.rand(cout, generator=g) + 0.5
     shift = torch.randn(cout, generator=g) * 0.1
-    oh, ow = h + pad[0] + pad[2] - k + 1, w + pad[1] + pad[3] - k + 1
-    residual = torch.randn(b, cout, oh, ow, generator=g).half() if res else None
-    want = _ref_conv(x.float(), wt.float(), scale, shift, 1, pad, relu, None if residual is None else residual.float(), 1)
+    oh, ow = (h + pad[0] + pad[2] - k) // stride + 1, (w + pad[1] + pad[3] - k) // stride + 1
+    residual = torch.randn(b, cout, oh // res, ow // res, generator=g).half() if res else None
+    want = _ref_conv(x.float(), wt.float(), scale, shift, stride, pad, relu, None if residual is None else residual.float(),
+                     max(res, 1))
     to_nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
-    assert ops.conv_f16_pipelined_supported(b, h, w, cin, cout, k, k, pad)
+    assert ops.conv_f16_pipelined_supported(b, h, w, cin, cout, k, k, pad, stride)
     got = ops.conv_f16_pipelined(to_nhwc(x), to_nhwc(wt), scale.to(dev), shift.to(dev), pad, relu,
-                                 None if residual is None else to_nhwc(residual), out_f16=o16, out_f32=o32, tile_rows=rows)
+                                 None if residual is None else to_nhwc(residual), out_f16=o16, out_f32=o32, tile_rows=rows,
+                                 stride=stride, res_div=max(res, 1), tile_cols=cols)
     outs = got if isinstance(got, tuple) else (got,)
     for y in outs:
         y16 = y.dtype == torch.float16
@@ -638,8 +648,24 @@ def test_conv_f16_pipelined_vs_torch_cpu(dev, case):
     if len(outs) == 2:  # the fp16 output is the fp32 output rounded once
         assert torch.equal(outs[0], outs[1].half())
     # unsupported shapes are refused, not mis-computed
-    assert not ops.conv_f16_pipelined_supported(b, h, w, cin + 32, cout, k, k, pad)
-    assert not ops.conv_f16_pipelined_supported(b, h, w, cin, cout + 64, k, k, pad)
+    assert not ops.conv_f16_pipelined_supported(b, h, w, cin + 32, cout, k, k, pad, stride)
+    assert not ops.conv_f16_pipelined_supported(b, h, w, cin, cout + 32, k, k, pad, stride)
+
+
+def test_conv_f16_pipelined_equals_the_tile_kernel_bitwise(dev):
+    """Same fp16 operands, same k order per output element, fp32 accumulation on both: the pipelined kernel and conv_igemm_f16
+    agree bit for bit (the 'f16' mode gives the same numbers with MRCNN_F16_PIPELINED=0), on every tile shape."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 24, 20, 128, generator=g).half().to(dev)
+    r = torch.randn(2, 24, 20, 256, generator=g).half().to(dev)
+    for k, pad in ((1, (0, 0, 0, 0)), (3, (1, 1, 1, 1))):
+        wt = (torch.randn(256, k, k, 128, generator=g) * math.sqrt(2.0 / (128 * k * k))).half().to(dev)
+        sc, sh = (torch.rand(256, generator=g) + 0.5).to(dev), (torch.randn(256, generator=g) * 0.1).to(dev)
+        ref = ops.conv_bn_act_f16mfma(x, wt, None, sc, sh, 1, pad, True, r, 1, products=1, out_f16=True)
+        for rows, cols in ((128, 256), (160, 256), (192, 256), (256, 256), (128, 128), (256, 128), (128, 64), (256, 64)):
+            got = ops.conv_f16_pipelined(x, wt, sc, sh, pad, True, r, tile_rows=rows, tile_cols=cols)
+            assert torch.equal(got, ref), (k, rows, cols)
 
 
 @pytest.mark.parametrize("case", F16IO_CASES, ids=lambda c: "x".join(str(int(v)) for v in c))

@@ -506,6 +506,9 @@ def test_kblocked_outputs_of_roialign_and_maxpool(dev):
     k = ops.roi_align_pyramid(fms, rois, 14, 128.0 * 160.0, rois_per_image=37, out_kblocked=True)
     assert tuple(k.shape) == (8, 74, 14, 14, 8)
     assert torch.equal(k, ops.nhwc_to_kblocked(a))
+    # fp16 NHWC output (the "f16" mode's heads): the fp32 result rounded once, nothing else
+    h = ops.roi_align_pyramid(fms, rois, 14, 128.0 * 160.0, rois_per_image=37, out_f16=True)
+    assert h.dtype == torch.float16 and torch.equal(h, a.half())
     x = torch.randn(3, 10, 12, 32, generator=g).to(dev)
     for kern, stride, pad in ((1, 2, (0, 0, 0, 0)), (3, 2, (0, 0, 1, 1))):
         assert torch.equal(ops.maxpool(x, kern, stride, pad, out_kblocked=True),

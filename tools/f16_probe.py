@@ -46,6 +46,9 @@ SHAPES = [
     ("C3 conv3 1x1 128->512 +res", 8, 104, 168, 128, 512, 1, True),
     ("C2 conv3 1x1 64->256 +res", 8, 208, 336, 64, 256, 1, True),
     ("fc1 7x7 as 1x1 12544->1024", 1, 80, 100, 12544, 1024, 1, False),
+    ("C3 conv1 1x1 512->128", 8, 104, 168, 512, 128, 1, False),
+    ("C2 conv2 3x3 64->64", 8, 208, 336, 64, 64, 3, False),
+    ("C2 conv1 1x1 256->64", 8, 208, 336, 256, 64, 1, False),
 ]
 
 
@@ -81,13 +84,16 @@ def main():
         print(f"big={tag} {name:30s} M={b*h*w:7d} N={cout:5d} K={cin*k*k:6d}  {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TFLOP/s  {same}",
               flush=True)
         if os.environ.get("F16_PROBE_P8") and ops.conv_f16_pipelined_supported(b, h, w, cin, cout, k, k, pad):
-            for rows in [int(v) for v in os.environ["F16_PROBE_P8"].split(",")]:
-                fp = lambda: ops.conv_f16_pipelined(x, wt, None, None, pad, True, r, True, False, rows)
+            for tile in os.environ["F16_PROBE_P8"].split(","):
+                rows, cols = [int(v) for v in tile.split("x")]
+                if cols and cout % cols:
+                    continue
+                fp = lambda: ops.conv_f16_pipelined(x, wt, None, None, pad, True, r, True, False, rows, tile_cols=cols)
                 yp = fp()
                 torch.cuda.synchronize()
-                err = (yp.float() - y.float()).abs().max().item()
+                same = "bitwise ==" if torch.equal(yp, y) else "DIFFERS from"
                 msp = timeit(fp)
-                print(f"      pipelined rows={rows:3d}: {msp*1e3:8.1f} us  {fl/msp/1e9:7.1f} TFLOP/s  max|diff| vs 128x128 kernel {err:.2e}",
+                print(f"      pipelined {rows:3d}x{cols:3d}: {msp*1e3:8.1f} us  {fl/msp/1e9:7.1f} TFLOP/s  {same} the 128x128 kernel",
                       flush=True)
     print(f"big={tag} total {tot:.3f} ms", flush=True)
 
