@@ -365,6 +365,11 @@ int mrcnn_conv3x3_winograd_nhwc_f32(const float* x, int32_t batch, int32_t heigh
 int mrcnn_stem_conv7x7_s2_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width, const float* w,
                                    const float* scale, const float* shift, int32_t activation, float* y,
                                    mrcnn_stream_t stream);
+/* The same reading the molded image itself, x_nchw [batch][3][H][W] (model.py:1102-1110): no NCHW -> NHWC4 pass over the image
+ * beforehand. w stays [64][7][7][4] (channel 3 zero). Bit-identical to the NHWC form on the converted image. */
+int mrcnn_stem_conv7x7_s2_nchw_f32(const float* x_nchw, int32_t batch, int32_t height, int32_t width, const float* w,
+                                   const float* scale, const float* shift, int32_t activation, float* y,
+                                   mrcnn_stream_t stream);
 
 /* ---- selection steps of the two refine stages (no library sort / top-k / gather in the step) --------------------
  * Total, deterministic order everywhere: descending score, ties by ascending index (ATen's sort, which the

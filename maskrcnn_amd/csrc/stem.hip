@@ -18,7 +18,7 @@ using namespace mrcnn_conv;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct StemParams {
-    const float* x;      // [B][H][W][4]
+    const float* x;      // [B][H][W][4], or the molded image itself [B][3][H][W] (NCHW template variant)
     const float* w;      // [64][7][7][4] (OHWI, channel 3 zero)
     const float* scale;  // [64] or null
     const float* shift;  // [64] or null
@@ -34,6 +34,11 @@ constexpr int PATCH_FLOATS = PS * PITCH * 4;
 constexpr int W_FLOATS = 49 * 64 * 4;
 constexpr size_t STEM_LDS = sizeof(float) * (PATCH_FLOATS + W_FLOATS);
 
+// NCHW: the input is the molded image [B][3][H][W] as the boundary hands it over (model.py:1102-1110): the patch is staged
+// plane by plane with 4-byte loads (consecutive lanes = consecutive x of one plane) into the same [37][37][4] LDS image, whose
+// fourth channel is zeroed once — the separate NCHW -> NHWC4 pass over the image (0.23 ms per batch of eight 1024^2 images)
+// is gone; the values the MFMAs see, and therefore the results, are the same bit for bit.
+template <bool NCHW>
 __global__ __launch_bounds__(256, 2) void stem7x7_s2_f32(const StemParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;              // [49 taps][64 channels][4]
@@ -64,20 +69,44 @@ __global__ __launch_bounds__(256, 2) void stem7x7_s2_f32(const StemParams p) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) b_base[ct] = (ct * 32 + ln) * 4 + lh * 2;
 
+    if constexpr (NCHW) {
+        for (int i = tid; i < PS * PS; i += 256) Pl[i * 4 + 3] = 0.f;
+    }
     for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
         const int b = tile / (p.tiles_y * p.tiles_x), rem = tile - b * p.tiles_y * p.tiles_x;
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
         const int oy0 = ty * TS, ox0 = tx * TS;
         const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
         __syncthreads();  // the previous tile's patch is no longer read (also orders the filter stores on the first trip)
-        for (int i = tid; i < PS * PS; i += 256) {
-            const int py = i / PS, px = i - py * PS;
-            const int iy = iy0 + py, ix = ix0 + px;
-            const bool ok = static_cast<unsigned>(iy) < static_cast<unsigned>(p.H) &&
-                            static_cast<unsigned>(ix) < static_cast<unsigned>(p.W);
-            const unsigned off = ok ? static_cast<unsigned>((b * p.H + iy) * p.W + ix) * 16u : OOB;
-            *reinterpret_cast<u32x4*>(Pl + (py * PITCH + px) * 4) =
-                __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(off), 0, 0);
+        if constexpr (!NCHW) {
+            for (int i = tid; i < PS * PS; i += 256) {
+                const int py = i / PS, px = i - py * PS;
+                const int iy = iy0 + py, ix = ix0 + px;
+                const bool ok = static_cast<unsigned>(iy) < static_cast<unsigned>(p.H) &&
+                                static_cast<unsigned>(ix) < static_cast<unsigned>(p.W);
+                const unsigned off = ok ? static_cast<unsigned>((b * p.H + iy) * p.W + ix) * 16u : OOB;
+                *reinterpret_cast<u32x4*>(Pl + (py * PITCH + px) * 4) =
+                    __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(off), 0, 0);
+            }
+        } else {
+            constexpr int NL = (3 * PS * PS + 255) / 256;  // 17 loads per thread, all issued before the first LDS store
+            unsigned v[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int i = tid + 256 * j;
+                const int c = i / (PS * PS), r = i - c * (PS * PS), py = r / PS, px = r - py * PS;
+                const int iy = iy0 + py, ix = ix0 + px;
+                const bool ok = i < 3 * PS * PS && static_cast<unsigned>(iy) < static_cast<unsigned>(p.H) &&
+                                static_cast<unsigned>(ix) < static_cast<unsigned>(p.W);
+                const unsigned off = ok ? static_cast<unsigned>(((b * 3 + c) * p.H + iy) * p.W + ix) * 4u : OOB;
+                v[j] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, static_cast<int>(off), 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int i = tid + 256 * j;
+                const int c = i / (PS * PS), r = i - c * (PS * PS);
+                if (i < 3 * PS * PS) Pl[r * 4 + c] = __uint_as_float(v[j]);
+            }
         }
         __syncthreads();
 
@@ -127,9 +156,9 @@ __global__ __launch_bounds__(256, 2) void stem7x7_s2_f32(const StemParams p) {
 
 }  // namespace
 
-extern "C" int mrcnn_stem_conv7x7_s2_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
-                                              const float* w, const float* scale, const float* shift,
-                                              int32_t activation, float* y, mrcnn_stream_t stream) {
+namespace {
+int run_stem(bool nchw, const float* x, int32_t batch, int32_t height, int32_t width, const float* w, const float* scale,
+             const float* shift, int32_t activation, float* y, mrcnn_stream_t stream) {
     MRCNN_REQUIRE(x && w && y, "stem: null pointer");
     MRCNN_REQUIRE(batch >= 1 && height >= 2 && width >= 2 && height % 2 == 0 && width % 2 == 0,
                   "stem: B=%d H=%d W=%d (even sizes required)", batch, height, width);
@@ -143,12 +172,27 @@ extern "C" int mrcnn_stem_conv7x7_s2_nhwc_f32(const float* x, int32_t batch, int
     p.tiles_y = (p.OH + TS - 1) / TS;
     p.tiles = batch * p.tiles_x * p.tiles_y;
     p.act = activation;
-    p.x_bytes = static_cast<unsigned>(16LL * batch * height * width);
+    p.x_bytes = static_cast<unsigned>((nchw ? 12LL : 16LL) * batch * height * width);
     p.y_bytes = static_cast<unsigned>(256LL * batch * p.OH * p.OW);
-    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(stem7x7_s2_f32), STEM_LDS, "stem")) return rc;
+    const void* kern = nchw ? reinterpret_cast<const void*>(stem7x7_s2_f32<true>) : reinterpret_cast<const void*>(stem7x7_s2_f32<false>);
+    if (int rc = mrcnn::ensure_dynamic_lds(kern, STEM_LDS, "stem")) return rc;
     const int num_cu = mrcnn::device_cu_count();
     if (num_cu <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "stem: cannot query the device");
     const int grid = p.tiles < 2 * num_cu ? p.tiles : 2 * num_cu;  // persistent: two workgroups per CU
-    hipLaunchKernelGGL(stem7x7_s2_f32, dim3(grid), dim3(256), STEM_LDS, mrcnn::as_stream(stream), p);
+    if (nchw) hipLaunchKernelGGL(stem7x7_s2_f32<true>, dim3(grid), dim3(256), STEM_LDS, mrcnn::as_stream(stream), p);
+    else hipLaunchKernelGGL(stem7x7_s2_f32<false>, dim3(grid), dim3(256), STEM_LDS, mrcnn::as_stream(stream), p);
     return mrcnn::check_launch("stem7x7_s2_f32");
+}
+}  // namespace
+
+extern "C" int mrcnn_stem_conv7x7_s2_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
+                                              const float* w, const float* scale, const float* shift,
+                                              int32_t activation, float* y, mrcnn_stream_t stream) {
+    return run_stem(false, x, batch, height, width, w, scale, shift, activation, y, stream);
+}
+
+extern "C" int mrcnn_stem_conv7x7_s2_nchw_f32(const float* x_nchw, int32_t batch, int32_t height, int32_t width,
+                                              const float* w, const float* scale, const float* shift,
+                                              int32_t activation, float* y, mrcnn_stream_t stream) {
+    return run_stem(true, x_nchw, batch, height, width, w, scale, shift, activation, y, stream);
 }

@@ -437,13 +437,13 @@ class FusedBackbone:
                        for k in (5, 4, 3, 2)}   # RoIAlign reads these
 
     def __call__(self, image_nchw):
-        x = ops.nchw_to_nhwc(image_nchw.contiguous(), self.cin_pad)   # 3 → 4 (8) channels, zero-padded
         st = self.stem                                          # conv7x7 s2 p3 + BN + ReLU
-        if (st.w.precision == "f32" and st.w.shape == (64, 7, 7, 4) and x.size(1) % 2 == 0 and x.size(2) % 2 == 0
-                and STEM_KERNEL):
-            x = ops.stem_conv(x, st.w.w, st.scale, st.shift, True, st.algo_cin)   # dedicated kernel (csrc/stem.hip)
+        if (st.w.precision == "f32" and st.w.shape == (64, 7, 7, 4) and image_nchw.size(2) % 2 == 0
+                and image_nchw.size(3) % 2 == 0 and STEM_KERNEL):
+            # dedicated kernel (csrc/stem.hip), reading the NCHW image itself: no layout pass over the image
+            x = ops.stem_conv(image_nchw.contiguous(), st.w.w, st.scale, st.shift, True, st.algo_cin, nchw=True)
         else:
-            x = st(x)
+            x = st(ops.nchw_to_nhwc(image_nchw.contiguous(), self.cin_pad))   # 3 → 4 (8) channels, zero-padded
         x = ops.maxpool(x, 3, 2, ops.same_pad(x.size(1), x.size(2), 3, 2))
         cs = []
         for blocks in self.stages:

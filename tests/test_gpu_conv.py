@@ -404,6 +404,9 @@ def test_stem_kernel_vs_generic_and_torch(dev):
         assert tuple(y.shape) == (b, h // 2, w // 2, 64)
         assert (y - yd).abs().max().item() <= 2e-5
         assert (y.cpu() - ref).abs().max().item() <= TOL
+        # the NCHW form (what the pipeline runs: the molded image itself, no layout pass) is the same computation
+        yn = ops.stem_conv(x[..., :3].permute(0, 3, 1, 2).contiguous().to(dev), wt.to(dev), sc.to(dev), sh.to(dev), True, nchw=True)
+        assert torch.equal(yn, y)
     # the headline shape, against the generic kernel
     x = torch.randint(0, 256, (2, 1024, 1024, 4), generator=g).float() - 120.0
     x[..., 3] = 0
@@ -413,6 +416,8 @@ def test_stem_kernel_vs_generic_and_torch(dev):
     y = ops.stem_conv(x.to(dev), wt.to(dev), None, sh.to(dev), True)
     yd = ops.conv_bn_act(x.to(dev), wt.to(dev), None, sh.to(dev), 2, (3, 3, 3, 3), True)
     assert (y - yd).abs().max().item() <= 1e-4 * max(1.0, yd.abs().max().item())
+    yn = ops.stem_conv(x[..., :3].permute(0, 3, 1, 2).contiguous().to(dev), wt.to(dev), None, sh.to(dev), True, nchw=True)
+    assert torch.equal(yn, y)
 
 
 # --------------------------------------------------------------------------------------------------
