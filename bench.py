@@ -213,10 +213,18 @@ def op_rooflines(dev, ops):
     ind = torch.zeros(256, dtype=torch.int32, device=dev)
     algo = 256 * 256 * 14 * 14 * 4 + fm.numel() * 4 + 256 * 20
     us = timeit(lambda: ops.crop(fm, boxes, ind, 0.0, 14, 14))
+    # context, not a target: a plain device-to-device copy moving the same number of bytes (half read, half written), timed
+    # the same way — what this box's memory system gives a kernel of this size with no gather in it
+    src = torch.empty(algo // 8, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    copy_us = timeit(lambda: dst.copy_(src))
+    del src, dst
     out.append({"op": "crop_forward_nchw (configs[1]: 256 RoIs x 256 ch x 14x14 on P2)", "bound": "hbm",
                 "kernel": "crop_forward_nchw_staged", "us": round(us, 2), "algorithmic_bytes": algo,
                 "achieved": round(algo / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(algo / us / 1e3 / HBM_PEAK_GBS, 4),
+                "device_copy_of_the_same_bytes_us": round(copy_us, 2),
+                "frac_of_that_copy_rate": round(copy_us / us, 4),
                 "timing": "device time per call, 20 calls replayed from a hipGraph (includes the ~1.5 us kernel boundary)"})
     del fm
     # the same call on the P3..P5 map sizes

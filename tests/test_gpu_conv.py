@@ -583,6 +583,28 @@ def _winograd_fused_rpn_heads(dev, shape):
 # --------------------------------------------------------------------------------------------------
 # fp16 ACTIVATIONS in HBM (plain-fp16 mode, BASELINE config 5's "fp16 MFMA path")
 # --------------------------------------------------------------------------------------------------
+def test_conv_f16_pipelined_full_size_layers_repeat_bitwise(dev):
+    """Race screen for the counted-vmcnt / raw-barrier pipeline: configs[4]-size layers (every CU busy, several tiles per CU,
+    one tile per CU, long K), each run six times — every run equals the 128 x 128 tile kernel's result bit for bit."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    shapes = [  # (B, H, W, Cin, Cout, k, residual)
+        (8, 104, 168, 256, 512, 3, False),   # RPN shared conv on P3: 5 tiles per CU
+        (8, 52, 84, 256, 256, 3, False),     # C4 conv2: one 160-row tile per CU
+        (8, 52, 84, 256, 1024, 1, True),     # C4 conv3: short K + residual
+        (1, 80, 100, 12544, 1024, 1, False), # classifier GEMM: 196 k tiles
+    ]
+    for b, h, w, cin, cout, k, res in shapes:
+        x = torch.randn(b, h, w, cin, generator=g).half().to(dev)
+        wt = (torch.randn(cout, k, k, cin, generator=g) * math.sqrt(2.0 / (cin * k * k))).half().to(dev)
+        r = torch.randn(b, h, w, cout, generator=g).half().to(dev) if res else None
+        pad = (1, 1, 1, 1) if k == 3 else (0, 0, 0, 0)
+        ref = ops.conv_bn_act_f16mfma(x, wt, None, None, None, 1, pad, True, r, 1, products=1, out_f16=True)
+        for _ in range(6):
+            got = ops.conv_f16_pipelined(x, wt, None, None, pad, True, r)
+            assert torch.equal(got, ref), (b, h, w, cin, cout, k)
+
+
 F16IO_CASES = [
     # (B, H, W, Cin, Cout, k, stride, relu, residual(0/1/2), x16, y16)
     (2, 16, 16, 64, 64, 1, 1, True, 0, True, True),
