@@ -231,6 +231,16 @@ int mrcnn_conv_f16_pipelined(const void* x_f16, int32_t batch, int32_t height, i
                              int32_t pad_bottom, int32_t pad_right, const float* scale, const float* shift,
                              const void* residual_f16, int32_t res_div, int32_t activation, void* y_f16, float* y_f32,
                              int32_t tile_rows, int32_t tile_cols, mrcnn_stream_t stream);
+/* The RPN's shared conv with its two 1x1 heads (model.py:605-607,624-641) on the pipelined fp16 kernel, one launch: stride 1,
+ * cout % 256 == 0; act(conv(x, w) * scale + shift) is rounded to fp16 and multiplied, while still in registers, by w_head_f16
+ * [32][cout] (rows 0-17: conv_class then conv_bbox weights, rows 18-31 zero). head_part fp32 [cout / 256][M][32], M = batch * OH *
+ * OW pixels in image order: the sums over each 256-channel tile, without the head bias — for cout = 512 the input form 4 of
+ * mrcnn_rpn_scores_deltas_v2_f32, which adds the two planes and the bias. Fully overwritten. The activation itself is not stored. */
+int mrcnn_conv_f16_pipelined_heads(const void* x_f16, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                   const void* w_f16, int32_t cout, int32_t kh, int32_t kw, int32_t pad_top, int32_t pad_left,
+                                   int32_t pad_bottom, int32_t pad_right, const float* scale, const float* shift,
+                                   int32_t activation, const void* w_head_f16, float* head_part, int32_t tile_rows,
+                                   mrcnn_stream_t stream);
 int mrcnn_maxpool_nhwc_f16(const void* x, int32_t batch, int32_t height, int32_t width, int32_t channels,
                            int32_t kernel, int32_t stride, int32_t pad_top, int32_t pad_left, int32_t pad_bottom,
                            int32_t pad_right, void* y, mrcnn_stream_t stream);
@@ -263,7 +273,9 @@ int mrcnn_rpn_scores_deltas_f32(const float* const heads[5], const int32_t level
 /* The same with a per-level input form (level_mode[l]): 0 = NHWC [batch][H_l][W_l][18] head outputs as above;
  * 1 / 2 = the head sums of mrcnn_conv3x3_winograd_heads_f32 in tile mode 1 / 2: [2][rows][32] fp32 in that function's row
  * order, bias not yet added: logits/deltas = (sum of the two k halves) + head_bias[c]; 3 = the head sums of
- * mrcnn_conv3x3_winograd4_heads_f32: [rows][32], logits/deltas = sum + head_bias[c]. level_h/level_w: H_l, W_l. */
+ * mrcnn_conv3x3_winograd4_heads_f32: [rows][32], logits/deltas = sum + head_bias[c]; 4 = the two planes of
+ * mrcnn_conv_f16_pipelined_heads (cout = 512): [2][batch*H_l*W_l][32] in pixel order, (plane 0 + plane 1) + head_bias[c].
+ * level_h/level_w: H_l, W_l. */
 int mrcnn_rpn_scores_deltas_v2_f32(const float* const heads[5], const int32_t level_h[5], const int32_t level_w[5],
                                    const int32_t level_mode[5], const float* head_bias, int32_t batch, float* scores,
                                    float* deltas, mrcnn_stream_t stream);

@@ -53,6 +53,8 @@ _SIGS = {
     "mrcnn_conv_f16_pipelined": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
                                                   c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32,
                                                   c_i32, c_vp]),
+    "mrcnn_conv_f16_pipelined_heads": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                                        c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
     "mrcnn_maxpool_nhwc_f16": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                                 c_vp, c_vp]),
     "mrcnn_deconv2x2_bias_act_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32,

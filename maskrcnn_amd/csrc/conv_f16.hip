@@ -141,6 +141,10 @@ __device__ __forceinline__ void epilogue16(const ConvCommon& p, f32x16 (&acc)[TM
                     v0 = v0 > 0.f ? v0 : 0.f;
                     v1 = v1 > 0.f ? v1 : 0.f;
                 }
+                // fp32 first, then ONE rounding to fp16 (the compiler otherwise folds multiply-add and conversion into
+                // v_fma_mixlo_f16 in some instantiations and not in others: 1 fp16 ulp apart on a few values per 100 000 —
+                // conv_f16p.hip pins the same sequence, so the two kernels agree bit for bit)
+                asm volatile("" : "+v"(v0), "+v"(v1));
                 const unsigned h0 = __builtin_bit_cast(unsigned short, static_cast<_Float16>(v0));
                 const unsigned h1 = __builtin_bit_cast(unsigned short, static_cast<_Float16>(v1));
                 const unsigned keep = odd ? h1 : h0, got = swap_pair(odd ? h0 : h1);

@@ -40,6 +40,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr int P8_MAX_TAPS = 25;
@@ -52,6 +53,8 @@ struct P8Params {
     const _Float16* residual;  // [B][OH/res_div][OW/res_div][Cout] fp16 or null
     _Float16* y16;             // fp16 output or null
     float* y32;                // fp32 output or null
+    const _Float16* w_head;    // HEADS: [32][Cout] fp16 (rows 0-17: the RPN's conv_class then conv_bbox weights, the rest zero)
+    float* head_part;          // HEADS: [Cout / 256][M][32] fp32 head sums, one plane per 256-channel tile
     int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
     int M, K, nk;              // M = B*OH*OW, K = KH*KW*Cin, nk = K / 64
     int relu, res_div;
@@ -104,8 +107,15 @@ struct P8Geom {
     static constexpr int WGS = (2 * LDS <= 160 * 1024 && TMW * NWT <= 8) ? 2 : 1;  // workgroups per CU (LDS and <= 128 registers)
 };
 
-template <int TMW, int NWT, bool RES>
+// HEADS (the RPN's shared conv with its two 1x1 heads, model.py:605-607,624-641, in one launch): the ReLU'd fp16 tile is not
+// stored. A lane's eight consecutive channels of a pixel ARE a B-operand fragment of v_mfma_f32_16x16x32_f16 (lane = (pixel
+// column l16, k chunk q)), so each wave multiplies its 64 channels by the [32][64] slice of the head weights straight out of
+// registers (4 MFMAs per pixel tile), the four waves of a pixel row add their partial sums through LDS in a fixed order, and
+// the workgroup writes [256 pixels][32] fp32 sums of its 256-channel tile; the consumer (mrcnn_rpn_scores_deltas_v2_f32, form
+// 4) adds the Cout / 256 planes and the bias. The 512-channel activation never reaches HBM.
+template <int TMW, int NWT, bool RES, bool HEADS = false>
 __global__ __launch_bounds__(512, (P8Geom<TMW, NWT>::WGS)) void conv_f16p(const P8Params p) {
+    static_assert(!HEADS || (NWT == 4 && !RES), "the heads epilogue belongs to the 256-channel tile without a residual");
     using G = P8Geom<TMW, NWT>;
     constexpr int BM = G::BM;
     constexpr int T0 = (TMW + 1) / 2, T1 = TMW - T0;  // pixel tiles of a wave's two phases
@@ -295,6 +305,54 @@ __global__ __launch_bounds__(512, (P8Geom<TMW, NWT>::WGS)) void conv_f16p(const 
             sc[h][e] = p.scale ? p.scale[cb + h * 32 + e] : 1.0f;
             sh[h][e] = p.shift ? p.shift[cb + h * 32 + e] : 0.0f;
         }
+    if constexpr (HEADS) {
+        const __amdgpu_buffer_rsrc_t wh_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<_Float16*>(p.w_head), 0, 32u * static_cast<unsigned>(p.Cout) * 2u, 0x00020000);
+        f16x8 wh[2][2];  // [head tile][32-channel half]: lane = (head l16 of the tile, k chunk lq)
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                wh[ht][h] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                    wh_rsrc, static_cast<int>(((ht * 16 + l16) * p.Cout + cb + h * 32) * 2), 0, 0));
+        // this wave's partial sums go to LDS as [pixel 0 .. 16 TMW)[32 heads] fp32 (the operand buffers are dead: every read
+        // of them was retired before the barriers above)
+        lds_u8* red = smem + wave * (TMW * 16 * 128);
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            f32x4 hacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f16x8 xb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = acc[i][2 * h + (e >> 2)][e & 3] * sc[h][e] + sh[h][e];
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    asm volatile("" : "+v"(v));  // an fp32 value rounded ONCE to fp16, exactly as the storing epilogue does
+                    xb[e] = static_cast<_Float16>(v);
+                }
+#pragma unroll
+                for (int ht = 0; ht < 2; ++ht) hacc[ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ht][h], xb, hacc[ht], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht)  // heads ht*16 + 4 lq + {0..3} of pixel i*16 + l16
+                *(lds_f32x4*)(red + ((i * 16 + l16) * 32 + ht * 16 + lq * 4) * 4) = hacc[ht];
+        }
+        __syncthreads();
+        const int nt = n0 >> 8;
+        for (int item = threadIdx.x; item < BM * 8; item += 512) {
+            const int px = item >> 3, hq = item & 7;
+            const int g = px / (16 * TMW), pl = px - g * (16 * TMW);
+            const lds_u8* src = smem + (g * 4) * (TMW * 16 * 128) + (pl * 32 + hq * 4) * 4;
+            const f32x4 s0 = *(const lds_f32x4*)(src), s1 = *(const lds_f32x4*)(src + TMW * 16 * 128);
+            const f32x4 s2 = *(const lds_f32x4*)(src + 2 * TMW * 16 * 128), s3 = *(const lds_f32x4*)(src + 3 * TMW * 16 * 128);
+            const f32x4 sum = ((s0 + s1) + s2) + s3;  // fixed order: deterministic
+            const int m = m0 + px;
+            if (m < p.M)
+                *reinterpret_cast<f32x4*>(p.head_part + (static_cast<size_t>(nt) * p.M + m) * 32 + hq * 4) = sum;
+        }
+        return;
+    }
     const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16*>(p.residual), 0, RES ? p.r_elems * 2u : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t y16_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y16, 0, p.y16 ? p.y_elems * 2u : 0u, 0x00020000);
@@ -349,6 +407,11 @@ __global__ __launch_bounds__(512, (P8Geom<TMW, NWT>::WGS)) void conv_f16p(const 
 #pragma unroll
                 for (int e = 0; e < CW; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             }
+            // the fp32 value is materialised before it is rounded to fp16: without this the compiler folds multiply-add and
+            // conversion into v_fma_mixlo_f16 in SOME instantiations (one rounding instead of two: 1 fp16 ulp apart on a few
+            // values per 100 000), and the heads epilogue / conv_igemm_f16 would not see the same activation bits
+#pragma unroll
+            for (int e = 0; e < CW; ++e) asm volatile("" : "+v"(v[e]));
             const unsigned eoff = erow[i] + h * 32;
             if (p.y16) {
                 const unsigned off = eok[i] ? eoff * 2u : OOB;
@@ -408,6 +471,19 @@ int launch_p8r(P8Params p, hipStream_t s) {
     if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv_f16p<TMW, NWT, RES>), G::LDS, "conv_f16p")) return rc;
     hipLaunchKernelGGL((conv_f16p<TMW, NWT, RES>), dim3(static_cast<unsigned>(grid)), dim3(512), G::LDS, s, p);
     return mrcnn::check_launch("conv_f16p");
+}
+
+template <int TMW>
+int launch_p8_heads(P8Params p, hipStream_t s) {
+    using G = P8Geom<TMW, 4>;
+    p.tiles_m = (p.M + G::BM - 1) / G::BM;
+    p.tiles_n = p.Cout / G::BN;
+    const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
+    if (grid > 0x7fffffffLL) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv_f16p: grid too large");
+    static_assert(8 * TMW * 16 * 128 <= G::LDS, "the partial head sums fit the operand buffers");
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv_f16p<TMW, 4, false, true>), G::LDS, "conv_f16p")) return rc;
+    hipLaunchKernelGGL((conv_f16p<TMW, 4, false, true>), dim3(static_cast<unsigned>(grid)), dim3(512), G::LDS, s, p);
+    return mrcnn::check_launch("conv_f16p<heads>");
 }
 
 template <int TMW, int NWT>
@@ -507,4 +583,50 @@ extern "C" int mrcnn_conv_f16_pipelined(const void* x_f16, int32_t batch, int32_
     return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT,
                        "conv_f16_pipelined: tile must be 0 (auto), rows 128 / 160 / 192 / 256 x 256 columns, or rows 128 / 256 x "
                        "128 / 64 columns (got %d x %d)", tile_rows, tile_cols);
+}
+
+extern "C" int mrcnn_conv_f16_pipelined_heads(const void* x_f16, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                              const void* w_f16, int32_t cout, int32_t kh, int32_t kw, int32_t pad_top,
+                                              int32_t pad_left, int32_t pad_bottom, int32_t pad_right, const float* scale,
+                                              const float* shift, int32_t activation, const void* w_head_f16,
+                                              float* head_part, int32_t tile_rows, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x_f16 && w_f16 && w_head_f16 && head_part, "conv_f16_pipelined_heads: null pointer");
+    MRCNN_REQUIRE(activation == 0 || activation == 1, "conv_f16_pipelined_heads: activation must be 0 (none) or 1 (ReLU)");
+    if (cout % 256 != 0 || !mrcnn_conv_f16_pipelined_supported(batch, height, width, cin, cout, kh, kw, 1, pad_top, pad_left,
+                                                               pad_bottom, pad_right))
+        return mrcnn::fail(MRCNN_ERR_UNSUPPORTED,
+                           "conv_f16_pipelined_heads: needs Cin %% 64 == 0, Cout %% 256 == 0, <= 25 taps, 0 <= pads < kernel, "
+                           "32-bit byte offsets (got %dx%dx%dx%d -> %d, %dx%d)", batch, height, width, cin, cout, kh, kw);
+    P8Params p{};
+    p.x = static_cast<const _Float16*>(x_f16);
+    p.w = static_cast<const _Float16*>(w_f16);
+    p.scale = scale;
+    p.shift = shift;
+    p.w_head = static_cast<const _Float16*>(w_head_f16);
+    p.head_part = head_part;
+    p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw; p.stride = 1;
+    p.pad_t = pad_top; p.pad_l = pad_left;
+    p.OH = height + pad_top + pad_bottom - kh + 1;
+    p.OW = width + pad_left + pad_right - kw + 1;
+    p.M = batch * p.OH * p.OW;
+    p.K = kh * kw * cin;
+    p.nk = p.K / 64;
+    p.relu = activation;
+    p.res_div = 1;
+    p.x_bytes = static_cast<unsigned>(static_cast<long long>(batch) * height * width * cin * 2);
+    p.w_bytes = static_cast<unsigned>(static_cast<long long>(cout) * p.K * 2);
+    p.x_bias = static_cast<unsigned>((pad_top * width + pad_left) * cin * 2);
+    p.y_elems = static_cast<unsigned>(static_cast<long long>(p.M) * cout);
+    p.r_elems = p.y_elems;
+    const int cus = mrcnn::device_cu_count() > 0 ? mrcnn::device_cu_count() : 256;
+    const int tmw = tile_rows ? tile_rows / 32 : pick_rows(p.M, cout, cus);
+    hipStream_t s = mrcnn::as_stream(stream);
+    switch (tmw) {
+        case 4: return launch_p8_heads<4>(p, s);
+        case 5: return launch_p8_heads<5>(p, s);
+        case 6: return launch_p8_heads<6>(p, s);
+        case 8: return launch_p8_heads<8>(p, s);
+        default: break;
+    }
+    return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "conv_f16_pipelined_heads: tile_rows must be 0 (auto), 128, 160, 192 or 256");
 }

@@ -267,6 +267,8 @@ __global__ __launch_bounds__(256) void rpn_scores_deltas(RpnLevels lv, int B, in
             int64_t row;
             if (lv.mode[l] == 1) {  // 64 consecutive positions per M tile: plain position-major order
                 row = ((static_cast<int64_t>(b) * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * 4 + (y & 1) * 2 + (x & 1);
+            } else if (lv.mode[l] == 4) {  // plain pixel order (the fp16 pipelined conv's head sums), two planes
+                row = static_cast<int64_t>(b) * lv.hw[l] + pix;
             } else if (lv.mode[l] == 2) {  // 8 x 8 position blocks: M-tile-major
                 const int ty = y >> 1, tx = x >> 1, tyb = ((H >> 1) + 7) >> 3, txb = ((W >> 1) + 7) >> 3;
                 const int64_t mt = (static_cast<int64_t>(b) * tyb + (ty >> 3)) * txb + (tx >> 3);
@@ -348,10 +350,12 @@ extern "C" int mrcnn_rpn_scores_deltas_v2_f32(const float* const heads[5], const
         MRCNN_REQUIRE(heads[l] && level_h[l] >= 1 && level_w[l] >= 1, "rpn_scores_deltas: bad level %d", l);
         MRCNN_REQUIRE(level_mode[l] == 0 ||
                           ((level_mode[l] == 1 || level_mode[l] == 2) && head_bias && level_h[l] % 2 == 0 && level_w[l] % 2 == 0) ||
-                          (level_mode[l] == 3 && head_bias && level_h[l] % 4 == 0 && level_w[l] % 4 == 0),
+                          (level_mode[l] == 3 && head_bias && level_h[l] % 4 == 0 && level_w[l] % 4 == 0) ||
+                          (level_mode[l] == 4 && head_bias),
                       "rpn_scores_deltas: level %d: mode must be 0 (NHWC heads), 1 or 2 (head sums of "
                       "mrcnn_conv3x3_winograd_heads_f32 in tile mode 1 / 2: even H, W and a bias vector) or 3 (head sums "
-                      "of mrcnn_conv3x3_winograd4_heads_f32: H, W multiples of 4 and a bias vector)", l);
+                      "of mrcnn_conv3x3_winograd4_heads_f32: H, W multiples of 4 and a bias vector) or 4 (the two planes of "
+                      "mrcnn_conv_f16_pipelined_heads for 512 channels, pixel order; a bias vector)", l);
         lv.y[l] = heads[l];
         lv.hw[l] = level_h[l] * level_w[l];
         lv.w[l] = level_w[l];
@@ -362,6 +366,8 @@ extern "C" int mrcnn_rpn_scores_deltas_v2_f32(const float* const heads[5], const
             lv.rows[l] = static_cast<int>(((t + 63) / 64) * 256);  // == mrcnn_conv3x3_winograd_heads_rows(.., 1)
         } else if (level_mode[l] == 2) {
             lv.rows[l] = batch * ((level_h[l] / 2 + 7) / 8) * ((level_w[l] / 2 + 7) / 8) * 256;
+        } else if (level_mode[l] == 4) {
+            lv.rows[l] = batch * level_h[l] * level_w[l];
         }
         lv.first[l] = a;
         a += lv.hw[l] * 3;

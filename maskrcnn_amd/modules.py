@@ -213,6 +213,9 @@ F16_ACT = os.environ.get("MRCNN_F16_ACT", "1") != "0"
 # (csrc/conv_f16p.hip: eight waves, LDS-DMA in flight across barriers — 1.4-1.5x the 128x128-tile kernel on the 3x3 layers);
 # MRCNN_F16_PIPELINED=0 keeps them on conv_igemm_f16.
 F16_PIPELINED = os.environ.get("MRCNN_F16_PIPELINED", "1") != "0"
+# the RPN heads run inside that kernel on levels of at least this many pixels PER IMAGE (never a function of the batch: the two
+# forms round differently, and image i of a batch must equal image i alone); below it the 18-channel conv is a launch of its own
+F16_HEADS_MIN_PIXELS = int(os.environ.get("MRCNN_F16_HEADS_MIN_PIXELS", "4096"))
 
 
 class ConvWeight:
@@ -515,6 +518,11 @@ class FusedRPN:
                 w32 = torch.zeros(32, w.size(1), dtype=torch.float32)
                 w32[:w.size(0)] = w.float().view(w.size(0), -1)
                 self.w_head32 = w32.contiguous().to(device)
+            if precision == "f16" and F16_PIPELINED and RPN_FUSED_HEADS and w.size(1) == 512:
+                # "f16" mode: heads inside the pipelined fp16 kernel's epilogue (levels whose map arrives as fp16)
+                w16 = torch.zeros(32, w.size(1), dtype=torch.float16)
+                w16[:w.size(0)] = w.float().view(w.size(0), -1).to(torch.float16)
+                self.w_head16 = w16.contiguous().to(device)
 
     def __call__(self, p, p_kblocked=None):
         """p: a pyramid level NHWC; p_kblocked: the same map k-blocked, when the producer wrote it (f32 Winograd mode)."""
@@ -537,6 +545,12 @@ class FusedRPN:
             p = p_kblocked
         if p_kblocked is not None and p_kblocked.dtype == torch.float16 and self.precision == "f16":
             p = p_kblocked   # "f16" mode: the producer's fp16 NHWC copy of the level
+            sh = self.shared
+            pad = sh.pad_for(p.size(1), p.size(2))
+            if (getattr(self, "w_head16", None) is not None and sh.w.takes_pipelined(p, 1, pad, True, None, 1, True)
+                    and p.size(1) * p.size(2) >= F16_HEADS_MIN_PIXELS):
+                return ops.conv_f16_pipelined_heads(p, sh.w.w_hi, sh.scale, sh.shift, self.w_head16, pad, True,
+                                                    algo_cin=sh.algo_cin)
         return self.w_head.conv(self.shared(p), None, self.b_head)   # fp32 out (the shared activation may be fp16)
 
 

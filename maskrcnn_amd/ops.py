@@ -428,6 +428,35 @@ def conv_f16_pipelined(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | N
     return y16 if out_f16 else y32
 
 
+@_on_device
+def conv_f16_pipelined_heads(x: torch.Tensor, w: torch.Tensor, scale, shift, w_head32: torch.Tensor, pad=(1, 1, 1, 1),
+                             relu: bool = True, tile_rows: int = 0, algo_cin: int | None = None) -> "HeadSums":
+    """RPN conv_shared + both 1x1 heads in one launch on the pipelined fp16 kernel ("f16" mode; model.py:605-607,624-641):
+    x fp16 NHWC, w fp16 OHWI with Cout = 512, w_head32 fp16 [32, 512] (rows 0-17: conv_class then conv_bbox). → HeadSums
+    (form 4: two planes in pixel order, without the bias)."""
+    _need_gpu(x, w, scale, shift, w_head32)
+    assert x.dtype == torch.float16 and w.dtype == torch.float16 and x.is_contiguous() and w.is_contiguous()
+    b, h, wd, cin = x.shape
+    cout, kh, kw, wcin = w.shape
+    assert wcin == cin and cout == 512, "the consumer (rpn_scores_deltas form 4) adds exactly two 256-channel planes"
+    assert w_head32.dtype == torch.float16 and w_head32.is_contiguous() and tuple(w_head32.shape) == (32, cout)
+    pt, pl, pb, pr = [int(v) for v in pad]
+    oh, ow = h + pt + pb - kh + 1, wd + pl + pr - kw + 1
+    part = torch.empty(cout // 256, b * oh * ow, 32, dtype=torch.float32, device=x.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mrcnn_conv_f16_pipelined_heads(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout, kh, kw, pt, pl, pb, pr,
+                                             _ptr(scale), _ptr(shift), 1 if relu else 0, w_head32.data_ptr(),
+                                             part.data_ptr(), int(tile_rows), _stream()))
+    if prof is not None:
+        e1.record()
+        m, k = b * oh * ow, kh * kw * (algo_cin or cin)
+        prof.append((e0, e1, 2.0 * m * cout * (k + 18), (m, cout, k), x.numel() * 2 + part.numel() * 4 + 2 * w.numel(), "f16p"))
+    return HeadSums(part, b, oh, ow, 4)
+
+
 def _conv_bn_act_op(x, w, scale, shift, stride, pad, relu, residual, res_div):
     return conv_bn_act(x, w, scale, shift, stride, pad, relu, residual, res_div)
 
@@ -596,6 +625,8 @@ class HeadSums:
     def to_nhwc(self, bias: torch.Tensor) -> torch.Tensor:
         """[B,H,W,18] = (half 0 + half 1) + bias, in image order (tests / debugging; the pipeline never needs it)."""
         b, h, w = self.batch, self.height, self.width
+        if self.tile_mode == 4:                                            # two planes in pixel order (conv_f16_pipelined_heads)
+            return ((self.part[0, :, :18] + self.part[1, :, :18]) + bias).view(b, h, w, 18).contiguous()
         th, tw = h // 2, w // 2
         if self.tile_mode == 1:
             t = b * th * tw

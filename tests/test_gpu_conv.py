@@ -605,6 +605,46 @@ def test_conv_f16_pipelined_full_size_layers_repeat_bitwise(dev):
             assert torch.equal(got, ref), (b, h, w, cin, cout, k)
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 16, 64, 0), (2, 26, 22, 256, 0), (1, 40, 56, 256, 160), (3, 32, 48, 128, 256)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_f16_pipelined_heads_vs_two_launches(dev, shape):
+    """The RPN's shared conv with both 1x1 heads inside the pipelined fp16 kernel against the two launches it replaces (the
+    fp16 shared activation, then the 18-channel head conv on fp16 operands): the same fp16 activation values meet the same
+    fp16 head weights, only the fp32 summation is grouped differently (per 64 channels, then four partials, then two planes).
+    Also through the consumer: scores / deltas from the head sums == from the NHWC heads to that tolerance, and the result
+    does not depend on the tile height or on the batch (image i alone == slice i)."""
+    from maskrcnn_amd import ops
+    b, h, w, cin, rows = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(b, h, w, cin, generator=g).half().to(dev)
+    wt = (torch.randn(512, 3, 3, cin, generator=g) * math.sqrt(2.0 / (9 * cin))).half().to(dev)
+    sc, sh = (torch.rand(512, generator=g) + 0.5).to(dev), (torch.randn(512, generator=g) * 0.1).to(dev)
+    wh = torch.randn(18, 512, generator=g) * math.sqrt(1.0 / 512)
+    bh = (torch.randn(18, generator=g) * 0.1).to(dev)
+    wh32 = torch.zeros(32, 512)
+    wh32[:18] = wh
+    wh16 = wh32.half().to(dev)
+    fused = ops.conv_f16_pipelined_heads(x, wt, sc, sh, wh16, (1, 1, 1, 1), True, tile_rows=rows)
+    assert fused.tile_mode == 4 and tuple(fused.part.shape) == (2, b * h * w, 32)
+    got = fused.to_nhwc(bh)
+    shared = ops.conv_f16_pipelined(x, wt, sc, sh, (1, 1, 1, 1), True)                       # fp16 activation
+    want = ops.conv_bn_act_f16mfma(shared, wh.half().view(18, 1, 1, 512).contiguous().to(dev), None, None, bh, 1,
+                                   (0, 0, 0, 0), False, None, 1, products=1, out_f16=False)
+    scale = max(1.0, want.abs().max().item())
+    assert (got - want).abs().max().item() <= 2e-5 * scale, (got - want).abs().max().item()
+    assert torch.equal(fused.part[:, :, 18:], torch.zeros_like(fused.part[:, :, 18:]))       # the padded head columns
+    # tile height and batch do not change a bit
+    for r2 in (128, 192):
+        assert torch.equal(ops.conv_f16_pipelined_heads(x, wt, sc, sh, wh16, (1, 1, 1, 1), True, tile_rows=r2).part, fused.part)
+    one = ops.conv_f16_pipelined_heads(x[b - 1:].contiguous(), wt, sc, sh, wh16, (1, 1, 1, 1), True)
+    assert torch.equal(one.part, fused.part[:, (b - 1) * h * w:])
+    # the consumer
+    lv = [torch.randn(b, max(h >> i, 1), max(w >> i, 1), 18, generator=g).to(dev) for i in (1, 2, 3, 4)]
+    s0, d0 = ops.rpn_scores_deltas([got] + lv)
+    s1, d1 = ops.rpn_scores_deltas([fused] + lv, bh)
+    assert torch.equal(s0, s1) and torch.equal(d0, d1)
+
+
 F16IO_CASES = [
     # (B, H, W, Cin, Cout, k, stride, relu, residual(0/1/2), x16, y16)
     (2, 16, 16, 64, 64, 1, 1, True, 0, True, True),
