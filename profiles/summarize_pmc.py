@@ -35,7 +35,8 @@ def base(name):
 
 
 def mfma_cycles(kernel):
-    return 32 if "f16" in kernel else 64
+    # issue cycles per SIMD: v_mfma_f32_16x16x32_f16 (conv_f16p) 16, v_mfma_f32_32x32x16_f16 32, v_mfma_f32_32x32x2_f32 64
+    return 16 if "conv_f16p" in kernel else 32 if "f16" in kernel else 64
 
 
 def read(path):
@@ -83,7 +84,7 @@ def cmd_mfma(path, meta):
                      "mfma_util": round(v["insts_x_cycles"] / (SIMDS * v["cycles"]), 4)} for b, v in agg.items()}
     tot_i = sum(v["insts_x_cycles"] for v in agg.values())
     tot_c = sum(v["cycles"] for v in agg.values())
-    return dict(meta, definition="mfma_util = SQ_INSTS_MFMA x issue cycles (64 fp32 / 32 fp16 MFMA) / (1024 SIMDs x "
+    return dict(meta, definition="mfma_util = SQ_INSTS_MFMA x issue cycles (64: fp32 32x32x2; 32: fp16 32x32x16; 16: fp16 16x16x32) / (1024 SIMDs x "
                                  "GRBM_GUI_ACTIVE / 8); launches summed per kernel over one step",
                 all_mfma_kernels={"mfma_util": round(tot_i / (SIMDS * tot_c), 4), "kernel_cycles_per_step": tot_c / steps},
                 by_kernel=dict(sorted(by_kernel.items(), key=lambda kv: -kv[1]["kernel_cycles_per_step"])),
