@@ -382,6 +382,11 @@ int mrcnn_stem_conv7x7_s2_nhwc_f32(const float* x, int32_t batch, int32_t height
 int mrcnn_stem_conv7x7_s2_nchw_f32(const float* x_nchw, int32_t batch, int32_t height, int32_t width, const float* w,
                                    const float* scale, const float* shift, int32_t activation, float* y,
                                    mrcnn_stream_t stream);
+/* The same with the output stored as fp16 NHWC (the "f16" mode's trunk input): fp32 products and accumulation as above, one
+ * rounding at the store. */
+int mrcnn_stem_conv7x7_s2_nchw_f16out(const float* x_nchw, int32_t batch, int32_t height, int32_t width, const float* w,
+                                      const float* scale, const float* shift, int32_t activation, void* y_f16,
+                                      mrcnn_stream_t stream);
 
 /* ---- selection steps of the two refine stages (no library sort / top-k / gather in the step) --------------------
  * Total, deterministic order everywhere: descending score, ties by ascending index (ATen's sort, which the

@@ -38,7 +38,9 @@ constexpr size_t STEM_LDS = sizeof(float) * (PATCH_FLOATS + W_FLOATS);
 // plane by plane with 4-byte loads (consecutive lanes = consecutive x of one plane) into the same [37][37][4] LDS image, whose
 // fourth channel is zeroed once — the separate NCHW -> NHWC4 pass over the image (0.23 ms per batch of eight 1024^2 images)
 // is gone; the values the MFMAs see, and therefore the results, are the same bit for bit.
-template <bool NCHW>
+// OUT16: the output is stored as fp16 (the "f16" mode: the products stay exact fp32, one rounding at the store): adjacent lanes
+// (adjacent channels) swap one value per pixel pair by DPP and each stores a 4-byte channel pair.
+template <bool NCHW, bool OUT16 = false>
 __global__ __launch_bounds__(256, 2) void stem7x7_s2_f32(const StemParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wl = smem;              // [49 taps][64 channels][4]
@@ -135,22 +137,54 @@ __global__ __launch_bounds__(256, 2) void stem7x7_s2_f32(const StemParams p) {
                                                                           s == 0 ? bw[ct].x : bw[ct].y, acc[pt][ct], 0, 0, 0);
         }
         // epilogue: accumulator row r of pixel tile pt = pixel (r&3) + 8*(r>>2) + 4*lh of the tile's 32
+        if constexpr (!OUT16) {
 #pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
+            for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int oy = oy0 + 4 * wave + 2 * pt + (q >> 4), ox = ox0 + (q & 15);
-                const bool ok = oy < p.OH && ox < p.OW;
-                const unsigned row = static_cast<unsigned>((b * p.OH + oy) * p.OW + ox) * 256u;
+                for (int r = 0; r < 16; ++r) {
+                    const int q = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int oy = oy0 + 4 * wave + 2 * pt + (q >> 4), ox = ox0 + (q & 15);
+                    const bool ok = oy < p.OH && ox < p.OW;
+                    const unsigned row = static_cast<unsigned>((b * p.OH + oy) * p.OW + ox) * 256u;
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    float v = acc[pt][ct][r] * sc[ct] + sh[ct];
-                    if (p.act) v = v > 0.f ? v : 0.f;
-                    const unsigned o = ok ? row + static_cast<unsigned>(ct * 32 + ln) * 4u : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(o), 0, 0);
+                    for (int ct = 0; ct < 2; ++ct) {
+                        float v = acc[pt][ct][r] * sc[ct] + sh[ct];
+                        if (p.act) v = v > 0.f ? v : 0.f;
+                        const unsigned o = ok ? row + static_cast<unsigned>(ct * 32 + ln) * 4u : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(o), 0, 0);
+                    }
                 }
-            }
+        } else {
+            const bool odd = ln & 1;
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    // rows 2 rp and 2 rp + 1 are neighbouring pixels; the even lane stores the first, the odd lane the second
+                    const int r0 = 2 * rp, rmine = r0 + (odd ? 1 : 0);
+                    const int q = (rmine & 3) + 8 * (rmine >> 2) + 4 * lh;
+                    const int oy = oy0 + 4 * wave + 2 * pt + (q >> 4), ox = ox0 + (q & 15);
+                    const bool ok = oy < p.OH && ox < p.OW;
+                    const unsigned row = static_cast<unsigned>((b * p.OH + oy) * p.OW + ox) * 128u;
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        float v0 = acc[pt][ct][r0] * sc[ct] + sh[ct], v1 = acc[pt][ct][r0 + 1] * sc[ct] + sh[ct];
+                        if (p.act) {
+                            v0 = v0 > 0.f ? v0 : 0.f;
+                            v1 = v1 > 0.f ? v1 : 0.f;
+                        }
+                        asm volatile("" : "+v"(v0), "+v"(v1));  // fp32 first, then one rounding to fp16
+                        const unsigned h0 = __builtin_bit_cast(unsigned short, static_cast<_Float16>(v0));
+                        const unsigned h1 = __builtin_bit_cast(unsigned short, static_cast<_Float16>(v1));
+                        const unsigned keep = odd ? h1 : h0;
+                        const unsigned got = static_cast<unsigned>(
+                            __builtin_amdgcn_update_dpp(0, static_cast<int>(odd ? h0 : h1), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+                        const unsigned word = odd ? (got | (keep << 16)) : (keep | (got << 16));
+                        const unsigned o = ok ? row + static_cast<unsigned>(ct * 32 + (ln & ~1)) * 2u : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(word, y_rsrc, static_cast<int>(o), 0, 0);
+                    }
+                }
+        }
     }
 }
 
@@ -158,7 +192,8 @@ __global__ __launch_bounds__(256, 2) void stem7x7_s2_f32(const StemParams p) {
 
 namespace {
 int run_stem(bool nchw, const float* x, int32_t batch, int32_t height, int32_t width, const float* w, const float* scale,
-             const float* shift, int32_t activation, float* y, mrcnn_stream_t stream) {
+             const float* shift, int32_t activation, float* y, mrcnn_stream_t stream, bool out16 = false) {
+    MRCNN_REQUIRE(!out16 || nchw, "stem: the fp16-output form reads the NCHW image");
     MRCNN_REQUIRE(x && w && y, "stem: null pointer");
     MRCNN_REQUIRE(batch >= 1 && height >= 2 && width >= 2 && height % 2 == 0 && width % 2 == 0,
                   "stem: B=%d H=%d W=%d (even sizes required)", batch, height, width);
@@ -173,13 +208,15 @@ int run_stem(bool nchw, const float* x, int32_t batch, int32_t height, int32_t w
     p.tiles = batch * p.tiles_x * p.tiles_y;
     p.act = activation;
     p.x_bytes = static_cast<unsigned>((nchw ? 12LL : 16LL) * batch * height * width);
-    p.y_bytes = static_cast<unsigned>(256LL * batch * p.OH * p.OW);
-    const void* kern = nchw ? reinterpret_cast<const void*>(stem7x7_s2_f32<true>) : reinterpret_cast<const void*>(stem7x7_s2_f32<false>);
+    p.y_bytes = static_cast<unsigned>((out16 ? 128LL : 256LL) * batch * p.OH * p.OW);
+    const void* kern = out16 ? reinterpret_cast<const void*>(stem7x7_s2_f32<true, true>)
+                     : nchw ? reinterpret_cast<const void*>(stem7x7_s2_f32<true>) : reinterpret_cast<const void*>(stem7x7_s2_f32<false>);
     if (int rc = mrcnn::ensure_dynamic_lds(kern, STEM_LDS, "stem")) return rc;
     const int num_cu = mrcnn::device_cu_count();
     if (num_cu <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "stem: cannot query the device");
     const int grid = p.tiles < 2 * num_cu ? p.tiles : 2 * num_cu;  // persistent: two workgroups per CU
-    if (nchw) hipLaunchKernelGGL(stem7x7_s2_f32<true>, dim3(grid), dim3(256), STEM_LDS, mrcnn::as_stream(stream), p);
+    if (out16) hipLaunchKernelGGL((stem7x7_s2_f32<true, true>), dim3(grid), dim3(256), STEM_LDS, mrcnn::as_stream(stream), p);
+    else if (nchw) hipLaunchKernelGGL(stem7x7_s2_f32<true>, dim3(grid), dim3(256), STEM_LDS, mrcnn::as_stream(stream), p);
     else hipLaunchKernelGGL(stem7x7_s2_f32<false>, dim3(grid), dim3(256), STEM_LDS, mrcnn::as_stream(stream), p);
     return mrcnn::check_launch("stem7x7_s2_f32");
 }
@@ -195,4 +232,10 @@ extern "C" int mrcnn_stem_conv7x7_s2_nchw_f32(const float* x_nchw, int32_t batch
                                               const float* w, const float* scale, const float* shift,
                                               int32_t activation, float* y, mrcnn_stream_t stream) {
     return run_stem(true, x_nchw, batch, height, width, w, scale, shift, activation, y, stream);
+}
+
+extern "C" int mrcnn_stem_conv7x7_s2_nchw_f16out(const float* x_nchw, int32_t batch, int32_t height, int32_t width,
+                                                 const float* w, const float* scale, const float* shift,
+                                                 int32_t activation, void* y_f16, mrcnn_stream_t stream) {
+    return run_stem(true, x_nchw, batch, height, width, w, scale, shift, activation, static_cast<float*>(y_f16), stream, true);
 }

@@ -428,6 +428,9 @@ class FusedBackbone:
         self.cin_pad = 4 if precision == "f32" else 8   # 16-byte pixels (fp32 path) / 8-half chunks (fp16 path)
         self.stem = FusedConv(sd, prefix + "C1.0", prefix + "C1.1", device, stride=2, relu=True,
                               pad=(3, 3, 3, 3), cin_pad=self.cin_pad, precision=precision)
+        # "f16" mode: the stem runs the dedicated fp32 kernel too (exact fp32 products on the NCHW image, fp16 store): the
+        # generic fp16 kernel on the 8-channel-padded image plus its layout pass cost more than the fp32 MFMAs do
+        self.stem_w32 = pack_weight(sd[prefix + "C1.0.weight"], device, 4) if (precision == "f16" and F16_ACT) else None
         self.stages = []
         for name, n, stride in (("C2", l[0], 1), ("C3", l[1], 2), ("C4", l[2], 2), ("C5", l[3], 2)):
             self.stages.append([FusedBottleneck.from_state_dict(sd, f"{prefix}{name}.{i}",
@@ -445,6 +448,10 @@ class FusedBackbone:
                 and image_nchw.size(3) % 2 == 0 and STEM_KERNEL):
             # dedicated kernel (csrc/stem.hip), reading the NCHW image itself: no layout pass over the image
             x = ops.stem_conv(image_nchw.contiguous(), st.w.w, st.scale, st.shift, True, st.algo_cin, nchw=True)
+        elif (self.stem_w32 is not None and STEM_KERNEL and F16_PIPELINED and image_nchw.size(2) % 2 == 0
+              and image_nchw.size(3) % 2 == 0):
+            x = ops.stem_conv(image_nchw.contiguous(), self.stem_w32, st.scale, st.shift, True, st.algo_cin, nchw=True,
+                              out_f16=True)
         else:
             x = st(ops.nchw_to_nhwc(image_nchw.contiguous(), self.cin_pad))   # 3 → 4 (8) channels, zero-padded
         x = ops.maxpool(x, 3, 2, ops.same_pad(x.size(1), x.size(2), 3, 2))

@@ -1150,7 +1150,7 @@ def conv3x3_winograd4_heads(x_kblocked: torch.Tensor, u4: torch.Tensor, scale, s
 
 @_on_device
 def stem_conv(x: torch.Tensor, w: torch.Tensor, scale, shift, relu: bool = True, algo_cin: int | None = None,
-              nchw: bool = False):
+              nchw: bool = False, out_f16: bool = False):
     """The ResNet stem: conv 7x7 stride 2 pad 3 + affine + ReLU. x NHWC [B,H,W,4] (RGB + zero channel) — or, with nchw=True,
     the molded image itself [B,3,H,W] (no layout pass beforehand; same result bit for bit) —, w OHWI [64,7,7,4] → [B,H/2,W/2,64]."""
     _need_gpu(x, w, scale, shift)
@@ -1160,15 +1160,17 @@ def stem_conv(x: torch.Tensor, w: torch.Tensor, scale, shift, relu: bool = True,
         b, _, h, wd = x.shape
     else:
         b, h, wd, _ = x.shape
-    y = torch.empty(b, h // 2, wd // 2, 64, dtype=torch.float32, device=x.device)
+    assert nchw or not out_f16, "the fp16-output form reads the NCHW image"
+    y = torch.empty(b, h // 2, wd // 2, 64, dtype=torch.float16 if out_f16 else torch.float32, device=x.device)
     prof = CONV_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    fn = lib.mrcnn_stem_conv7x7_s2_nchw_f32 if nchw else lib.mrcnn_stem_conv7x7_s2_nhwc_f32
+    fn = lib.mrcnn_stem_conv7x7_s2_nchw_f16out if out_f16 else \
+        lib.mrcnn_stem_conv7x7_s2_nchw_f32 if nchw else lib.mrcnn_stem_conv7x7_s2_nhwc_f32
     check(fn(x.data_ptr(), b, h, wd, w.data_ptr(), _ptr(scale), _ptr(shift), 1 if relu else 0, y.data_ptr(), _stream()))
     if prof is not None:
         e1.record()
         m, k = y.numel() // 64, 49 * (algo_cin or 4)
-        prof.append((e0, e1, 2.0 * m * 64 * k, (m, 64, k), 4.0 * (x.numel() + y.numel() + w.numel()), "stem"))
+        prof.append((e0, e1, 2.0 * m * 64 * k, (m, 64, k), 4.0 * (x.numel() + w.numel()) + y.numel() * y.element_size(), "stem"))
     return y

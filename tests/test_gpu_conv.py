@@ -407,6 +407,10 @@ def test_stem_kernel_vs_generic_and_torch(dev):
         # the NCHW form (what the pipeline runs: the molded image itself, no layout pass) is the same computation
         yn = ops.stem_conv(x[..., :3].permute(0, 3, 1, 2).contiguous().to(dev), wt.to(dev), sc.to(dev), sh.to(dev), True, nchw=True)
         assert torch.equal(yn, y)
+        # the fp16-output form ("f16" mode): the fp32 result rounded once
+        yh = ops.stem_conv(x[..., :3].permute(0, 3, 1, 2).contiguous().to(dev), wt.to(dev), sc.to(dev), sh.to(dev), True, nchw=True,
+                           out_f16=True)
+        assert yh.dtype == torch.float16 and torch.equal(yh, y.half())
     # the headline shape, against the generic kernel
     x = torch.randint(0, 256, (2, 1024, 1024, 4), generator=g).float() - 120.0
     x[..., 3] = 0
