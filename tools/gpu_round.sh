@@ -29,7 +29,7 @@ if [[ "$WHAT" == *" bench "* ]]; then
     tail -c 600 $OUT/bench_n1.json
 fi
 if [[ "$WHAT" == *" stats "* ]]; then
-    step stats 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --cpu-images 0 --alt-precision none > $OUT/kt.json 2> $OUT/kt.err
+    step stats 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --cpu-images 0 --alt-precision none --in-flight 1 > $OUT/kt.json 2> $OUT/kt.err
     find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
     find $OUT/kt -name "*_kernel_trace.csv" -delete   # large; the stats summary is what is kept
 fi
