@@ -84,7 +84,59 @@ def calibrate_heads_(sd, make_net, images, windows):
     return net
 
 
-def conv_roofline(prof, args, H, W, modules):
+def measure_traffic_in_run(args, H, W):
+    """HBM / fabric bytes per kernel of ONE step of this workload, measured in this run: two rocprofv3 counter passes
+    (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`: separate passes, `--kernel-trace` only, as MI355X_MICROARCH.md prescribes) over
+    `tools/profile_step.py` — the same step, weights and inputs — as CHILD processes, summarised by profiles/summarize_pmc.py
+    (KiB -> bytes, FETCH_SIZE doubled on gfx950). Must run BEFORE this process touches the GPU (a child is fork + exec).
+    Returns (summary dict | None, reason)."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process already runs under a profiler"
+    tmp = tempfile.mkdtemp(prefix="mrcnn_pmc_", dir="/tmp")
+    found = {}
+    try:
+        for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            d = os.path.join(tmp, name)
+            os.makedirs(d)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "profile_step.py"), "--steps", "1", "--batch", str(args.batch),
+                   "--arch", args.arch, "--height", str(H), "--width", str(W), "--proposals", str(args.proposals),
+                   "--precision", args.precision, "--meta", os.path.join(d, "meta.json")]
+            t0 = time.perf_counter()
+            with open(os.path.join(d, "log.txt"), "w") as lf:
+                rc = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=lf, stderr=lf,
+                                    timeout=args.traffic_timeout).returncode
+            if rc != 0:
+                with open(os.path.join(d, "log.txt")) as lf:
+                    tail = lf.read()[-400:]
+                return None, f"rocprofv3 --pmc {ctr} exited {rc}: {tail!r}"
+            csvs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+            if not csvs or not os.path.exists(os.path.join(d, "meta.json")):
+                return None, f"rocprofv3 --pmc {ctr}: no counter_collection.csv"
+            found[name] = csvs[0]
+            log(f"[bench] traffic pass {ctr}: {time.perf_counter() - t0:.1f} s")
+        spec = importlib.util.spec_from_file_location("_summarize_pmc", os.path.join(ROOT, "profiles", "summarize_pmc.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        with open(os.path.join(tmp, "fetch", "meta.json")) as fh:
+            meta = json.load(fh)
+        return mod.cmd_traffic(found["fetch"], found["write"], meta), "measured"
+    except subprocess.TimeoutExpired:
+        return None, f"a counter pass exceeded {args.traffic_timeout} s"
+    except Exception as e:  # a profiler problem never costs the GPU number
+        return None, f"failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def conv_roofline(prof, args, H, W, modules, measured=None, measured_reason=None):
     """prof: ops.CONV_PROFILE rows (start event, end event, algorithmic FLOPs = 2*M*N*K of the convolution, (M,N,K),
     algorithmic bytes = every operand/result tensor once, kernel tag) of `args.roofline_steps` steps."""
     steps = args.roofline_steps
@@ -133,9 +185,16 @@ def conv_roofline(prof, args, H, W, modules):
             json.dump(rows, fh, indent=0)
     # HBM traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, summarised per kernel by
     # profiles/summarize_pmc.py into a file that records the mode it was taken in; anything else → null
-    traffic, traffic_src = None, None
+    traffic, traffic_src, in_run, conv_traffic = None, None, False, None
+    if measured is not None:   # this run's own counter passes (measure_traffic_in_run)
+        k = measured.get("per_kernel", {}).get(kernel_of.get(dominant, dominant))
+        if k and k.get("launches_per_step") == dom["launches_per_step"]:
+            traffic, traffic_src, in_run = k["hbm_bytes_per_step"], "rocprofv3 --pmc passes run by this bench.py invocation", True
+            conv_traffic = measured.get("conv_path_hbm_bytes_per_step")
+        else:
+            measured_reason = f"launch count of the counter pass ({k and k.get('launches_per_step')}) != this run's"
     tpath = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
-    if os.path.exists(tpath):
+    if traffic is None and os.path.exists(tpath):
         try:
             with open(tpath) as fh:
                 tj = json.load(fh)
@@ -164,10 +223,16 @@ def conv_roofline(prof, args, H, W, modules):
             "avg_launch_us": dom["avg_launch_us"],
             "algorithmic_tflops": dom["algorithmic_tflops"],
             "algorithmic_speedup": round(dom["algorithmic_tflops"] / dom["executed_tflops"], 3),
-            "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_this_run": False,
-            "traffic_note": "fabric bytes of this kernel's launches of one step from the committed rocprofv3 passes (--pmc "
-                            "FETCH_SIZE x2 + WRITE_SIZE, separate passes of tools/profile_step.py): NOT measured in this run; "
-                            "null unless the profile's mode flags, launch count and csrc/ source hash equal this run's",
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_this_run": in_run,
+            "traffic_conv_path": conv_traffic,
+            "traffic_note": ("fabric bytes of this kernel's launches of one step: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
+                             "--pmc WRITE_SIZE, two separate counter passes over tools/profile_step.py (the same step, weights "
+                             "and inputs) started by this bench.py run before its timed region"
+                             if in_run else
+                             "fabric bytes of this kernel's launches of one step from the committed rocprofv3 passes (--pmc "
+                             "FETCH_SIZE x2 + WRITE_SIZE, separate passes of tools/profile_step.py): NOT measured in this run"
+                             f" ({measured_reason}); null unless the profile's mode flags, launch count and csrc/ source hash "
+                             "equal this run's"),
             "algorithmic_bytes": dom["algorithmic_bytes_per_step"],
             "conv_path": dict(whole, conv_gflop_per_image=round(sum(r[2] for r in prof) / steps / args.batch / 1e9, 1)),
             "by_kernel": by_tag}
@@ -311,9 +376,20 @@ def main():
                     help="comma-separated contraction modes also timed after the headline (none | f32 | f16x3 | f16 | f32+f16x3); "
                          "the first is reported under alt_precision, all of them under alt_precisions")
     ap.add_argument("--dump-conv", default=None, help="write per-launch conv (M,N,K,ms,TFLOP/s) JSON here")
+    ap.add_argument("--measure-traffic", type=int, default=1,
+                    help="N=1 only: measure roofline.traffic in this run (two rocprofv3 --pmc child passes of tools/profile_step.py, "
+                         "about a minute); 0 = report the committed profile's figure instead")
+    ap.add_argument("--traffic-timeout", type=int, default=300, help="seconds allowed per counter pass")
     ap.add_argument("--alt-config5", type=int, default=1,
                     help="also time BASELINE configs[4]'s geometry (R101-FPN, 832x1344, fp16 MFMA path) on this GPU, N=1 only")
     args = ap.parse_args()
+
+    # the counter passes are child processes: started before this process initialises the GPU
+    measured, measured_reason = None, "--measure-traffic 0"
+    if args.measure_traffic and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and args.roofline_steps > 0:
+        measured, measured_reason = measure_traffic_in_run(args, args.height or args.size, args.width or args.size)
+        if measured is None:
+            log(f"[bench] roofline.traffic not measured in this run: {measured_reason}")
 
     from maskrcnn_amd import dist as mdist
     rank, local, world = mdist.init_from_env()
@@ -418,7 +494,7 @@ def main():
             net.predict(images, windows, with_masks=True)
         torch.cuda.synchronize()
         prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-        roofline = conv_roofline(prof, args, H, W, modules)
+        roofline = conv_roofline(prof, args, H, W, modules, measured, measured_reason)
         roofline_ops = op_rooflines(dev, ops)
 
     # ---- other contraction modes, same weights/inputs/steps (every rank takes part) --------------------
