@@ -102,10 +102,10 @@ def measure_traffic_in_run(args, H, W):
     tmp = tempfile.mkdtemp(prefix="mrcnn_pmc_", dir="/tmp")
     found = {}
     try:
-        for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("mfma", "SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE")):
             d = os.path.join(tmp, name)
             os.makedirs(d)
-            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+            cmd = [exe, "--pmc", *ctr.split(), "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.join(ROOT, "tools", "profile_step.py"), "--steps", "1", "--batch", str(args.batch),
                    "--arch", args.arch, "--height", str(H), "--width", str(W), "--proposals", str(args.proposals),
                    "--precision", args.precision, "--meta", os.path.join(d, "meta.json")]
@@ -127,7 +127,10 @@ def measure_traffic_in_run(args, H, W):
         spec.loader.exec_module(mod)
         with open(os.path.join(tmp, "fetch", "meta.json")) as fh:
             meta = json.load(fh)
-        return mod.cmd_traffic(found["fetch"], found["write"], meta), "measured"
+        out = mod.cmd_traffic(found["fetch"], found["write"], meta)
+        with open(os.path.join(tmp, "mfma", "meta.json")) as fh:
+            out["mfma"] = mod.cmd_mfma(found["mfma"], json.load(fh))
+        return out, "measured"
     except subprocess.TimeoutExpired:
         return None, f"a counter pass exceeded {args.traffic_timeout} s"
     except Exception as e:  # a profiler problem never costs the GPU number
@@ -185,14 +188,33 @@ def conv_roofline(prof, args, H, W, modules, measured=None, measured_reason=None
             json.dump(rows, fh, indent=0)
     # HBM traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, summarised per kernel by
     # profiles/summarize_pmc.py into a file that records the mode it was taken in; anything else → null
-    traffic, traffic_src, in_run, conv_traffic = None, None, False, None
+    traffic, traffic_src, in_run, conv_traffic, counters = None, None, False, None, None
+    # the kernels behind a tag: the direct implicit GEMM is two kernels since the streaming 1x1 kernel (same arithmetic)
+    members = {"direct": ("conv_igemm_f32", "conv_pw_stream_f32")}.get(dominant, (kernel_of.get(dominant, dominant),))
+
+    def summed(per_kernel, field):
+        rows = [per_kernel[m] for m in members if m in per_kernel]
+        return (sum(r[field] for r in rows), sum(r["launches_per_step"] for r in rows)) if rows else (None, None)
+
     if measured is not None:   # this run's own counter passes (measure_traffic_in_run)
-        k = measured.get("per_kernel", {}).get(kernel_of.get(dominant, dominant))
-        if k and k.get("launches_per_step") == dom["launches_per_step"]:
-            traffic, traffic_src, in_run = k["hbm_bytes_per_step"], "rocprofv3 --pmc passes run by this bench.py invocation", True
+        tb, tl = summed(measured.get("per_kernel", {}), "hbm_bytes_per_step")
+        if tb is not None and tl == dom["launches_per_step"]:
+            traffic, traffic_src, in_run = tb, "rocprofv3 --pmc passes run by this bench.py invocation", True
             conv_traffic = measured.get("conv_path_hbm_bytes_per_step")
+            mf = measured.get("mfma", {})
+            rows = [mf.get("by_kernel", {}).get(m) for m in members]
+            rows = [r for r in rows if r]
+            if rows:
+                cyc = sum(r["kernel_cycles_per_step"] for r in rows)
+                counters = {"mfma_util": round(sum(r["mfma_util"] * r["kernel_cycles_per_step"] for r in rows) / cyc, 4),
+                            "all_mfma_kernels_mfma_util": mf["all_mfma_kernels"]["mfma_util"],
+                            "by_kernel": {b: v["mfma_util"] for b, v in mf["by_kernel"].items()},
+                            "definition": "SQ_INSTS_MFMA x 64 issue cycles (v_mfma_f32_32x32x2_f32) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), "
+                                          "one rocprofv3 --pmc pass over tools/profile_step.py started by this bench.py run; a counter "
+                                          "pass serialises dispatches and runs at its own clock, so this is the fraction of the kernels' "
+                                          "OWN cycles the MFMA pipe was issuing, to set beside the time-derived `frac`"}
         else:
-            measured_reason = f"launch count of the counter pass ({k and k.get('launches_per_step')}) != this run's"
+            measured_reason = f"launch count of the counter pass ({tl}) != this run's ({dom['launches_per_step']})"
     tpath = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
     if traffic is None and os.path.exists(tpath):
         try:
@@ -208,13 +230,13 @@ def conv_roofline(prof, args, H, W, modules, measured=None, measured_reason=None
                     and tj.get("winograd4_trunk") == bool(getattr(modules, "WINOGRAD4_TRUNK", False))
                     # the byte counts are only this run's if the kernels are the ones that were profiled
                     and tj.get("kernel_source_sha16") == kernel_source_sha16())
-            k = tj.get("per_kernel", {}).get(kernel_of.get(dominant, dominant))
-            if same and k and k.get("launches_per_step") == dom["launches_per_step"]:
-                traffic = k["hbm_bytes_per_step"]
+            tb, tl = summed(tj.get("per_kernel", {}), "hbm_bytes_per_step")
+            if same and tb is not None and tl == dom["launches_per_step"]:
+                traffic = tb
                 traffic_src = "profiles/" + TRAFFIC_PROFILE
         except (OSError, ValueError, KeyError):
             traffic = None
-    return {"bound": "mfma", "kernel": kernel_of.get(dominant, dominant),
+    return {"bound": "mfma", "kernel": " + ".join(members),
             "achieved": dom["executed_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["executed_frac"],
             "definition": "achieved = multiply-adds the kernel executes x 2 (Winograd F(2x2,3x3): 2*M*N*K / 2.25, F(4x4,3x3): / 4) / "
                           "summed launch durations of that kernel in one step (HIP events on the launch stream); "
@@ -224,7 +246,7 @@ def conv_roofline(prof, args, H, W, modules, measured=None, measured_reason=None
             "algorithmic_tflops": dom["algorithmic_tflops"],
             "algorithmic_speedup": round(dom["algorithmic_tflops"] / dom["executed_tflops"], 3),
             "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_this_run": in_run,
-            "traffic_conv_path": conv_traffic,
+            "traffic_conv_path": conv_traffic, "mfma_counters": counters,
             "traffic_note": ("fabric bytes of this kernel's launches of one step: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + "
                              "--pmc WRITE_SIZE, two separate counter passes over tools/profile_step.py (the same step, weights "
                              "and inputs) started by this bench.py run before its timed region"

@@ -21,6 +21,7 @@
 //               (FPN nearest-neighbour upsample + add, model.py:150-152).
 #include "conv_common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -339,6 +340,117 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
     if constexpr (RES != 5) epilogue<TM, TN, WTM, WTN, RES>(p, acc, rv, m0, n0, wm, wn, lane, EARLY_AFFINE ? &affine : nullptr);
 }
 
+
+// ---- streaming 1x1 kernel: ResNet C2's conv1 / downsample layers (model.py:179-180,254-262 at 256 x 256 per image) -----
+// K = Cin <= 256 and Cout <= 256 with short K: those layers move 0.67 GB for 17 GFLOP — HBM floor == MFMA floor — and the
+// tiled kernel above pays a prologue (two memory round trips before the first MFMA), one barrier per k tile and an epilogue per
+// tile, none of which a second workgroup hides completely (3.2-3.8 TB/s). Here NOTHING is shared between waves except the
+// weights:
+//   B   the whole [Cout][K] weight matrix sits in LDS for the life of a persistent workgroup ([32*TN][K+4] floats, 65-70 KB:
+//       two workgroups per CU), read with the same conflict-free ds_read_b128 fragments as above;
+//   A   a wave owns blocks of 32 pixels and loads ITS OWN A fragments straight from global memory into registers — lane
+//       (row r, half h) reads k = 8j+4h..+3 of row r, exactly the operand the MFMA wants — no LDS staging, no barrier in the
+//       loop. The four loads that consume one 128-byte line of a row are issued back to back; a register group is reloaded
+//       for the wave's NEXT block right after its last MFMA, so a whole block (8-32 KB per wave) is always in flight;
+//   epilogue: conv_common.hpp's, unchanged. Same MFMA sequence per output as the tiled kernel: results are bit-identical.
+template <int KC, int TN, int TNP>
+__global__ __launch_bounds__(256, 2) void conv_pw_stream_f32(const ConvParams p) {
+    constexpr int K = KC * 8, LDSB = K + 4, NPASS = TN / TNP;
+    static_assert(KC % 4 == 0 && TN % TNP == 0, "whole 128-byte lines; whole passes");
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // Bs[32*TN][LDSB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
+    for (int idx = tid; idx < 32 * TN * (K / 4); idx += 256) {  // rows beyond Cout: beyond w_bytes, i.e. zeros
+        const int n = idx / (K / 4), c = idx - n * (K / 4);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (n * K + 4 * c) * 4, 0, 0);
+        *reinterpret_cast<u32x4*>(smem + n * LDSB + 4 * c) = v;
+    }
+    AffineRegs<TN> affine;
+    load_affine<TN, 32 * TN>(p, 0, 0, lane, affine);
+    __syncthreads();
+
+    const int nblocks = (p.M + 31) >> 5;
+    const int nw = static_cast<int>(gridDim.x) * 4;
+    int blk = static_cast<int>(blockIdx.x) * 4 + wave;
+    if (blk >= nblocks) return;
+    const unsigned lane_off = static_cast<unsigned>(ln * K + 4 * lh) * 4u;
+    auto voff = [&](int b) -> unsigned {  // the lane's row of block b; beyond M (or past the last block): out of range, zeros
+        return (b < nblocks && b * 32 + ln < p.M) ? static_cast<unsigned>(b) * (32u * K * 4u) + lane_off : OOB;
+    };
+    u32x4 a[KC];
+    {
+        const unsigned vo = voff(blk);
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+            a[j] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(vo == OOB ? OOB : vo + j * 32u), 0, 0);
+    }
+    const float* Bw = smem + ln * LDSB + lh * 4;
+    for (; blk < nblocks; blk += nw) {
+        const unsigned vo_next = voff(blk + nw);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            f32x16 acc[1][TNP];
+#pragma unroll
+            for (int jn = 0; jn < TNP; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][jn][r] = 0.f;
+            float4 fb[2][TNP];
+            auto read_b = [&](int slot, int j) {
+#pragma unroll
+                for (int jn = 0; jn < TNP; ++jn)
+                    fb[slot][jn] = *reinterpret_cast<const float4*>(Bw + (ps * TNP + jn) * 32 * LDSB + j * 8);
+            };
+            read_b(0, 0);
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                if (j + 1 < KC) read_b((j + 1) & 1, j + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 av = a[j];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float af = __uint_as_float(s == 0 ? av.x : s == 1 ? av.y : s == 2 ? av.z : av.w);
+#pragma unroll
+                    for (int jn = 0; jn < TNP; ++jn) {
+                        const float4 b = fb[j & 1][jn];
+                        const float bf = s == 0 ? b.x : s == 1 ? b.y : s == 2 ? b.z : b.w;
+                        acc[0][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[0][jn], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (ps == NPASS - 1 && (j & 3) == 3) {  // the line's four fragments are dead: fetch the next block's
+#pragma unroll
+                    for (int jj = j - 3; jj <= j; ++jj)
+                        a[jj] = __builtin_amdgcn_raw_buffer_load_b128(
+                            x_rsrc, static_cast<int>(vo_next == OOB ? OOB : vo_next + jj * 32u), 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            AffineRegs<TNP> af;
+#pragma unroll
+            for (int jn = 0; jn < TNP; ++jn) {
+                af.sc[jn] = affine.sc[ps * TNP + jn];
+                af.sh[jn] = affine.sh[ps * TNP + jn];
+            }
+            ResidualRegs<1, TNP, 0> rv;
+            epilogue<1, TNP, 32, 32 * TNP, 0>(p, acc, rv, blk * 32, ps * TNP * 32, 0, 0, lane, &af);
+        }
+    }
+}
+
+template <int KC, int TN, int TNP>
+int launch_pw_stream(ConvParams p, hipStream_t stream) {
+    constexpr size_t lds = sizeof(float) * 32 * TN * (KC * 8 + 4);
+    auto kern = conv_pw_stream_f32<KC, TN, TNP>;
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "conv_pw_stream")) return rc;
+    const int cus = mrcnn::device_cu_count();
+    if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv_pw_stream: no device");
+    const int nblocks = (p.M + 31) / 32;
+    const int grid = std::min(2 * cus, (nblocks + 3) / 4);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
+    return mrcnn::check_launch("conv_pw_stream_f32");
+}
+
 template <int BM, int BN, int WM, int WN, int BK>
 int launch_conv(ConvParams p, int mode, hipStream_t stream) {  // mode: 0 aligned taps, 1 generic, 2 pointwise
     const bool generic = mode == 1;
@@ -403,6 +515,14 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
     const int mode = generic ? 1 : pointwise ? 2 : 0;
     hipStream_t s = mrcnn::as_stream(stream);
     static const int force = getenv("MRCNN_CONV_TILE") ? atoi(getenv("MRCNN_CONV_TILE")) : 0;  // tuning aid
+    // ResNet C2's 1x1 layers without a residual (conv1 256 -> 64 / 64 -> 64, downsample 64 -> 256) on large maps: the streaming
+    // kernel (bit-identical results; chosen by size only because a persistent wave needs several blocks to pipeline)
+    static const bool no_stream = getenv("MRCNN_CONV_NO_STREAM") != nullptr;
+    if (pointwise && !no_stream && stride == 1 && !residual && relu <= 1 && out_mode != 1 && p.M >= 131072) {
+        if (cin == 256 && cout > 32 && cout <= 64) return launch_pw_stream<32, 2, 2>(p, s);
+        if (cin == 64 && cout > 32 && cout <= 64) return launch_pw_stream<8, 2, 2>(p, s);
+        if (cin == 64 && cout > 128 && cout <= 256) return launch_pw_stream<8, 8, 4>(p, s);
+    }
     if (cout <= 32) return launch_conv<128, 32, 4, 1, 32>(p, mode, s);
     // Cout <= 64: 256x64 tile. BK = 16 keeps its LDS at 51 KB (two workgroups per CU; BK = 32 needs 92 KB = one):
     // measured 3-20 % faster on the C2 layers. The stem (generic K) keeps BK = 32.

@@ -927,3 +927,38 @@ def test_winograd4_fused_conv3(dev, b, h, w, cin, c3):
     f0 = ops.conv3x3_winograd4_conv3(xk, u4, None, None, w3d, None, None, resd)
     m0 = ops.conv3x3_winograd4(xk, u4, None, None, True)
     assert torch.equal(f0, ops.conv_bn_act(m0, w3d, None, None, relu=True, residual=resd))
+
+
+@pytest.mark.parametrize("cin,cout,relu,kblocked,m_extra", [(256, 64, True, True, 0), (64, 64, True, False, 0),
+                                                            (64, 256, False, False, 0), (256, 48, True, False, 37)],
+                         ids=["c2_conv1_kblocked", "c2_block1_conv1", "c2_downsample", "ragged_M_and_N"])
+def test_streaming_1x1_kernel_bit_identical_to_tiled(dev, cin, cout, relu, kblocked, m_extra):
+    """conv.hip's streaming 1x1 kernel (conv_pw_stream_f32: weights resident in LDS, every wave streams its own A fragments from
+    global memory; taken from M >= 131072 rows) runs the same MFMA sequence per output as the tiled kernel, which the same call
+    takes below that size: the big call must equal the row-chunked calls bit for bit, ragged last block and padded columns
+    included, and stay within 1e-4 of torch (model.py:179-180,254-262: ResNet C2's conv1 / downsample at batch 8)."""
+    from maskrcnn_amd import ops
+    g = torch.Generator().manual_seed(11)
+    m = 131072 + 32 * 8 + m_extra          # past the threshold; m_extra: a last block of fewer than 32 rows
+    x = torch.randn(1, m, 1, cin, generator=g).to(dev)
+    wt = (torch.randn(cout, 1, 1, cin, generator=g) / math.sqrt(cin)).to(dev)
+    sc = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    sh = torch.randn(cout, generator=g).to(dev)
+    canary = torch.full((1, m + 64, 1, cout), 7.0, device=dev)
+    if kblocked:
+        y = ops.conv_bn_act(x, wt, sc, sh, relu=relu, out_kblocked=True)                      # [Cout/8, 1, m, 1, 8]
+        parts = [ops.conv_bn_act(x[:, lo:lo + 65536].contiguous(), wt, sc, sh, relu=relu, out_kblocked=True)
+                 for lo in range(0, m, 65536)]
+        ref = torch.cat(parts, dim=2)
+        y_nhwc = y.permute(1, 2, 3, 0, 4).reshape(1, m, 1, cout)
+    else:
+        out = canary[:, :m]                                                                   # guard rows behind the output
+        assert out.is_contiguous()
+        y = ops.conv_bn_act(x, wt, sc, sh, relu=relu, out=out)
+        ref = torch.cat([ops.conv_bn_act(x[:, lo:lo + 65536].contiguous(), wt, sc, sh, relu=relu)
+                         for lo in range(0, m, 65536)], dim=1)
+        assert torch.all(canary[:, m:] == 7.0), "the streaming kernel wrote past its last row"
+        y_nhwc = y
+    assert torch.equal(y, ref)
+    want = _ref_conv(x.permute(0, 3, 1, 2).cpu(), wt.permute(0, 3, 1, 2).cpu(), sc.cpu(), sh.cpu(), 1, (0, 0, 0, 0), relu)
+    assert (y_nhwc.permute(0, 3, 1, 2).cpu() - want).abs().max().item() <= TOL
