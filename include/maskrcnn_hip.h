@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 12
+#define MRCNN_ABI_VERSION 13
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -498,6 +498,34 @@ int mrcnn_bottleneck_fused_f32(const float* x, int32_t batch, int32_t height, in
                                const float* w1, const float* scale1, const float* shift1, const float* u2,
                                const float* scale2, const float* shift2, const float* w3, const float* scale3,
                                const float* shift3, int32_t planes, float* y, mrcnn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Bottleneck.forward as ONE call — replaces the module composite  Bottleneck.forward  (model.py:174-211, downsample branch
+ * :254-262) for EVERY block of the trunk; the implementation of torch.ops.maskrcnn.bottleneck_forward (csrc/bottleneck_op.hip).
+ * The call plans the block and enqueues its launches on `stream`:
+ *   ResNet C2 (planes = 64, maps of >= winograd4_min_tiles tiles of 16 x 32 pixels per image, u4 given, fuse_conv3 != 0):
+ *       conv1 (+ downsample) on the direct kernel, then conv2 + conv3 + residual + ReLU in ONE launch
+ *       (mrcnn_conv3x3_winograd4_conv3_f32): 2 launches per identity block;
+ *   elsewhere: conv1 (+ downsample), conv2 by F(4x4) (u4, same size rule) / F(2x2) (u2, even maps) Winograd or, with neither
+ *       transform given, the exact direct kernel, then conv3 + residual + ReLU: 3 (4) launches.
+ * The plan depends on the shape per image and on which transforms are passed, never on the batch.
+ *   x   fp32 NHWC [batch][height][width][cin];  y  fp32 NHWC [batch][ceil(H/s)][ceil(W/s)][4*planes], y != x
+ *   weights[14] (device pointers, fp32; scale / shift = folded BatchNorm + bias per output channel, NULL = 1 / 0):
+ *       0 w1 [planes][cin]          1 scale1   2 shift1
+ *       3 w2 [planes][3][3][planes] (OHWI)     4 u2 = mrcnn_winograd_weights_f32(w2) or NULL     5 u4 = mrcnn_winograd4_weights_f32(w2) or NULL
+ *       6 scale2   7 shift2         8 w3 [4*planes][planes]   9 scale3   10 shift3
+ *       11 wd [4*planes][cin] or NULL (identity block: stride 1, cin == 4*planes)   12 scale_d   13 shift_d
+ *   workspace: >= mrcnn_bottleneck_workspace_bytes(...) bytes of device memory, 256-byte aligned (the block's intermediates).
+ * ---------------------------------------------------------------------------------------------- */
+size_t mrcnn_bottleneck_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t cin, int32_t planes,
+                                        int32_t stride, int32_t has_downsample);
+/* The plan mrcnn_bottleneck_forward_f32 follows for these arguments, as bits: 1 = conv2 on the F(4x4) kernel, 2 = conv2 on the
+ * F(2x2) kernel (neither: direct kernel), 4 = conv2 + conv3 + residual in one launch; -1 = bad shape. */
+int32_t mrcnn_bottleneck_plan(int32_t batch, int32_t height, int32_t width, int32_t cin, int32_t planes, int32_t stride,
+                              int32_t have_u2, int32_t have_u4, int32_t winograd4_min_tiles, int32_t fuse_conv3);
+int mrcnn_bottleneck_forward_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin, int32_t planes,
+                                 int32_t stride, const float* const weights[14], int32_t winograd4_min_tiles,
+                                 int32_t fuse_conv3, void* workspace, size_t workspace_bytes, float* y, mrcnn_stream_t stream);
 
 #ifdef __cplusplus
 }

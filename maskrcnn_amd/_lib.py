@@ -98,6 +98,10 @@ _SIGS = {
     "mrcnn_bottleneck_fused_supported": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
     "mrcnn_bottleneck_fused_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                     c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "mrcnn_bottleneck_workspace_bytes": (ctypes.c_size_t, [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "mrcnn_bottleneck_plan": (c_i32, [c_i32] * 10),
+    "mrcnn_bottleneck_forward_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_vp), c_i32,
+                                                      c_i32, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "mrcnn_nhwc_to_kblocked_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "mrcnn_stem_conv7x7_s2_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "mrcnn_stem_conv7x7_s2_nchw_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),

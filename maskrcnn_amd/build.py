@@ -37,6 +37,7 @@ SOURCES = {
                       + ([f"-DMRCNN_W4_WALK_SHIFT={int(os.environ['MRCNN_W4_WALK_SHIFT'])}"] if os.environ.get("MRCNN_W4_WALK_SHIFT") else []),
     "stem.hip": [],
     "bottleneck.hip": [],
+    "bottleneck_op.hip": [],
     "misc.hip": ["-ffp-contract=off"],
     "select.hip": ["-ffp-contract=off"],
     "image.hip": ["-ffp-contract=off"],   # Pillow's coefficient arithmetic, operation by operation in fp64

@@ -332,8 +332,9 @@ class FusedConv:
 
 class FusedBottleneck:
     """Bottleneck.forward (model.py:190-211): conv1 1x1 (stride) + BN + ReLU → SamePad(3,1) + conv2 3x3 + BN +
-    ReLU → conv3 1x1 + BN, + residual (identity or 1x1-stride downsample + BN), ReLU. In f32 mode this is
-    torch.ops.maskrcnn.bottleneck_forward; the fp16-MFMA modes run the same four fused conv launches."""
+    ReLU → conv3 1x1 + BN, + residual (identity or 1x1-stride downsample + BN), ReLU. In f32 mode this is ONE call of the C ABI
+    per block (ops.bottleneck_native, what torch.ops.maskrcnn.bottleneck_forward runs); the fp16-MFMA modes run the same
+    launches as separate binding calls."""
 
     def __init__(self, p, precision="f32", convs=None):
         self.p, self.precision, self.convs = p, precision, convs
@@ -374,6 +375,19 @@ class FusedBottleneck:
                 and ops.bottleneck_fused_supported(x.size(1), x.size(2), x.size(3), c1.w.shape[0])):
             return ops.bottleneck_fused(x, c1.w.w, c1.scale, c1.shift, c2.w.u, c2.scale, c2.shift,
                                         c3.w.w, c3.scale, c3.shift)
+        if (self.precision == "f32" and x.dim() == 4 and x.dtype == torch.float32
+                and all(c is None or c.w.precision == "f32" for c in self.convs)):
+            # the whole block as ONE call of the C ABI (mrcnn_bottleneck_forward_f32 = torch.ops.maskrcnn.bottleneck_forward's
+            # implementation): the plan below, made by the library — same launches, same results
+            return ops.bottleneck_native(x, c1.w.w, c1.scale, c1.shift, c2.w.w, c2.w.u, c2.w.u4, c2.scale, c2.shift,
+                                         c3.w.w, c3.scale, c3.shift, None if cd is None else cd.w.w,
+                                         None if cd is None else cd.scale, None if cd is None else cd.shift, c1.stride,
+                                         WINOGRAD4_MIN_TILES, FUSED_CONV3)
+        return self.launch_by_launch(x)
+
+    def launch_by_launch(self, x):
+        """The block as separate binding calls (the fp16-MFMA modes and the mixed mode; tests compare the native call with it)."""
+        c1, c2, c3, cd = self.convs
         res = x if cd is None else cd(x)
         oh, ow = -(-x.size(1) // c1.stride), -(-x.size(2) // c1.stride)
         # conv1's output only feeds conv2: written directly in the layout the Winograd kernel reads

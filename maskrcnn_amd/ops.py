@@ -589,20 +589,94 @@ def _cached_winograd_weights(w2: torch.Tensor) -> torch.Tensor:
     return u
 
 
+_U4_CACHE: dict = {}   # the same for the F(4x4) transform
+
+
+def _cached_winograd4_weights(w2: torch.Tensor) -> torch.Tensor:
+    import weakref
+    e = _U4_CACHE.get(w2.data_ptr())
+    if e is not None and e[0]() is w2 and e[1] == w2._version:
+        return e[2]
+    if len(_U4_CACHE) > 256:
+        _U4_CACHE.clear()
+    u = winograd4_weights(w2)
+    _U4_CACHE[w2.data_ptr()] = (weakref.ref(w2), w2._version, u)
+    return u
+
+
+def bottleneck_plan(batch, h, w, cin, planes, stride, have_u2, have_u4, min_tiles4, fuse_conv3) -> int:
+    """Bits of the plan mrcnn_bottleneck_forward_f32 follows: 1 = conv2 on F(4x4), 2 = conv2 on F(2x2), 4 = conv2 + conv3 fused."""
+    return int(lib.mrcnn_bottleneck_plan(batch, h, w, cin, planes, int(stride), int(bool(have_u2)), int(bool(have_u4)),
+                                         int(min_tiles4), int(bool(fuse_conv3))))
+
+
+@_on_device
+def bottleneck_native(x, w1, s1, t1, w2, u2, u4, s2, t2, w3, s3, t3, wd, sd, td, stride: int, min_tiles4: int = 8,
+                      fuse_conv3: bool = True) -> torch.Tensor:
+    """Bottleneck.forward (model.py:190-211) as ONE call of the C ABI (mrcnn_bottleneck_forward_f32, csrc/bottleneck_op.hip):
+    the library plans the block — conv1 (+ downsample), then conv2 + conv3 + residual in one launch for ResNet C2, or conv2
+    (F(4x4) / F(2x2) Winograd when u4 / u2 are given, else the exact direct kernel) and conv3 + residual — and enqueues the
+    launches on the current stream. x [B,H,W,Cin] NHWC fp32; w* OHWI; u2 / u4 = winograd_weights / winograd4_weights of w2 or
+    None. While ops.CONV_PROFILE is collecting per-launch events, the same plan runs launch by launch from Python
+    (identical launches, identical result) so that every launch can be timed."""
+    _need_gpu(x, w1, s1, t1, w2, u2, u4, s2, t2, w3, s3, t3, wd, sd, td)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    b, h, w, cin = x.shape
+    planes, stride = w1.size(0), int(stride)
+    assert tuple(w1.shape) == (planes, 1, 1, cin) and tuple(w2.shape) == (planes, 3, 3, planes)
+    assert tuple(w3.shape) == (4 * planes, 1, 1, planes) and (wd is None or tuple(wd.shape) == (4 * planes, 1, 1, cin))
+    for t in (w1, w2, w3, wd, u2, u4, s1, t1, s2, t2, s3, t3, sd, td):
+        assert t is None or (t.is_contiguous() and t.dtype == torch.float32)
+    if CONV_PROFILE is not None:
+        return _bottleneck_launch_by_launch(x, w1, s1, t1, w2, u2, u4, s2, t2, w3, s3, t3, wd, sd, td, stride, min_tiles4,
+                                            fuse_conv3)
+    oh, ow = -(-h // stride), -(-w // stride)
+    y = torch.empty(b, oh, ow, 4 * planes, dtype=torch.float32, device=x.device)
+    nbytes = int(lib.mrcnn_bottleneck_workspace_bytes(b, h, w, cin, planes, stride, int(wd is not None)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    assert ws.data_ptr() % 256 == 0
+    ptrs = (ctypes.c_void_p * 14)(*[_ptr(t) for t in (w1, s1, t1, w2, u2, u4, s2, t2, w3, s3, t3, wd, sd, td)])
+    check(lib.mrcnn_bottleneck_forward_f32(x.data_ptr(), b, h, w, cin, planes, stride, ptrs, int(min_tiles4), int(bool(fuse_conv3)),
+                                           ws.data_ptr(), nbytes, y.data_ptr(), _stream()))
+    return y
+
+
+def _bottleneck_launch_by_launch(x, w1, s1, t1, w2, u2, u4, s2, t2, w3, s3, t3, wd, sd, td, stride, min_tiles4, fuse_conv3):
+    """The plan of mrcnn_bottleneck_forward_f32 (asked from the library), one binding call per launch."""
+    b, h, w, cin = x.shape
+    planes = w1.size(0)
+    plan = bottleneck_plan(b, h, w, cin, planes, stride, u2 is not None, u4 is not None, min_tiles4, fuse_conv3)
+    res = x if wd is None else conv_bn_act(x, wd, sd, td, stride=stride, relu=False)
+    hmid = conv_bn_act(x, w1, s1, t1, stride=stride, relu=True, out_kblocked=bool(plan & 3))
+    if plan & 4:
+        return conv3x3_winograd4_conv3(hmid, u4, s2, t2, w3, s3, t3, res)
+    if plan & 1:
+        h2 = conv3x3_winograd4(hmid, u4, s2, t2, True)
+    elif plan & 2:
+        h2 = conv3x3_winograd(hmid, u2, s2, t2, True)
+    else:
+        h2 = conv_bn_act(hmid, w2, s2, t2, stride=1, pad=(1, 1, 1, 1), relu=True)
+    return conv_bn_act(h2, w3, s3, t3, stride=1, relu=True, residual=res)
+
+
 def bottleneck_forward(x, w1, s1, t1, w2, s2, t2, w3, s3, t3, wd, sd, td, stride: int):
-    """Bottleneck.forward (model.py:190-211) on NHWC: conv1 1x1 (stride) + BN + ReLU, SamePad(3,1) + conv2 3x3 + BN +
-    ReLU, conv3 1x1 + BN, + residual (identity or 1x1-stride downsample + BN), ReLU. BN/bias are (scale, shift) epilogues.
-    Three or four fused conv launches on the exact direct kernel; with BOTTLENECK_OP_FUSED (above) the stride-1 identity
-    blocks with planes = 64 (bottleneck_fused_supported) run as ONE launch of the whole-block kernel instead."""
+    """torch.ops.maskrcnn.bottleneck_forward — Bottleneck.forward (model.py:190-211) on NHWC: conv1 1x1 (stride) + BN + ReLU,
+    SamePad(3,1) + conv2 3x3 + BN + ReLU, conv3 1x1 + BN, + residual (identity or 1x1-stride downsample + BN), ReLU; BN / bias
+    are (scale, shift) epilogues. ONE call of the C ABI per block (bottleneck_native): with Winograd enabled (the default) conv2
+    runs the F(4x4) / F(2x2) kernels from cached transforms of w2 and the ResNet C2 blocks fuse conv2 + conv3 + residual into
+    one launch — exactly what the inference pipeline launches; with MRCNN_WINOGRAD=0 every conv is the exact direct kernel
+    (bitwise an fmaf chain). With BOTTLENECK_OP_FUSED (above) the stride-1 identity blocks with planes = 64 run the opt-in
+    whole-block kernel instead."""
+    from . import modules as _m
     if (BOTTLENECK_OP_FUSED and wd is None and int(stride) == 1 and x.is_cuda and x.dim() == 4
             and tuple(w2.shape[1:3]) == (3, 3)
             and bottleneck_fused_supported(x.size(1), x.size(2), x.size(3), w1.size(0)) and w3.size(0) == x.size(3)):
         return bottleneck_fused(x, w1, s1, t1, _cached_winograd_weights(w2), s2, t2, w3, s3, t3)
-    h = conv_bn_act(x, w1, s1, t1, stride=stride, relu=True)
-    pad = same_pad(h.size(1), h.size(2), 3, 1)
-    h = conv_bn_act(h, w2, s2, t2, stride=1, pad=pad, relu=True)
-    res = x if wd is None else conv_bn_act(x, wd, sd, td, stride=stride, relu=False)
-    return conv_bn_act(h, w3, s3, t3, stride=1, relu=True, residual=res)
+    wino = bool(_m.WINOGRAD) and x.is_cuda and tuple(w2.shape[1:3]) == (3, 3) and w2.size(3) % 8 == 0
+    u2 = _cached_winograd_weights(w2) if wino else None
+    u4 = _cached_winograd4_weights(w2) if (wino and _m.WINOGRAD4 and _m.WINOGRAD4_TRUNK and w2.size(0) % 64 == 0) else None
+    return bottleneck_native(x, w1, s1, t1, w2, u2, u4, s2, t2, w3, s3, t3, wd, sd, td, int(stride), _m.WINOGRAD4_MIN_TILES,
+                             _m.FUSED_CONV3)
 
 
 _LIB.define("bottleneck_forward(Tensor x, Tensor w1, Tensor s1, Tensor t1, Tensor w2, Tensor s2, "
@@ -612,7 +686,7 @@ _LIB.impl("bottleneck_forward", bottleneck_forward, "CUDA")
 _LIB.impl("bottleneck_forward", lambda x, *a: _need_gpu(x), "CPU")
 
 __all__ += ["conv_bn_act", "conv_bn_act_f16mfma", "split_f16", "same_pad", "maxpool", "nchw_to_nhwc", "nhwc_to_nchw", "bottleneck_forward",
-            "bottleneck_fused", "bottleneck_fused_supported"]
+            "bottleneck_fused", "bottleneck_fused_supported", "bottleneck_native", "bottleneck_plan"]
 
 
 class HeadSums:

@@ -498,22 +498,115 @@ def test_bottleneck_fused_whole_block(dev, shape):
         modules.FUSED_BOTTLENECK = saved
     err4 = (got4.permute(0, 3, 1, 2).cpu() - want).abs().max().item()
     assert err4 <= TOL, f"F(4x4): max abs err {err4:.3e} (|ref|max {want.abs().max().item():.2f})"
-    # the registered op with the reference-shaped argument list: the exact direct-kernel composite by default (it must not
-    # slip a Winograd conv2 into the "every conv on the direct kernel" mode), the whole-block launch only when switched on
+    # the registered op with the reference-shaped argument list is ONE call of the C ABI (mrcnn_bottleneck_forward_f32): by
+    # default what the pipeline launches (conv2 from cached Winograd transforms, conv2 + conv3 fused where the map is large
+    # enough), the exact direct-kernel composite when Winograd is switched off (it must not slip a Winograd conv2 into the
+    # "every conv on the direct kernel" mode), the whole-block launch only when that is switched on
     args = (xd, c1.w.w, c1.scale, c1.shift, c2.w.w, c2.scale, c2.shift, c3.w.w, c3.scale, c3.shift, None, None, None, 1)
-    saved_op = ops.BOTTLENECK_OP_FUSED
+    saved_op, saved_w = ops.BOTTLENECK_OP_FUSED, modules.WINOGRAD
     try:
         ops.BOTTLENECK_OP_FUSED = False
+        assert torch.equal(torch.ops.maskrcnn.bottleneck_forward(*args), got4)
+        assert torch.equal(torch.ops.maskrcnn.bottleneck_forward(*args), got4)           # second call: cached conv2 transforms
+        modules.WINOGRAD = False
         y = torch.ops.maskrcnn.bottleneck_forward(*args)
         h1 = ops.conv_bn_act(xd, c1.w.w, c1.scale, c1.shift, relu=True)
         h2 = ops.conv_bn_act(h1, c2.w.w, c2.scale, c2.shift, pad=(1, 1, 1, 1), relu=True)
         direct = ops.conv_bn_act(h2, c3.w.w, c3.scale, c3.shift, relu=True, residual=xd)
         assert torch.equal(y, direct)
+        modules.WINOGRAD = saved_w
         ops.BOTTLENECK_OP_FUSED = True
         assert torch.equal(torch.ops.maskrcnn.bottleneck_forward(*args), fused)
         assert torch.equal(torch.ops.maskrcnn.bottleneck_forward(*args), fused)      # second call: cached conv2 transform
     finally:
-        ops.BOTTLENECK_OP_FUSED = saved_op
+        ops.BOTTLENECK_OP_FUSED, modules.WINOGRAD = saved_op, saved_w
+
+
+def _block_sd(g, inplanes, planes, downsample):
+    """state dict of one reference Bottleneck (model.py:174-188 names), Xavier-scale weights, non-trivial BN statistics"""
+    sd = {}
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = torch.randn(co, ci, k, k, generator=g) * math.sqrt(2.0 / (ci * k * k))
+        sd[name + ".bias"] = torch.randn(co, generator=g) * 0.1
+    def bn(name, c):
+        sd[name + ".weight"] = torch.rand(c, generator=g) + 0.5
+        sd[name + ".bias"] = torch.randn(c, generator=g) * 0.1
+        sd[name + ".running_mean"] = torch.randn(c, generator=g) * 0.1
+        sd[name + ".running_var"] = torch.rand(c, generator=g) + 0.5
+    conv("conv1", planes, inplanes, 1); bn("bn1", planes)
+    conv("conv2", planes, planes, 3); bn("bn2", planes)
+    conv("conv3", 4 * planes, planes, 1); bn("bn3", 4 * planes)
+    if downsample:
+        conv("downsample.0", 4 * planes, inplanes, 1); bn("downsample.1", 4 * planes)
+    return sd
+
+
+# (batch, H, W, inplanes, planes, stride, downsample): the block kinds of ResNet-50/101 (model.py:214-270) on maps that take
+# each of the three conv2 kernels — F(4x4) with conv3 fused (C2 size), F(4x4) alone, F(2x2), and odd sizes (direct kernel)
+NATIVE_BLOCKS = [
+    (2, 64, 64, 64, 64, 1, True),      # C2 block 0: downsample branch, fused conv2 + conv3
+    (2, 64, 64, 256, 64, 1, False),    # C2 identity: two launches
+    (1, 128, 128, 256, 128, 2, True),  # C3 block 0: stride 2, F(4x4) conv2 (64 x 64 output = 8 tiles)
+    (2, 64, 64, 512, 128, 1, False),   # C3 identity, F(4x4)
+    (1, 32, 32, 512, 256, 2, True),    # C4 block 0 on a small map: F(2x2)
+    (2, 16, 16, 1024, 256, 1, False),  # C4 identity, F(2x2)
+    (1, 16, 16, 1024, 512, 2, True),   # C5 block 0
+    (1, 8, 8, 2048, 512, 1, False),    # C5 identity
+    (1, 14, 10, 256, 64, 1, False),    # H, W not multiples of 4: F(2x2)
+    (1, 13, 11, 256, 64, 1, False),    # odd sizes: the direct kernel for conv2
+    (1, 13, 11, 64, 64, 2, True),      # odd input, stride 2: 7 x 6 output
+]
+
+
+@pytest.mark.parametrize("blk", NATIVE_BLOCKS, ids=lambda c: "x".join(str(int(v)) for v in c))
+def test_bottleneck_native_call_equals_launch_by_launch(dev, blk):
+    """mrcnn_bottleneck_forward_f32 (one C call per block: the library plans and enqueues the launches; it backs both
+    modules.FusedBottleneck and torch.ops.maskrcnn.bottleneck_forward) gives bit for bit what the same launches give as separate
+    binding calls, for every block kind of the trunk and every conv2 kernel, and stays within 1e-4 of the reference module's
+    arithmetic in torch-CPU fp32 (model.py:190-211,254-262)."""
+    from maskrcnn_amd import modules, ops
+    b, h, w, cin, planes, stride, ds = blk
+    g = torch.Generator().manual_seed(1000 + h * 7 + cin + planes + stride)
+    sd = _block_sd(g, cin, planes, ds)
+    x = torch.randn(b, cin, h, w, generator=g)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    m = modules.FusedBottleneck.from_state_dict(sd, "", stride, dev)
+    native = m(xd)
+    assert torch.equal(native, m.launch_by_launch(xd))
+    assert torch.equal(native, m(xd))
+    c1, c2, c3, cd = m.convs
+    # the plan is the one modules.py's own rules give
+    oh, ow = -(-h // stride), -(-w // stride)
+    plan = ops.bottleneck_plan(b, h, w, cin, planes, stride, c2.w.u is not None, c2.w.u4 is not None,
+                               modules.WINOGRAD4_MIN_TILES, modules.FUSED_CONV3)
+    t4 = c2.w.takes_winograd4(oh, ow, 1, (1, 1, 1, 1), None, True, b)
+    assert bool(plan & 1) == bool(t4) and bool(plan & 2) == bool(c2.takes_winograd(oh, ow) and not t4)
+    assert bool(plan & 4) == bool(t4 and planes == 64 and modules.FUSED_CONV3)
+    # the torch op with the reference-shaped argument list (raw conv2 weight: transforms cached per weight tensor)
+    args = (xd, c1.w.w, c1.scale, c1.shift, c2.w.w, c2.scale, c2.shift, c3.w.w, c3.scale, c3.shift,
+            None if cd is None else cd.w.w, None if cd is None else cd.scale, None if cd is None else cd.shift, stride)
+    assert torch.equal(torch.ops.maskrcnn.bottleneck_forward(*args), native)
+    # the reference arithmetic
+    def bn(y, n):
+        return F.batch_norm(y, sd[f"{n}.running_mean"], sd[f"{n}.running_var"], sd[f"{n}.weight"], sd[f"{n}.bias"], False, 0.0, 1e-3)
+    r = F.relu(bn(F.conv2d(x, sd["conv1.weight"], sd["conv1.bias"], stride=stride), "bn1"))
+    r = F.relu(bn(F.conv2d(F.pad(r, (1, 1, 1, 1)), sd["conv2.weight"], sd["conv2.bias"]), "bn2"))
+    r = bn(F.conv2d(r, sd["conv3.weight"], sd["conv3.bias"]), "bn3")
+    res = bn(F.conv2d(x, sd["downsample.0.weight"], sd["downsample.0.bias"], stride=stride), "downsample.1") if ds else x
+    want = F.relu(r + res)
+    err = (native.permute(0, 3, 1, 2).cpu() - want).abs().max().item()
+    assert err <= TOL, f"max abs err {err:.3e} (|ref|max {want.abs().max().item():.2f})"
+    # a workspace that is too small is refused, not overrun
+    with pytest.raises(RuntimeError, match="workspace"):
+        import ctypes
+        from maskrcnn_amd._lib import check, lib
+        ptrs = (ctypes.c_void_p * 14)(*[None if t is None else t.data_ptr() for t in
+                                        (c1.w.w, c1.scale, c1.shift, c2.w.w, c2.w.u, c2.w.u4, c2.scale, c2.shift, c3.w.w, c3.scale,
+                                         c3.shift, None if cd is None else cd.w.w, None if cd is None else cd.scale,
+                                         None if cd is None else cd.shift)])
+        ws = torch.empty(256, dtype=torch.uint8, device=dev)
+        check(lib.mrcnn_bottleneck_forward_f32(xd.data_ptr(), b, h, w, cin, planes, stride, ptrs, 8, 1, ws.data_ptr(), 256,
+                                               native.data_ptr(), torch.cuda.current_stream().cuda_stream))
 
 
 def test_bottleneck_fused_rejects_other_shapes(dev):
