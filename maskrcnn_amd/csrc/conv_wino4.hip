@@ -691,14 +691,21 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                     f32x16 hacc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+                    // the B fragment of step j + 1 is read while the four MFMAs of step j run (read-then-wait in front of
+                    // every group of four left the LDS latency exposed eight times per column block)
+                    f32x4 bq[2];
+                    bq[0] = *(const lds_f32x4*)(W3s + (cb * 8) * 256);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const f32x4 a4 = afr[j];
-                        const f32x4 b4 = *(const lds_f32x4*)(W3s + (cb * 8 + j) * 256);
+                        if (j + 1 < 8) bq[(j + 1) & 1] = *(const lds_f32x4*)(W3s + (cb * 8 + j + 1) * 256);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const f32x4 b4 = bq[j & 1];
                         hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, hacc, 0, 0, 0);
                         hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, hacc, 0, 0, 0);
                         hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, hacc, 0, 0, 0);
                         hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, hacc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
