@@ -38,7 +38,7 @@ struct ConvParams : ConvCommon {
 
 template <int BM, int BN, int BK>
 constexpr size_t conv_lds_bytes() {
-    return sizeof(float) * 2 * (BM + BN) * (BK + 4);
+    return sizeof(float) * 2 * (BM + BN) * (BK == 16 ? BK : BK + 4);   // LDS_STRIDE of the kernel
 }
 
 // MODE 0: Cin % 32 == 0, any kernel size / stride / padding: a k tile lies inside one tap.
@@ -50,7 +50,14 @@ constexpr size_t conv_lds_bytes() {
 template <int BM, int BN, int WM, int WN, int BK, int MODE, int RES>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
     constexpr bool GENERIC = MODE == 1, PW = MODE == 2;
-    constexpr int LDS_STRIDE = BK + 4;           // floats; keeps ds_read_b128 conflict-free (BK = 16 or 32)
+    // LDS row pitch in floats. BK = 32: 36 — the +4 pad makes the fragment reads (16 consecutive rows, one 16-byte chunk each)
+    // conflict-free, and a 16-lane ds_write_b128 pass (two rows of eight chunks) overlaps in one chunk only. BK = 16: a pad
+    // cannot serve both — a write pass is FOUR rows of four chunks, and no odd chunk pitch keeps those sixteen chunks apart
+    // (pitch 20: SQ_LDS_BANK_CONFLICT = 0.34 of the LDS-active cycles on the BK = 16 instantiations,
+    // profiles/r03_cache_lds_counters.json) — so the rows are unpadded (pitch 16) and chunk c of row r sits at c ^ ((r >> 2) & 3):
+    // sixteen consecutive rows of one logical chunk, and four consecutive rows of all four chunks, both cover the 64 banks once.
+    constexpr bool SWZ = BK == 16;
+    constexpr int LDS_STRIDE = SWZ ? BK : BK + 4;
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
     constexpr int TPR = BK / 4;                  // threads (16-byte slots) per tile row
@@ -184,11 +191,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
             rb[i] = bload(w_rsrc, ok ? static_cast<unsigned>(b_off[i] + cur_k0) * 4u : OOB);
         }
     };
+    // (RPP is a multiple of 4 * 4 rows whenever SWZ: the swizzle term of a thread's rows is that of r0)
+    static_assert(!SWZ || RPP % 16 == 0, "swizzle term must not depend on the piece");
+    const int kqs = SWZ ? (kq ^ ((r0 >> 2) & 3)) : kq;   // physical 16-byte chunk of this thread's staging slot
     auto store_piece = [&](int pc, int buf) {
         if (pc < PA)
-            *reinterpret_cast<float4*>(As + buf * BM * LDS_STRIDE + (r0 + RPP * pc) * LDS_STRIDE + kq * 4) = ra[pc];
+            *reinterpret_cast<float4*>(As + buf * BM * LDS_STRIDE + (r0 + RPP * pc) * LDS_STRIDE + kqs * 4) = ra[pc];
         else
-            *reinterpret_cast<float4*>(Bs + buf * BN * LDS_STRIDE + (r0 + RPP * (pc - PA)) * LDS_STRIDE + kq * 4) =
+            *reinterpret_cast<float4*>(Bs + buf * BN * LDS_STRIDE + (r0 + RPP * (pc - PA)) * LDS_STRIDE + kqs * 4) =
                 rb[pc - PA];
     };
     constexpr int NP = PA + PB;  // pieces per k tile
@@ -224,17 +234,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
 #pragma unroll
     for (int pc = 0; pc < NP; ++pc) load_piece(pc);
 
-    const int frag = (lane & 31) * LDS_STRIDE + (lane >> 5) * 4;
-    const float* Aw = As + wm * WTM * LDS_STRIDE + frag;
-    const float* Bw = Bs + wn * WTN * LDS_STRIDE + frag;
+    // lane (row ln, half h) reads logical chunk 2 j + h; every row this lane reads is ln + a multiple of 32, so its swizzle
+    // term is (ln >> 2) & 3 and (SWZ: two chunks per k tile) the lane needs just two chunk offsets
+    const int fsw = SWZ ? (((lane & 31) >> 2) & 3) : 0;
+    const int frow = (lane & 31) * LDS_STRIDE;
+    const int fch0 = (((lane >> 5)) ^ fsw) * 4, fch1 = ((2 + (lane >> 5)) ^ fsw) * 4;   // SWZ: floats, chunk j = 0 / 1
+    const int frag = frow + (lane >> 5) * 4;
+    const float* Aw = As + wm * WTM * LDS_STRIDE + (SWZ ? frow : frag);
+    const float* Bw = Bs + wn * WTN * LDS_STRIDE + (SWZ ? frow : frag);
     float4 fa[2][TM], fb[2][TN];
     auto read_frags = [&](int slot, int buf, int j) {
+        const int jo = SWZ ? (j == 0 ? fch0 : fch1) : j * 8;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-            fa[slot][i] = *reinterpret_cast<const float4*>(Aw + buf * BM * LDS_STRIDE + i * 32 * LDS_STRIDE + j * 8);
+            fa[slot][i] = *reinterpret_cast<const float4*>(Aw + buf * BM * LDS_STRIDE + i * 32 * LDS_STRIDE + jo);
 #pragma unroll
         for (int i = 0; i < TN; ++i)
-            fb[slot][i] = *reinterpret_cast<const float4*>(Bw + buf * BN * LDS_STRIDE + i * 32 * LDS_STRIDE + j * 8);
+            fb[slot][i] = *reinterpret_cast<const float4*>(Bw + buf * BN * LDS_STRIDE + i * 32 * LDS_STRIDE + jo);
     };
     read_frags(0, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {

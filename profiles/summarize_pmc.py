@@ -115,12 +115,46 @@ def cmd_traffic(fetch_path, write_path, meta):
                 per_kernel=dict(sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"])))
 
 
+def cmd_counters(paths, meta):
+    """Any set of counter passes over tools/profile_step.py -> per kernel instantiation, per step: the raw counter sums plus the
+    ratios the design discussion uses (L2 hit rate, fabric read bytes, LDS bank-conflict share)."""
+    steps = meta["predict_calls"]
+    rows = defaultdict(dict)
+    launches = {}
+    for path in paths:
+        per, n, ns = read(path)
+        for k, c in per.items():
+            launches[k] = n[k] / steps
+            for name, v in c.items():
+                rows[k][name] = v / steps
+    out = {}
+    for k, c in rows.items():
+        if not any(t in k for t in ("conv", "stem", "wino", "bottleneck", "roi_align", "crop", "maxpool")):
+            continue
+        e = {"launches_per_step": launches[k]}
+        e.update({name: round(v, 1) for name, v in sorted(c.items())})
+        if "TCC_HIT_sum" in c and c["TCC_HIT_sum"] + c.get("TCC_MISS_sum", 0) > 0:
+            e["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+        if "TCC_EA0_RDREQ_sum" in c:   # 128-byte read requests from the L2s to the fabric (64-byte ones counted apart when asked for)
+            e["fabric_read_GB_at_128B_per_request"] = round(c["TCC_EA0_RDREQ_sum"] * 128 / 1e9, 3)
+        if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
+            e["lds_bank_conflict_share_of_lds_active"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4)
+        out[k] = e
+    key = lambda kv: -kv[1].get("TCC_EA0_RDREQ_sum", kv[1].get("GRBM_GUI_ACTIVE", 0))
+    return dict(meta, definition="rocprofv3 --pmc passes (one counter group per pass, --kernel-trace only) over tools/profile_step.py: "
+                                 "sums over all launches of a kernel instantiation in one step; TCC_* are summed over the L2 channels of "
+                                 "all eight XCDs, SQ_* over all SIMDs",
+                by_instantiation=dict(sorted(out.items(), key=key)))
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1]
     if cmd == "mfma":
         res = cmd_mfma(sys.argv[2], json.load(open(sys.argv[3])))
     elif cmd == "traffic":
         res = cmd_traffic(sys.argv[2], sys.argv[3], json.load(open(sys.argv[4])))
+    elif cmd == "counters":   # counters <meta.json> <counter_collection.csv> ...
+        res = cmd_counters(sys.argv[3:], json.load(open(sys.argv[2])))
     else:
         raise SystemExit(__doc__)
     print(json.dumps(res, indent=1))
