@@ -191,3 +191,25 @@ def test_winograd4_point_set_is_exact_and_dyadic():
     assert np.abs(y - ref).max() < 1e-13
     for m in (BT, AT):
         assert np.array_equal(m.astype(np.float32).astype(np.float64), m)
+
+
+def test_bench_traffic_measurement_degrades_to_a_reason_without_a_gpu(monkeypatch):
+    """bench.py measures roofline.traffic itself through rocprofv3 child passes (measure_traffic_in_run). Anything that goes wrong
+    there — no rocprofv3, already under a profiler, a pass that fails (here: no GPU in the build container) — must come back
+    as (None, reason) and never cost the run its GPU number."""
+    import argparse
+    import bench
+    args = argparse.Namespace(batch=1, arch="resnet50", proposals=10, precision="f32", traffic_timeout=120)
+    monkeypatch.setenv("ROCPROFILER_FAKE", "1")
+    got, why = bench.measure_traffic_in_run(args, 128, 128)
+    assert got is None and "profiler" in why
+    monkeypatch.delenv("ROCPROFILER_FAKE")
+    if torch.cuda.is_available():
+        return   # on a GPU box the passes would succeed: covered by the bench run itself
+    import shutil
+    if shutil.which("rocprofv3") is None and not os.path.exists("/opt/rocm/bin/rocprofv3"):
+        got, why = bench.measure_traffic_in_run(args, 128, 128)
+        assert got is None and "rocprofv3" in why
+        return
+    got, why = bench.measure_traffic_in_run(args, 128, 128)
+    assert got is None and isinstance(why, str) and why
