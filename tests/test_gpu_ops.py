@@ -291,6 +291,23 @@ def test_roi_align_pyramid_golden(dev):
         assert np.array_equal(got.permute(0, 3, 1, 2).cpu().numpy(), z[f"pooled{pool}"])
 
 
+def test_roi_align_dropin_reference_signature_golden(dev):
+    """maskrcnn_amd.roi_align(inputs, pool_size, image_shape) — the reference's own signature (model.py:276): list of
+    [boxes [1,N,4]] + four [1,C,H,W] NCHW maps in, [N,C,p,p] out, batch dimensions squeezed in the caller's list — against the
+    reference's output on the same inputs (tests/golden/roi_align.npz, generated by the reference's model.roi_align), bit for bit."""
+    import maskrcnn_amd
+    z = load_golden("roi_align")
+    shape = tuple(int(v) for v in z["image_shape"])
+    for pool in (7, 14):
+        inputs = [torch.from_numpy(z["boxes"]).to(dev).unsqueeze(0)] + [torch.from_numpy(z[f"fm{i}"]).to(dev) for i in range(4)]
+        got = maskrcnn_amd.roi_align(inputs, pool, shape)
+        assert got.shape == z[f"pooled{pool}"].shape and got.is_contiguous()
+        assert np.array_equal(got.cpu().numpy(), z[f"pooled{pool}"])
+        assert inputs[0].dim() == 2 and inputs[1].dim() == 3      # squeezed in place, as the reference does (:312-313)
+    with pytest.raises(RuntimeError, match="four pyramid levels"):
+        maskrcnn_amd.roi_align([torch.zeros(1, 2, 4, device=dev), torch.zeros(1, 8, 4, 4, device=dev)], 7, (64, 64, 3))
+
+
 def test_roi_align_pyramid_batched_vs_oracle(dev, oracle):
     """1000 proposals/img x 2 images x 256 ch on a 512x512 pyramid vs per-image oracle roi_align."""
     from maskrcnn_amd import ops
