@@ -29,4 +29,4 @@ def roi_align(inputs, pool_size, image_shape):
     return ops.nhwc_to_nchw(pooled)
 
 
-__all__ = ["ops", "roi_align"]
+__all__ = ["ops", "roi_align"]   # reference-signature refine stages: maskrcnn_amd.refine (imports the pipeline)

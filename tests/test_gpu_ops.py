@@ -331,6 +331,40 @@ def test_roi_align_pyramid_batched_vs_oracle(dev, oracle):
         assert torch.equal(got[b * R:(b + 1) * R][ok], want)
 
 
+def test_refine_stages_reference_signature_golden(dev):
+    """maskrcnn_amd.refine.rpn_refine / mrn_refine — the reference's MaskRCNN.rpn_refine / mrn_refine signatures on the HIP
+    kernels — against the reference's OWN outputs on the same inputs (tests/golden/refine.npz, generated by running the
+    reference's methods: model.py:1307-1382, :1389-1487): same number of proposals, rois equal up to the expf ulp of the box
+    decode (1e-6 in normalised coordinates), the same detections in the same order with integral boxes equal exactly and
+    scores to 1e-6 (the decode kernel re-normalises log(probs))."""
+    from maskrcnn_amd import refine
+    from maskrcnn_amd.anchors import pyramid_anchors
+    from maskrcnn_amd.config import InferenceConfig
+    z = load_golden("refine")
+    cfg = InferenceConfig(image_height=256, image_width=256)      # the fixture's configuration: 16368 anchors, top 500, 500 rois
+    anchors = pyramid_anchors(cfg).to(dev)
+    assert tuple(anchors.shape) == tuple(int(v) for v in z["anchors_shape"])
+    rois = refine.rpn_refine(torch.from_numpy(z["rpn_class"]).to(dev), torch.from_numpy(z["rpn_bbox"]).to(dev), anchors, cfg)
+    want = torch.from_numpy(z["rois"])
+    assert rois.shape == want.shape, f"{tuple(rois.shape)} proposals kept, the reference keeps {tuple(want.shape)}"
+    # the same SET of rois (the reference orders equal scores as torch.sort happens to, model.py:1345; the kernel by index),
+    # each within the expf ulp of the decode; and row by row wherever the scores are distinct
+    d = (rois[0].cpu()[:, None, :] - want[0][None, :, :]).abs().amax(dim=2)           # [R, R] pairwise row distance
+    assert d.min(dim=1).values.max().item() <= 1e-6 and d.min(dim=0).values.max().item() <= 1e-6
+    same_row = (rois[0].cpu() - want[0]).abs().amax(dim=1) <= 1e-6
+    assert same_row.float().mean().item() >= 0.95, f"only {same_row.float().mean().item():.3f} of the rows are in the reference's order"
+    cls, sc, bx = refine.mrn_refine(want.to(dev), torch.from_numpy(z["probs"]).to(dev), torch.from_numpy(z["deltas"]).to(dev),
+                                    tuple(int(v) for v in z["window"]), cfg)
+    assert torch.equal(cls.cpu(), torch.from_numpy(z["det_class_ids"]))
+    assert torch.equal(bx.cpu(), torch.from_numpy(z["det_boxes"]))
+    assert (sc.cpu() - torch.from_numpy(z["det_scores"])).abs().max().item() <= 1e-6
+    # nothing kept: background everywhere → the reference's (None, None, None) (model.py:1445-1447)
+    bg = torch.zeros_like(torch.from_numpy(z["probs"]))
+    bg[:, 0] = 1.0
+    bg = (bg + 1e-12) / (1.0 + 81e-12)
+    assert refine.mrn_refine(want.to(dev), bg.to(dev), torch.from_numpy(z["deltas"]).to(dev), (0, 0, 256, 256), cfg) == (None, None, None)
+
+
 # ------------------------------------------------------------------------------------ RPN glue kernels
 def test_rpn_scores_deltas_and_proposal_decode(dev, oracle):
     from maskrcnn_amd import ops
