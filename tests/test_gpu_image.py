@@ -278,3 +278,38 @@ def test_config1_car_image_mold_and_detect(ops, oracle):
     assert torch.equal(masks.cpu(), oracle.decode_masks(full, scale, window))
     assert torch.equal(boxes.cpu(), oracle.decode_boxes(bx, scale, window))
     assert tuple(masks.shape[1:]) == (1200, 1920)                              # back at the original image's size
+
+
+def test_predict_cli_on_an_image_file(tmp_path, capsys):
+    """predict.py — the reference's entry point (`python predict.py [-model m] image`, predict.py:30-72 there): image file in,
+    one printed line per detection, full-size masks out. Random weights of the R50 architecture (no checkpoint offline): what
+    is checked is the plumbing — the file is read, molded, pushed through detect(), and the printed / saved results agree with
+    each other and with the image's size."""
+    import importlib.util
+    import os
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("predict_cli", os.path.join(root, "predict.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    assert len(cli.COCO_NAMES) == 81
+    rng = np.random.default_rng(5)
+    path, out = str(tmp_path / "im.jpg"), str(tmp_path / "det.npz")
+    Image.fromarray(rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)).save(path, quality=95)
+    with pytest.raises(SystemExit):
+        cli.main([path])                                   # neither -model nor --random-weights: refuses to guess
+    res = cli.main(["--random-weights", "--backbone", "resnet50", "--save", out, path])
+    printed = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    z = np.load(out)
+    n = z["class_ids"].shape[0]
+    assert z["masks"].shape == (n, 300, 400) and z["boxes"].shape == (n, 4) and z["scores"].shape == (n,)
+    assert len(res) == n and (len(printed) == n if n else printed == ["no instances"])
+    if n:
+        assert z["masks"].dtype == np.bool_ or z["masks"].dtype == np.uint8
+        assert (z["class_ids"] > 0).all() and (z["class_ids"] < 81).all()
+        assert (z["boxes"][:, 0] >= 0).all() and (z["boxes"][:, 2] <= 300).all() and (z["boxes"][:, 3] <= 400).all()
+        assert (np.diff(z["scores"]) <= 1e-7).all()        # by descending score, as the reference returns them
+    # a grey image file is read as RGB (grey2rgb in the reference)
+    gpath = str(tmp_path / "g.png")
+    Image.fromarray(rng.integers(0, 256, (64, 80), dtype=np.uint8)).save(gpath)
+    assert cli.read_image(gpath).shape == (64, 80, 3)
