@@ -420,6 +420,7 @@ def main():
                          f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    local = mdist.device_index(local)   # LOCAL_RANK, or cuda:0 for every rank of a one-GPU rehearsal (MRCNN_DIST_REHEARSAL=1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -600,7 +601,8 @@ def main():
                                    f"{args.proposals} proposals/img, {cfg.detection_max_instances} mask slots/img",
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}: image shards, replicated weights, one RCCL all-gather of "
-                                      f"detections [{world * args.batch},{cfg.detection_max_instances},6]",
+                                      f"detections [{world * args.batch},{cfg.detection_max_instances},6]"
+                                      + (" — REHEARSAL: all ranks on one GPU over gloo, not a measurement" if mdist.rehearsal() else ""),
                        "hipgraph": bool(args.graph),
                        "conv3x3": (("winograd F(4x4,3x3) on maps of >= 8 tiles of 16x32 pixels per image"
                                     + ("" if modules.WINOGRAD4_TRUNK else " (FPN smoothing and RPN only)")

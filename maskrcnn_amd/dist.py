@@ -27,11 +27,23 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MRCNN_DIST_REHEARSAL=1: several ranks on ONE GPU box (all on cuda:0, gloo moves the detections block): RCCL refuses
+            # two ranks on one device, and the multi-rank control flow of bench.py can be exercised this way where only one GPU
+            # is to be had. Never a measurement: the ranks share the card.
+            backend = "gloo" if (rehearsal() or not torch.cuda.is_available()) else "nccl"
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def rehearsal() -> bool:
+    return os.environ.get("MRCNN_DIST_REHEARSAL") == "1"
+
+
+def device_index(local_rank: int) -> int:
+    """The GPU a rank drives: its LOCAL_RANK; in a one-GPU rehearsal every rank drives cuda:0."""
+    return 0 if rehearsal() else local_rank
 
 
 def shard_range(global_batch: int, rank: int, world: int) -> tuple[int, int]:
