@@ -665,7 +665,10 @@ def config5_entry(dev, args, ops, modules, InferenceConfig, MaskRCNNInference):
             "conv_frac_of_per_launch_roofline": round(floor_ms / ms, 4),
             "conv_launches": len(prof) // max(1, args.roofline_steps), "conv_launches_hbm_bound_at_peak": hbm_bound,
             "per_launch_roofline_note": "sum over launches of max(algorithmic FLOPs / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s) / summed "
-                                        "launch durations: most 1x1 layers of this path have their HBM floor above their fp16-MFMA floor",
+                                        "launch durations: most 1x1 layers of this path have their HBM floor above their fp16-MFMA floor; "
+                                        "the fp16-MFMA launches are power-bound on random data (the same kernel on all-zero operands "
+                                        "runs 1.3x faster: tools/f16_dvfs_probe.py, DESIGN.md 5.2a), so the nominal 2.5 PFLOP/s is not "
+                                        "reachable on real activations",
             "mean_detections": round(float(det.counts.float().mean().item()), 1)}
 
 
