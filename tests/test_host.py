@@ -213,3 +213,16 @@ def test_bench_traffic_measurement_degrades_to_a_reason_without_a_gpu(monkeypatc
         return
     got, why = bench.measure_traffic_in_run(args, 128, 128)
     assert got is None and isinstance(why, str) and why
+
+
+def test_dist_rehearsal_switch(monkeypatch):
+    """MRCNN_DIST_REHEARSAL=1 (several ranks on one GPU box over gloo, for rehearsing bench.py's multi-rank control flow): every
+    rank drives cuda:0; without it a rank drives its LOCAL_RANK."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mdist_r", os.path.join(ROOT, "maskrcnn_amd", "dist.py"))
+    mdist = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mdist)
+    monkeypatch.delenv("MRCNN_DIST_REHEARSAL", raising=False)
+    assert not mdist.rehearsal() and [mdist.device_index(r) for r in range(4)] == [0, 1, 2, 3]
+    monkeypatch.setenv("MRCNN_DIST_REHEARSAL", "1")
+    assert mdist.rehearsal() and [mdist.device_index(r) for r in range(4)] == [0, 0, 0, 0]
