@@ -111,8 +111,18 @@ def measure_traffic_in_run(args, H, W):
                    "--precision", args.precision, "--meta", os.path.join(d, "meta.json")]
             t0 = time.perf_counter()
             with open(os.path.join(d, "log.txt"), "w") as lf:
-                rc = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=lf, stderr=lf,
-                                    timeout=args.traffic_timeout).returncode
+                # its own session: on a timeout the WHOLE group goes (rocprofv3 is a wrapper; a profiled python left behind
+                # would share the GPU with the timed region)
+                proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=lf, stderr=lf,
+                                        start_new_session=True)
+                try:
+                    rc = proc.wait(timeout=args.traffic_timeout)
+                except subprocess.TimeoutExpired:
+                    import signal
+                    with contextlib.suppress(ProcessLookupError):
+                        os.killpg(proc.pid, signal.SIGKILL)
+                    proc.wait()
+                    raise
             if rc != 0:
                 with open(os.path.join(d, "log.txt")) as lf:
                     tail = lf.read()[-400:]
@@ -374,9 +384,51 @@ def cpu_baseline(sd, cfg, n_images, seed):
                       f"(torch-CPU fp32 convs + C nms/crop), {t:.2f} s/image, host cpus={os.cpu_count()}"}
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N-rank job as a CHILD process — `python -m
+    torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <same
+    arguments>` — relay rank 0's JSON line on stdout and return the child's exit code. This process never touches the GPU (a
+    process that has must not be replaced or forked into a launcher); `torch.cuda.device_count()` does not initialise it.
+    `--dry-run-launch` prints the child command as one JSON line instead of running it."""
+    import socket
+    import subprocess
+    with socket.socket() as s:   # a free port: two benches on one node must not collide on 29500
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = [a for a in argv if a != "--dry-run-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MASTER_PORT", None)
+    if args.dry_run_launch:
+        print(json.dumps({"launch": cmd, "env": {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}}), flush=True)
+        return 0
+    rehearsal = os.environ.get("MRCNN_DIST_REHEARSAL") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not rehearsal:
+        log(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s)")
+        return 2
+    log("[bench] launching: " + " ".join(cmd))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        for ln in proc.stdout:   # rank 0's line goes to our stdout, anything else a rank printed to stderr
+            tgt = sys.stdout if ln.lstrip().startswith('{"metric"') else sys.stderr
+            tgt.write(ln)
+            tgt.flush()
+        return proc.wait()
+    except BaseException:
+        import signal
+        with contextlib.suppress(ProcessLookupError):
+            os.killpg(proc.pid, signal.SIGTERM)
+        proc.wait()
+        raise
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="with --gpus N > 1 outside torchrun: print the child command bench.py would start, and exit")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reps", type=int, default=3, help="timed repetitions of --steps steps; value = the median one")
@@ -401,10 +453,14 @@ def main():
     ap.add_argument("--measure-traffic", type=int, default=1,
                     help="N=1 only: measure roofline.traffic in this run (two rocprofv3 --pmc child passes of tools/profile_step.py, "
                          "about a minute); 0 = report the committed profile's figure instead")
-    ap.add_argument("--traffic-timeout", type=int, default=300, help="seconds allowed per counter pass")
+    ap.add_argument("--traffic-timeout", type=int, default=120, help="seconds allowed per counter pass")
     ap.add_argument("--alt-config5", type=int, default=1,
                     help="also time BASELINE configs[4]'s geometry (R101-FPN, 832x1344, fp16 MFMA path) on this GPU, N=1 only")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N`, N > 1, not under torchrun: become the launcher (before anything here touches the GPU)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     # the counter passes are child processes: started before this process initialises the GPU
     measured, measured_reason = None, "--measure-traffic 0"
@@ -583,6 +639,10 @@ def main():
                    "sample": "FAILED", "error": repr(e)}
             cpu_failed = True
 
+    td = torch.distributed
+    dist_backend = td.get_backend() if (td.is_available() and td.is_initialized()) else None
+    rccl_ranks = td.get_world_size() if dist_backend == "nccl" else 0
+    mdist.check_gather_errors()   # the device-side flag of poisoned detection blocks, read once, after every timed region
     if rank == 0:
         line = {
             "metric": f"images/sec at {H}x{W}, {args.proposals} proposals/img (Mask R-CNN inference hot path)",
@@ -592,6 +652,7 @@ def main():
                                   "images_per_s": [round(n_images / t, 2) for t in reps],
                                   "min": round(n_images / max(reps), 2), "max": round(n_images / min(reps), 2)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dist_backend": dist_backend, "rccl_ranks": rccl_ranks,
             "dtype": {"f32": "f32", "f16x3": "f16x3 split operands, f32 accumulate",
                       "f16": "f16 operands, f32 accumulate"}[args.precision],
             "data": "synthetic (seeded uint8-range images minus MEAN_PIXEL; reference-init random weights, "

@@ -14,6 +14,7 @@
 //     1 KiB of consecutive channels of the NHWC output.
 #pragma clang fp contract(off)
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -602,7 +603,11 @@ extern "C" int mrcnn_crop_forward_f32(const float* image, int32_t batch, int32_t
             const dim3 grid = mode == 0 ? dim3(num_boxes, slabs) : dim3(static_cast<unsigned>(wgs));
             int ring_slots = CS_RING_SLOTS;
             if (const char* e = getenv("MRCNN_CROP_RING")) ring_slots = atoi(e) >= 512 && atoi(e) % 256 == 0 && atoi(e) <= 4096 ? atoi(e) : ring_slots;
-            const size_t lds = static_cast<size_t>(ring_slots) * 16 + 16;   // + the dword a (lo, lo+1) pair may read past the last slot
+            // + the dword a (lo, lo+1) pair may read past the last slot; and never less than the in-launch gather fallback
+            // (footprints of more than 256 slots) writes from the start of LDS: its sample table + one Tap per crop position
+            // (16 x 16 crops: 512 + 8192 B, more than the default ring)
+            const size_t lds = std::max(static_cast<size_t>(ring_slots) * 16 + 16,
+                                        sizeof(Sample) * (crop_height + crop_width) + sizeof(Tap) * plane);
             hipLaunchKernelGGL(crop_forward_nchw_staged, grid, dim3(64), lds, s, image, batch, depth,
                                height, width, boxes, box_index, num_boxes, extrapolation_value, crop_height, crop_width, cpw,
                                slabs, mode, ring_slots, crops);

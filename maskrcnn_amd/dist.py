@@ -53,7 +53,8 @@ def shard_range(global_batch: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_detections(packed: torch.Tensor, counts: torch.Tensor, global_batch: int | None = None):
+def all_gather_detections(packed: torch.Tensor, counts: torch.Tensor, global_batch: int | None = None,
+                          max_detections: int | None = None):
     """packed [B_local, D, 6] fp32, counts [B_local] int32 → ([G, D, 6], [G] int32) in global image order
     (rank-major under shard_range). Identity at world 1.
 
@@ -61,47 +62,81 @@ def all_gather_detections(packed: torch.Tensor, counts: torch.Tensor, global_bat
     exact in fp32 for counts < 2^24). `global_batch` (G) tells how the batch was sharded: ranks then own
     shard_range(G, r, world) images, which differ by one image when G % world != 0 — all_gather_into_tensor needs
     identical shapes, so every rank pads its block to ceil(G / world) images (count 0) and the padding is stripped
-    after the gather. Without `global_batch` every rank must hold the same B_local (G = world * B_local)."""
+    after the gather. Without `global_batch` every rank must hold the same B_local (G = world * B_local).
+    `max_detections` (D) is what every rank EXPECTS; without it the first healthy call fixes it for the process."""
     if not _collectives_on():
         return packed, counts
     world, rank = dist.get_world_size(), dist.get_rank()
-    b, d = packed.size(0), packed.size(1)
+    # Is this rank's shard what every other rank expects? Decided BEFORE any of its sizes is used to shape the block: a rank
+    # whose shard disagrees with shard_range (or is not [b, D, 6] at all) must neither raise before the collective — the other
+    # ranks would sit in all_gather_into_tensor until the backend's timeout — nor send a block of another shape. It sends a
+    # poisoned block of the EXPECTED shape (count rows = -1) and EVERY rank raises after the gather.
+    well_formed = packed.dim() == 3 and packed.size(2) == 6 and counts.dim() == 1
+    d_exp = max_detections if max_detections is not None else _EXPECTED_D.get("d")
+    if d_exp is None:
+        if not well_formed:
+            raise RuntimeError("all_gather_detections: first call with a malformed block and no max_detections: the "
+                               "expected shape is unknown (pass max_detections=)")
+        d_exp = packed.size(1)
+    b = packed.size(0) if packed.dim() >= 1 else -1
     if global_batch is None:
+        # every rank claims its own b: nothing to check it against, b IS the expectation
         sizes = [b] * world
     else:
         sizes = [hi - lo for lo, hi in (shard_range(global_batch, r, world) for r in range(world))]
     b_max = max(sizes)
-    # A rank whose shard disagrees with shard_range must not raise BEFORE the collective — the other ranks would sit in
-    # all_gather_into_tensor until the backend's timeout. It sends a poisoned block instead (count row = -1, the shape
-    # every rank expects) and EVERY rank raises after the gather: the failure is loud on all of them.
-    ok = sizes[rank] == b and counts.numel() == b and packed.dim() == 3 and packed.size(2) == 6
-    block = packed.new_zeros(b_max, d + 1, 6)
+    ok = well_formed and sizes[rank] == b and counts.numel() == b and packed.size(1) == d_exp
+    d = d_exp
+    block = torch.zeros(b_max, d + 1, 6, dtype=torch.float32, device=counts.device if not well_formed else packed.device)
     if ok:
+        _EXPECTED_D.setdefault("d", d)
         block[:b, :d] = packed
-        block[:b, d, 0] = counts.to(packed.dtype)
+        block[:b, d, 0] = counts.to(block.dtype)
     else:
         block[:, d, 0] = -1.0
-    out = packed.new_empty(world * b_max, d + 1, 6)
+    out = block.new_empty(world * b_max, d + 1, 6)
     dist.all_gather_into_tensor(out, block)
     if not ok:
-        raise RuntimeError(f"all_gather_detections: rank {rank} holds {b} images (counts {counts.numel()}), "
-                           f"shard_range({global_batch}, {rank}, {world}) says {sizes[rank]}")
+        raise RuntimeError(f"all_gather_detections: rank {rank} holds a block of shape {tuple(packed.shape)} with "
+                           f"{counts.numel()} counts; shard_range({global_batch}, {rank}, {world}) x max_detections says "
+                           f"[{sizes[rank]}, {d}, 6]")
     # The healthy ranks learn of it from the gathered count rows. Looking at them is a device-to-host read, so it is done on
-    # the FIRST step of every sharding layout (set-up-time validation: a layout that was right once stays right) and not in
-    # the steady state, which stays free of host synchronisation; the poisoned counts (-1) travel on to the caller anyway.
+    # the FIRST step of every sharding layout (set-up-time validation) — and on every LATER step the same test is folded into
+    # a device-side flag without a host read (`check_gather_errors()` reads it once, where the caller can afford a sync: after
+    # its timed region, at the end of a serving window); the poisoned counts (-1) travel on to the caller in any case.
     layout = (tuple(sizes), d, str(out.device))
+    bad_rows = out[:, d, 0] < 0
     if layout not in _VALIDATED:
-        neg = (out[:, d, 0] < 0).nonzero().flatten().tolist()
+        neg = bad_rows.nonzero().flatten().tolist()
         if neg:
             bad = sorted({int(i) // b_max for i in neg})
             raise RuntimeError(f"all_gather_detections: rank(s) {bad} hold a shard that disagrees with "
                                f"shard_range({global_batch}, r, {world})")
         _VALIDATED.add(layout)
+    else:
+        flag = _ERR_FLAG.get(str(out.device))
+        if flag is None:
+            flag = _ERR_FLAG[str(out.device)] = torch.zeros(world, dtype=torch.int32, device=out.device)
+        flag += bad_rows.view(world, b_max).any(dim=1).to(torch.int32)   # per rank; no host read
     if min(sizes) != b_max:  # strip the padding rows (index list cached per layout: no per-step host-to-device copy)
         out = out.index_select(0, _strip_index(tuple(sizes), b_max, out.device))
     return out[:, :d].contiguous(), out[:, d, 0].to(torch.int32)
 
 
+def check_gather_errors() -> None:
+    """Reads (one device-to-host copy) and clears the device-side flags all_gather_detections keeps after its first step:
+    raises if any rank sent a poisoned block since the last check."""
+    for key, flag in list(_ERR_FLAG.items()):
+        hits = flag.tolist()
+        flag.zero_()
+        bad = [r for r, n in enumerate(hits) if n]
+        if bad:
+            raise RuntimeError(f"all_gather_detections: rank(s) {bad} sent a poisoned detections block "
+                               f"({[hits[r] for r in bad]} step(s)) since the last check")
+
+
+_EXPECTED_D: dict = {}
+_ERR_FLAG: dict = {}
 _VALIDATED: set = set()
 _STRIP_CACHE: dict = {}
 

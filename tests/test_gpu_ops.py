@@ -206,7 +206,10 @@ def test_crop_forward_staged_path_vs_oracle(dev, oracle, monkeypatch):
     cases = [(2, 70, 64, 64, 40, 14, 14, 0.02, 0.9), (1, 256, 256, 256, 48, 14, 14, 0.02, 0.12),
              (3, 37, 40, 48, 50, 16, 16, 0.02, 0.5), (1, 5, 8, 8, 20, 2, 2, 0.1, 0.9), (1, 9, 12, 20, 20, 4, 1, 0.05, 0.9),
              (1, 130, 32, 32, 30, 8, 8, 0.02, 0.3), (2, 64, 128, 128, 30, 1, 4, 0.02, 0.4), (1, 19, 16, 36, 25, 14, 14, 0.3, 1.5),
-             (1, 1, 4, 4, 7, 2, 6, 0.1, 0.9), (1, 256, 32, 32, 64, 14, 14, 0.02, 0.12)]
+             (1, 1, 4, 4, 7, 2, 6, 0.1, 0.9), (1, 256, 32, 32, 64, 14, 14, 0.02, 0.12),
+             # plane = 256 crops whose whole-image box takes the in-launch gather fallback: its Tap table (32 B per position)
+             # + sample table is LARGER than the default DMA ring — the launch must size its LDS for it (8 x 32: 8832 B)
+             (1, 24, 96, 96, 12, 8, 32, 0.3, 0.95), (2, 17, 80, 64, 9, 32, 8, 0.4, 0.95), (1, 33, 72, 72, 8, 16, 16, 0.5, 0.99)]
     for (b, c, h, w, n, ch, cw, lo, hi) in cases:
         img = torch.randn(b, c, h, w, generator=g)
         img[img.abs() < 0.05] = -0.0

@@ -136,10 +136,25 @@ def _gather_worker(rank, world, port, q, global_batch):
                                     global_batch=global_batch)
     except RuntimeError as e:
         one_sided = str(e)
+    # steady state (the layout was validated by the first call): the LAST rank goes bad with a block that is not even 3-D.
+    # It must still send the expected shape (no hang, no shape mismatch inside the collective) and raise afterwards; the
+    # healthy rank returns without a host read, and check_gather_errors() reports the bad rank.
+    late = None
+    try:
+        if r == w - 1:
+            mdist.all_gather_detections(torch.zeros(b_local, d), counts, global_batch=global_batch)
+        else:
+            mdist.all_gather_detections(packed, counts, global_batch=global_batch)
+            mdist.check_gather_errors()
+    except RuntimeError as e:
+        late = str(e)
+    if w > 1:
+        assert late is not None and (("rank(s) [%d]" % (w - 1)) in late or "holds a block" in late), late
+    mdist.check_gather_errors()   # cleared by the read above: a second check is silent
     mdist.barrier()
     t = mdist.max_over_ranks(float(r + 1), "cpu")
     q.put((r, tuple(gp.shape), gp[:, 0, 0].tolist(), gp[:, 3, 5].tolist(), gc.tolist(), str(gc.dtype), t, len(calls),
-           bad is not None and one_sided is not None))
+           bad is not None and one_sided is not None and late is not None))
     torch.distributed.destroy_process_group()
 
 
@@ -226,3 +241,28 @@ def test_dist_rehearsal_switch(monkeypatch):
     assert not mdist.rehearsal() and [mdist.device_index(r) for r in range(4)] == [0, 1, 2, 3]
     monkeypatch.setenv("MRCNN_DIST_REHEARSAL", "1")
     assert mdist.rehearsal() and [mdist.device_index(r) for r in range(4)] == [0, 0, 0, 0]
+
+
+def test_bench_self_launch_builds_the_torchrun_child_command():
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE) becomes the launcher of `python -m torch.distributed.run
+    --nproc-per-node N bench.py --gpus N ...` — a child process, a free port, the caller's own arguments — before anything
+    touches the GPU; --dry-run-launch prints that command instead of running it."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2",
+                        "--dry-run-launch"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    cmd = rec["launch"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    i = cmd.index("--master-addr")
+    assert cmd[i + 1] == "127.0.0.1" and cmd[i + 2] == "--master-port" and 1024 < int(cmd[i + 3]) < 65536
+    j = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[j + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    assert rec["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under torchrun (WORLD_SIZE set) bench.py does NOT re-launch: with a world that disagrees with --gpus it refuses
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run-launch"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                                MASTER_PORT=str(_free_port())), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 8" in r.stderr
