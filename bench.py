@@ -177,8 +177,13 @@ def conv_roofline(prof, args, H, W, modules, measured=None, measured_reason=None
 
     whole = agg([True] * len(prof))
     by_tag = {t: agg([x == t for x in tag]) for t in sorted(set(tag))}
-    dominant = max(by_tag, key=lambda t: by_tag[t]["ms_per_step"])
-    dom = by_tag[dominant]
+    ranked = sorted(by_tag, key=lambda t: -by_tag[t]["ms_per_step"])
+    # The dominant kernel FAMILY — and every family within 5 % of its summed time: with two co-dominant families (the direct
+    # implicit GEMM and the F(4x4) Winograd kernel are 1-2 % apart in this step) `frac` is the fraction of BOTH together, and
+    # each is listed under `co_dominant`, so the line cannot quote the better half
+    dom_tags = [t for t in ranked if by_tag[t]["ms_per_step"] >= 0.95 * by_tag[ranked[0]]["ms_per_step"]]
+    dominant = ranked[0]
+    dom = agg([x in dom_tags for x in tag])
     kernel_of = {"winograd": "conv3x3_wino8_f32", "winograd_spatial": "conv3x3_wino8s_f32", "winograd4": "conv3x3_wino4_f32",
                  "direct": "conv_igemm_f32",
                  "stem": "stem7x7_s2_f32",
@@ -200,10 +205,13 @@ def conv_roofline(prof, args, H, W, modules, measured=None, measured_reason=None
     # profiles/summarize_pmc.py into a file that records the mode it was taken in; anything else → null
     traffic, traffic_src, in_run, conv_traffic, counters = None, None, False, None, None
     # the kernels behind a tag: the direct implicit GEMM is two kernels since the streaming 1x1 kernel (same arithmetic)
-    members = {"direct": ("conv_igemm_f32", "conv_pw_stream_f32")}.get(dominant, (kernel_of.get(dominant, dominant),))
+    def members_of(t):
+        return {"direct": ("conv_igemm_f32", "conv_pw_stream_f32")}.get(t, (kernel_of.get(t, t),))
 
-    def summed(per_kernel, field):
-        rows = [per_kernel[m] for m in members if m in per_kernel]
+    members = tuple(m for t in dom_tags for m in members_of(t))
+
+    def summed(per_kernel, field, mem=None):
+        rows = [per_kernel[m] for m in (mem or members) if m in per_kernel]
         return (sum(r[field] for r in rows), sum(r["launches_per_step"] for r in rows)) if rows else (None, None)
 
     if measured is not None:   # this run's own counter passes (measure_traffic_in_run)
@@ -246,7 +254,18 @@ def conv_roofline(prof, args, H, W, modules, measured=None, measured_reason=None
                 traffic_src = "profiles/" + TRAFFIC_PROFILE
         except (OSError, ValueError, KeyError):
             traffic = None
-    return {"bound": "mfma", "kernel": " + ".join(members),
+    co = []
+    for t in dom_tags:
+        row = dict(family=t, kernel=" + ".join(members_of(t)), **by_tag[t])
+        if measured is not None:
+            tb, tl = summed(measured.get("per_kernel", {}), "hbm_bytes_per_step", members_of(t))
+            if tb is not None and tl == by_tag[t]["launches_per_step"]:
+                row["traffic"] = tb
+                row["traffic_over_algorithmic"] = round(tb / max(1, by_tag[t]["algorithmic_bytes_per_step"]), 3)
+        co.append(row)
+    return {"bound": "mfma", "kernel": " + ".join(members), "co_dominant": co,
+            "co_dominant_note": "every kernel family whose summed launch time is within 5 % of the largest; achieved / frac / "
+                                "traffic / algorithmic_bytes of this object are over ALL of them together",
             "achieved": dom["executed_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["executed_frac"],
             "definition": "achieved = multiply-adds the kernel executes x 2 (Winograd F(2x2,3x3): 2*M*N*K / 2.25, F(4x4,3x3): / 4) / "
                           "summed launch durations of that kernel in one step (HIP events on the launch stream); "

@@ -39,6 +39,14 @@ class Detections:
         return torch.cat([self.class_ids.float().unsqueeze(-1), self.scores.unsqueeze(-1), self.boxes], -1)
 
 
+def max_batch_per_launch(cfg: InferenceConfig) -> int:
+    """Largest per-GPU batch one pass of the step takes: every activation tensor stays under the kernels' 2^30-element limit
+    (32-bit byte offsets), so that no layer's kernel choice depends on the batch. The largest tensor per image is the RPN's
+    512-channel shared activation on P2, (H/4)(W/4) x 512 = 32 HW elements (the stem's output is 16 HW): 31 images at 1024^2,
+    29 at 832 x 1344. predict() splits larger batches into equal sub-batches."""
+    return max(1, ((1 << 30) - 1) // (32 * cfg.image_height * cfg.image_width))
+
+
 class MaskRCNNInference:
     def __init__(self, state_dict: dict, cfg: InferenceConfig | None = None, device="cuda:0",
                  precision: str = "f32"):
@@ -59,6 +67,7 @@ class MaskRCNNInference:
         self.mask = modules.FusedMask(state_dict, self.device, precision=precision)
         self.anchors = pyramid_anchors(c).to(self.device)
         self.image_area = float(c.image_height * c.image_width)
+        self.max_batch = max_batch_per_launch(c)
 
     # ---------------------------------------------------------------- stage 1: proposals
     def rpn_heads(self, fms):
@@ -111,6 +120,16 @@ class MaskRCNNInference:
         assert images.is_cuda and images.dtype == torch.float32
         b = images.size(0)
         assert tuple(images.shape[1:]) == (3, c.image_height, c.image_width)
+        if b > self.max_batch:
+            # Which kernel a layer takes (F(4x4) / F(2x2) / fused conv3) must never depend on the batch — image i of a batch
+            # equals image i alone bit for bit — but the kernels address tensors with 32-bit element offsets (< 2^30 elements),
+            # so past max_batch a layer would fall to another kernel. Oversized batches therefore run as equal sub-batches.
+            assert not return_intermediates, f"return_intermediates needs batch <= {self.max_batch} at this image size"
+            n = -(-b // self.max_batch)
+            step = -(-b // n)
+            parts = [self.predict(images[i:i + step], windows[i:i + step], with_masks) for i in range(0, b, step)]
+            cat = lambda f: torch.cat([getattr(p_, f) for p_ in parts], 0)
+            return Detections(cat("class_ids"), cat("scores"), cat("boxes"), cat("counts"), cat("masks") if with_masks else None)
         fms = self.backbone(images)                                        # [P2..P6] NHWC
         scores, deltas = self.rpn_heads(fms)
         rois, roi_counts, rpn_dets = self.proposals(scores, deltas)

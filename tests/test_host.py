@@ -266,3 +266,47 @@ def test_bench_self_launch_builds_the_torchrun_child_command():
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                                 MASTER_PORT=str(_free_port())), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 8" in r.stderr
+
+
+def test_bench_roofline_reports_co_dominant_families_together():
+    """When the two largest kernel families are within 5 % of each other's summed time (direct implicit GEMM vs F(4x4) in the
+    headline step), roofline.frac is the fraction of BOTH together and each is listed — the line cannot quote the better half."""
+    import argparse
+    import bench
+    from types import SimpleNamespace as NS
+
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    def row(ms, flops, tag, t0=[0.0]):
+        a = Ev(t0[0]); t0[0] += ms
+        return (a, Ev(t0[0]), flops, (1, 1, 1), 1000, tag)
+    peak = bench.F32_MFMA_PEAK_TFLOPS * 1e12
+    # direct: 8.3 ms at 0.76 of peak; winograd4: 8.2 ms at 0.62 executed (x4 algorithmic); stem: 0.5 ms
+    prof = [row(8.3, 0.76 * peak * 8.3e-3, "direct"), row(8.2, 4 * 0.62 * peak * 8.2e-3, "winograd4"), row(0.5, 1e9, "stem")]
+    args = argparse.Namespace(roofline_steps=1, precision="f32", dump_conv=None, batch=8, arch="resnet50", proposals=1000)
+    mods = NS(WINOGRAD=True, STEM_KERNEL=True, FUSED_BOTTLENECK=False, RPN_FUSED_HEADS=True, WINOGRAD4=True, WINOGRAD4_TRUNK=True)
+    r = bench.conv_roofline(prof, args, 1024, 1024, mods, None, "test")
+    assert [c["family"] for c in r["co_dominant"]] == ["direct", "winograd4"]
+    assert abs(r["co_dominant"][0]["executed_frac"] - 0.76) < 1e-3 and abs(r["co_dominant"][1]["executed_frac"] - 0.62) < 1e-3
+    assert abs(r["frac"] - (0.76 * 8.3 + 0.62 * 8.2) / 16.5) < 1e-3 and r["launches_per_step"] == 2
+    assert "conv_igemm_f32" in r["kernel"] and "conv3x3_wino4_f32" in r["kernel"]
+    # a clear winner stays alone
+    prof = [row(8.3, 0.76 * peak * 8.3e-3, "direct"), row(6.0, 4 * 0.62 * peak * 6.0e-3, "winograd4")]
+    r = bench.conv_roofline(prof, args, 1024, 1024, mods, None, "test")
+    assert [c["family"] for c in r["co_dominant"]] == ["direct"] and abs(r["frac"] - 0.76) < 1e-3
+
+
+def test_max_batch_per_launch_bound():
+    """pipeline.max_batch_per_launch: the batch up to which every layer keeps the kernel it takes at batch 1 (2^30-element limit of
+    the 32-bit offsets; the RPN's shared activation on P2 is the largest tensor)."""
+    from maskrcnn_amd.config import InferenceConfig
+    from maskrcnn_amd.pipeline import max_batch_per_launch
+    for h, w in ((1024, 1024), (832, 1344), (256, 256)):
+        m = max_batch_per_launch(InferenceConfig(image_height=h, image_width=w))
+        assert m * (h // 4) * (w // 4) * 512 < (1 << 30) <= (m + 1) * (h // 4) * (w // 4) * 512
+    assert max_batch_per_launch(InferenceConfig(image_height=1024, image_width=1024)) == 31
