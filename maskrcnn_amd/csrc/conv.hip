@@ -24,7 +24,6 @@
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
-#include <utility>
 
 namespace {
 
@@ -455,335 +454,6 @@ __global__ __launch_bounds__(256, 2) void conv_pw_stream_f32(const ConvParams p)
     }
 }
 
-
-// ---- persistent, software-pipelined 1x1 kernel: the epilogue of tile t is DRAINED INSIDE the main loop of tile t + 1 (round 4) ----
-// Bottleneck conv3 / downsample and the FPN laterals (model.py:183-184,254-262,145-152) are short-K GEMMs with big outputs:
-// per tile the tiled kernel above does a main loop that moves almost nothing and an epilogue that moves almost everything
-// (residual read + output write: 268 of the 303 MB of a C4 conv3), and its co-resident workgroups run IN LOCK-STEP — two
-// workgroups that share a SIMD each get half the MFMA pipe while both are in their main loop, and the one that lags catches up
-// at full speed while the other sits in its epilogue: the lag halves every tile, lock-step is the attractor (which is why the
-// start-up stagger of round 3 changed nothing). In-kernel stamps agree: 31 k cycles of epilogue per tile on a C4 conv3 = every
-// workgroup of the chip storing at once at ~5 TB/s, after 71 k cycles in which HBM idles: MFMA time and memory time ADD.
-// Here they overlap by construction, inside ONE instruction stream:
-//   * a persistent workgroup walks its tiles (XCD-aware order, N fastest) as one continuous stream of k tiles: the staging
-//     loads of the last two k tiles of tile t already fetch k tiles 0, 1 of tile t + 1 — no prologue, no exposed round trip;
-//   * when a tile's last MFMA retires, its accumulators move to a second register set and the next tile's MFMAs start at
-//     once; the finished tile leaves piece by piece between those MFMAs over the first U k tiles: per k tile D / U residual
-//     loads go out in chunk 0 and the D / U affine + residual + ReLU + store pieces follow in the last chunk (one per MFMA
-//     slot), so the memory system sees the epilogue traffic spread over the whole tile time;
-//   * barriers are LDS-only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would wait for the drain's stores.
-// Same products in the same order per output, same epilogue expression: bit-identical to conv_igemm_f32 (tested).
-// POINTWISE layers only (1x1, no padding, Cin % (U * BK) == 0); epilogue variants 0 (plain), 1 (residual), 2 (half-size
-// residual); NHWC or k-blocked output / residual.
-template <typename F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-__device__ __forceinline__ bool tile_origin_v(const ConvCommon& p, int t, int BM, int BN, int& m0, int& n0) {
-    const int xcd = t & 7, seq = t >> 3;
-    const int mt_lo = (xcd * p.tiles_m) >> 3, mt_hi = ((xcd + 1) * p.tiles_m) >> 3;
-    const int mt = mt_lo + seq / p.tiles_n;
-    if (mt >= mt_hi) return false;
-    m0 = mt * BM;
-    n0 = (seq % p.tiles_n) * BN;
-    return true;
-}
-
-template <int BM, int BN, int BK, int RES, int U>
-__global__ __launch_bounds__(256, 2) void conv_pw_pipe_f32(const ConvParams p) {
-    static_assert(RES == 0 || RES == 1 || RES == 2, "plain / residual / half-size residual");
-    constexpr int WM = 2, WN = 2;
-    constexpr bool SWZ = BK == 16;
-    constexpr int LDS_STRIDE = SWZ ? BK : BK + 4;
-    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
-    constexpr int TPR = BK / 4, RPP = 256 / TPR, PA = BM / RPP, PB = BN / RPP, NP = PA + PB;
-    constexpr int NCH = BK / 8, NM = 4 * TM * TN;
-    constexpr int D = TM * TN * 16, PK = D / U;   // accumulator registers per lane; drain pieces per k tile
-    static_assert(TM >= 1 && TN >= 1 && PA >= 1 && PB >= 1 && NCH >= 2 && D % U == 0 && (!SWZ || RPP % 16 == 0), "tile shape");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Bs = smem + 2 * BM * LDS_STRIDE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, lh = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
-    const int kq = tid % TPR, r0 = tid / TPR;
-    const int total = 8 * ((p.tiles_m + 7) / 8) * p.tiles_n;
-    const int nk = p.K / BK;
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual), 0, RES ? p.r_bytes : 0u, 0x00020000);
-
-    // the next valid virtual tile at or after t (a workgroup's tiles: blockIdx.x, + gridDim.x, ...); -1 = none
-    auto next_tile = [&](int t, int& m0, int& n0) -> int {
-        for (; t < total; t += gridDim.x)
-            if (tile_origin_v(p, t, BM, BN, m0, n0)) return t;
-        return -1;
-    };
-    // staging offsets of a tile: fixed byte offsets per thread (k tile = the scalar offset of the loads), OOB where zero
-    unsigned a_voff[PA], b_voff[PB];
-    auto stage_setup = [&](bool valid, int m0, int n0) {
-        int a_off[PA], a_iy[PA], a_ix[PA];
-        row_setup<PA, RPP>(p, m0, r0, a_off, a_iy, a_ix);
-#pragma unroll
-        for (int i = 0; i < PA; ++i)
-            a_voff[i] = (valid && (m0 + r0 + RPP * i) < p.M) ? static_cast<unsigned>(a_off[i] + kq * 4) * 4u : OOB;
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int n = n0 + r0 + RPP * i;
-            b_voff[i] = (valid && n < p.Cout) ? static_cast<unsigned>(n * p.K + kq * 4) * 4u : OOB;
-        }
-    };
-    float4 ra[PA], rb[PB];
-    auto load_piece = [&](int pc, int kk) {   // kk: first channel of the k tile (scalar offset; not range-checked: kk < K always)
-        const bool isa = pc < PA;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(isa ? x_rsrc : w_rsrc,
-                                                              static_cast<int>(isa ? a_voff[isa ? pc : 0] : b_voff[isa ? 0 : pc - PA]),
-                                                              kk * 4, 0);
-        const float4 f = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-        if (isa) ra[isa ? pc : 0] = f;
-        else rb[isa ? 0 : pc - PA] = f;
-    };
-    const int kqs = SWZ ? (kq ^ ((r0 >> 2) & 3)) : kq;
-    auto store_piece = [&](int pc, int buf) {
-        if (pc < PA)
-            *reinterpret_cast<float4*>(As + buf * BM * LDS_STRIDE + (r0 + RPP * pc) * LDS_STRIDE + kqs * 4) = ra[pc];
-        else
-            *reinterpret_cast<float4*>(Bs + buf * BN * LDS_STRIDE + (r0 + RPP * (pc - PA)) * LDS_STRIDE + kqs * 4) = rb[pc - PA];
-    };
-    const int fsw = SWZ ? ((ln >> 2) & 3) : 0;
-    const int frow = ln * LDS_STRIDE;
-    const int fch0 = (lh ^ fsw) * 4, fch1 = ((2 + lh) ^ fsw) * 4;
-    const int frag = frow + lh * 4;
-    const float* Aw = As + wm * WTM * LDS_STRIDE + (SWZ ? frow : frag);
-    const float* Bw = Bs + wn * WTN * LDS_STRIDE + (SWZ ? frow : frag);
-    float4 fa[2][TM], fb[2][TN];
-    auto read_frags = [&](int slot, int buf, int j) {
-        const int jo = SWZ ? (j == 0 ? fch0 : fch1) : j * 8;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-            fa[slot][i] = *reinterpret_cast<const float4*>(Aw + buf * BM * LDS_STRIDE + i * 32 * LDS_STRIDE + jo);
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-            fb[slot][i] = *reinterpret_cast<const float4*>(Bw + buf * BN * LDS_STRIDE + i * 32 * LDS_STRIDE + jo);
-    };
-    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-    // ---- per-tile output state: the tile being computed (c*) and the finished tile being drained (d*) -------------------
-    const unsigned row_bytes = p.out_mode == 2 ? 32u : static_cast<unsigned>(p.Cout) * 4u;
-    const unsigned rrow_bytes = p.res_kblocked ? 32u : static_cast<unsigned>(p.Cout) * 4u;
-    const unsigned rplane = static_cast<unsigned>(RES == 1 ? p.M : p.M >> 2) * 32u;
-    struct Out {
-        float sc[TN], sh[TN];
-        unsigned ycol[TN], rcol[RES ? TN : 1];
-        int mb;   // first row of the wave's tile + 4 * lh; rows beyond M are dropped
-    };
-    auto out_setup = [&](Out& o, bool valid, int m0, int n0) {
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
-            const int n = n0 + wn * WTN + jn * 32 + ln;
-            const bool n_ok = valid && n < p.Cout;
-            o.sc[jn] = (n_ok && p.scale) ? p.scale[n] : 1.0f;
-            o.sh[jn] = (n_ok && p.shift) ? p.shift[n] : 0.0f;
-            o.ycol[jn] = !n_ok ? OOB
-                         : p.out_mode == 2 ? static_cast<unsigned>(n >> 3) * (static_cast<unsigned>(p.M) * 32u) + static_cast<unsigned>(n & 7) * 4u
-                                           : static_cast<unsigned>(n) * 4u;
-            if constexpr (RES != 0)
-                o.rcol[jn] = !n_ok ? OOB
-                             : p.res_kblocked ? static_cast<unsigned>(n >> 3) * rplane + static_cast<unsigned>(n & 7) * 4u
-                                              : static_cast<unsigned>(n) * 4u;
-        }
-        o.mb = valid ? m0 + wm * WTM + 4 * lh : p.M;   // invalid: every row is beyond M
-    };
-    Out dn;   // of the tile being drained; the tile being computed needs none of it before it is finished
-    f32x16 acc[TM][TN], old[TM][TN];
-    float rres[RES ? PK : 1];
-    // drain piece q of the finished tile: register (i, jn, r) = (q / (16 TN), (q / 16) % TN, q % 16)
-    // (the opaque copy keeps the compiler from computing all D store / residual offsets of a tile ahead of its k loop — they are
-    // invariant there — and holding them in registers: +2 D registers, i.e. spills)
-    auto piece_row = [&](int q) {
-        const int i = q / (16 * TN), r = q % 16;
-        int mb = dn.mb;
-        asm volatile("" : "+v"(mb));
-        return mb + i * 32 + (r & 3) + 8 * (r >> 2);
-    };
-    auto res_load = [&](int q, int slot) {
-        if constexpr (RES != 0) {
-            const int jn = (q / 16) % TN;
-            const int m = piece_row(q);
-            const bool ok = m < p.M;
-            unsigned rrow;
-            if constexpr (RES == 1) {
-                rrow = ok ? static_cast<unsigned>(m) * rrow_bytes : OOB;
-            } else {
-                int b, oy, ox;
-                decode_pixel(p, ok ? m : 0, b, oy, ox);
-                rrow = ok ? static_cast<unsigned>((b * (p.OH >> 1) + (oy >> 1)) * (p.OW >> 1) + (ox >> 1)) * rrow_bytes : OOB;
-            }
-            rres[slot] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_rsrc, static_cast<int>(oob_add(rrow, dn.rcol[jn])), 0, 0));
-        }
-    };
-    auto drain = [&](int q, int slot) {
-        const int i = q / (16 * TN), jn = (q / 16) % TN, r = q % 16;
-        const int m = piece_row(q);
-        float v = old[i][jn][r] * dn.sc[jn] + dn.sh[jn];
-        if constexpr (RES != 0) v += rres[slot];
-        if (p.act) asm("v_max_f32 %0, 0, %0" : "+v"(v));
-        const unsigned yrow = m < p.M ? static_cast<unsigned>(m) * row_bytes : OOB;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), y_rsrc, static_cast<int>(oob_add(yrow, dn.ycol[jn])), 0, 0);
-    };
-
-    // ---- first tile: the only prologue of the workgroup ------------------------------------------------------------------
-    int m0 = 0, n0 = 0, nm0 = 0, nn0 = 0;
-    int t = next_tile(blockIdx.x, m0, n0);
-    if (t < 0) return;
-    stage_setup(true, m0, n0);
-    out_setup(dn, false, 0, 0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; old[i][j][r] = 0.f; }   // (the first tile drains nothing: rows beyond M)
-#pragma unroll
-    for (int pc = 0; pc < NP; ++pc) load_piece(pc, 0);
-#pragma unroll
-    for (int pc = 0; pc < NP; ++pc) store_piece(pc, 0);
-    lds_barrier();
-#pragma unroll
-    for (int pc = 0; pc < NP; ++pc) load_piece(pc, BK);
-    read_frags(0, 0, 0);
-
-    // one k tile of the stream. DRAIN: the finished tile's pieces u * PK .. + PK - 1 leave between this k tile's MFMAs
-    auto ktile = [&](int kt, auto drain_tag, auto u_tag) {
-        constexpr bool DRAIN = decltype(drain_tag)::value;
-        constexpr int UU = decltype(u_tag)::value;
-        const int buf = kt & 1;
-        // the k tile the last chunk's loads fetch: two ahead in the stream — past this tile's end that is k tile 0 / 1 of the
-        // NEXT tile (whose staging offsets replace this tile's just before, see below)
-        const int kk = (kt + 2 >= nk ? kt + 2 - nk : kt + 2) * BK;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int cur = j & 1;
-            if (j + 1 < NCH) {
-                read_frags(cur ^ 1, buf, j + 1);
-            } else {
-                lds_barrier();
-                read_frags(cur ^ 1, buf ^ 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float4 a = fa[cur][i];
-                    const float av = s == 0 ? a.x : s == 1 ? a.y : s == 2 ? a.z : a.w;
-#pragma unroll
-                    for (int jn = 0; jn < TN; ++jn) {
-                        const float4 b = fb[cur][jn];
-                        const float bv = s == 0 ? b.x : s == 1 ? b.y : s == 2 ? b.z : b.w;
-                        // a tile's first k step starts from the inline constant 0 (the drain bodies with u = 0 ARE every tile's
-                        // first k tile): no zeroing pass, and no register set of zeros kept alive for it
-                        if (DRAIN && UU == 0 && j == 0 && s == 0) {
-                            f32x16 z;
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, z, 0, 0, 0);
-                        } else {
-                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jn], 0, 0, 0);
-                        }
-                        const int m = (s * TM + i) * TN + jn;
-#pragma unroll
-                        for (int pc = m * NP / NM; pc < (m + 1) * NP / NM; ++pc) {
-                            if (j == NCH - 2) store_piece(pc, buf ^ 1);
-                            if (j == NCH - 1) load_piece(pc, kk);
-                        }
-                        if constexpr (DRAIN) {
-#pragma unroll
-                            for (int q = m * PK / NM; q < (m + 1) * PK / NM; ++q) {
-                                if (j == 0) res_load(UU * PK + q, q);
-                                if (j == NCH - 1) drain(UU * PK + q, q);
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-        }
-    };
-
-    auto group = [&](int kt0, auto drain_tag, bool last_group, bool next_valid) {
-        static_for<U>([&](auto is) {
-            constexpr int I = decltype(is)::value;
-            // (before k tile nk - 2 the staging offsets become the next tile's: from there on the loads fetch ITS k tiles 0, 1)
-            if (I == U - 2 && last_group) stage_setup(next_valid, nm0, nn0);
-            ktile(kt0 + I, drain_tag, is);
-        });
-    };
-    for (;;) {
-        // the tile after this one (its first k tiles are fetched by this tile's last two)
-        const int tn = next_tile(t + gridDim.x, nm0, nn0);
-        for (int kt0 = 0; kt0 < nk; kt0 += U) {
-            if (kt0 == 0) group(kt0, std::true_type{}, kt0 + U == nk, tn >= 0);
-            else group(kt0, std::false_type{}, kt0 + U == nk, tn >= 0);
-        }
-        // tile switch: the finished accumulators become the drain set (affine / column offsets of ITS channels are fetched now:
-        // first used a k tile from here)
-        out_setup(dn, true, m0, n0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) old[i][j] = acc[i][j];
-        if (tn < 0) break;
-        t = tn;
-        m0 = nm0;
-        n0 = nn0;
-    }
-    // ---- the workgroup's last tile: nothing left to hide it behind ---------------------------------------------------------
-    if constexpr (RES != 0) {
-        float rv[D];
-#pragma unroll
-        for (int q = 0; q < D; ++q) {
-            res_load(q, 0);
-            rv[q] = rres[0];
-        }
-#pragma unroll
-        for (int q = 0; q < D; ++q) {
-            rres[0] = rv[q];
-            drain(q, 0);
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < D; ++q) drain(q, 0);
-    }
-}
-
-template <int BM, int BN, int BK, int U>
-int launch_pw_pipe(ConvParams p, hipStream_t stream) {
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.Cout + BN - 1) / BN;
-    const long long total = tile_grid(p);
-    if (total > 0x7fffffffLL) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv_pw_pipe: grid too large");
-    constexpr size_t lds = conv_lds_bytes<BM, BN, BK>();
-    const int res = epilogue_variant(p, false);
-    const int cus = mrcnn::device_cu_count();
-    if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv_pw_pipe: no device");
-    const int wgs_per_cu = getenv("MRCNN_PIPE_WGS") ? std::max(1, atoi(getenv("MRCNN_PIPE_WGS"))) : 2;
-    long long grid = std::min<long long>(total, static_cast<long long>(wgs_per_cu) * (cus >= 8 ? (cus / 8) * 8 : 8));
-    grid = (grid + 7) / 8 * 8;   // a multiple of 8: workgroup b stays on XCD b % 8 for all its tiles
-    auto go = [&](auto kern) -> int {
-        if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "conv_pw_pipe")) return rc;
-        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(256), lds, stream, p);
-        return mrcnn::check_launch("conv_pw_pipe_f32");
-    };
-    return res == 0 ? go(conv_pw_pipe_f32<BM, BN, BK, 0, U>) : res == 1 ? go(conv_pw_pipe_f32<BM, BN, BK, 1, U>)
-                                                                         : go(conv_pw_pipe_f32<BM, BN, BK, 2, U>);
-}
-
 template <int KC, int TN, int TNP>
 int launch_pw_stream(ConvParams p, hipStream_t stream) {
     constexpr size_t lds = sizeof(float) * 32 * TN * (KC * 8 + 4);
@@ -868,30 +538,6 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
         if (cin == 256 && cout > 32 && cout <= 64) return launch_pw_stream<32, 2, 2>(p, s);
         if (cin == 64 && cout > 32 && cout <= 64) return launch_pw_stream<8, 2, 2>(p, s);
         if (cin == 64 && cout > 128 && cout <= 256) return launch_pw_stream<8, 8, 4>(p, s);
-    }
-    // the software-pipelined persistent kernel (round 4; bit-identical results): 1x1 layers with Cout >= 128, plain or with a
-    // same-size residual, whose 128 x 128 tiles give every CU at least two — the Bottleneck conv1 / conv3 / downsample layers of
-    // C2-C5 and the heads' GEMMs. The finished tile drains over U k tiles of the next one: U = 16 (K % 256 == 0), 8 (K = 128),
-    // 4 (K = 64). Measured per layer (tools/pw_pipe_probe.py, profiles/r04_pw_pipe_probe.jsonl): -6 ... -11 % against the tiled
-    // kernel's best tile; the FPN laterals (half-size residual, k-blocked both ways: variant 2) gain nothing and stay there.
-    // MRCNN_CONV_PIPE=0 switches it off; 2 ... 7 force a tile shape / drain spread for tuning.
-    {
-        const int pipe = getenv("MRCNN_CONV_PIPE") ? atoi(getenv("MRCNN_CONV_PIPE")) : -1;   // (read per call: a tuning switch)
-        const int resv = epilogue_variant(p, false);
-        if (pipe != 0 && pointwise && cout >= 128 && resv <= 2 && relu <= 1 && out_mode != 1 && p.K % 64 == 0) {
-            if (pipe == 2) return launch_pw_pipe<128, 64, 16, 4>(p, s);
-            if (pipe == 3) return launch_pw_pipe<128, 128, 16, 4>(p, s);
-            if (pipe == 4 && p.K % 128 == 0) return launch_pw_pipe<128, 64, 32, 4>(p, s);
-            if (pipe == 5 && p.K % 128 == 0) return launch_pw_pipe<128, 128, 16, 8>(p, s);
-            if (pipe == 6 && p.K % 128 == 0) return launch_pw_pipe<128, 64, 16, 8>(p, s);
-            if (pipe == 7 && p.K % 256 == 0) return launch_pw_pipe<128, 128, 16, 16>(p, s);
-            const long long t128 = ((p.M + 127) / 128) * static_cast<long long>((cout + 127) / 128);
-            if (pipe < 0 && resv <= 1 && t128 >= 2LL * mrcnn::device_cu_count()) {
-                if (p.K % 256 == 0) return launch_pw_pipe<128, 128, 16, 16>(p, s);
-                if (p.K % 128 == 0) return launch_pw_pipe<128, 128, 16, 8>(p, s);
-                return launch_pw_pipe<128, 128, 16, 4>(p, s);
-            }
-        }
     }
     if (cout <= 32) return launch_conv<128, 32, 4, 1, 32>(p, mode, s);
     // Cout <= 64: 256x64 tile. BK = 16 keeps its LDS at 51 KB (two workgroups per CU; BK = 32 needs 92 KB = one):
