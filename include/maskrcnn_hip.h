@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 13
+#define MRCNN_ABI_VERSION 14
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -134,6 +134,14 @@ int mrcnn_roi_align_pyramid_f32(const float* const fm[4], const int32_t fm_h[4],
                                 int32_t depth, const float* rois, const int32_t* roi_batch, int32_t num_rois,
                                 int32_t rois_per_image, int32_t pool, float image_area, void* out, int32_t out_layout,
                                 int32_t* levels_out, mrcnn_stream_t stream);
+/* The same for the fixed-shape pipeline, whose rois tensor holds rois_per_image SLOTS per image of which only the first
+ * roi_counts[image] carry a proposal (model.py:1366-1374: the reference's rois tensor simply ends after the boxes NMS kept):
+ * slots beyond the count are skipped — nothing is read, their output rows are left untouched. roi_counts int32 [num_rois /
+ * rois_per_image] device memory, or NULL (= mrcnn_roi_align_pyramid_f32); needs roi_batch == NULL. */
+int mrcnn_roi_align_pyramid_counted_f32(const float* const fm[4], const int32_t fm_h[4], const int32_t fm_w[4], int32_t batch,
+                                        int32_t depth, const float* rois, const int32_t* roi_batch, int32_t num_rois,
+                                        int32_t rois_per_image, const int32_t* roi_counts, int32_t pool, float image_area,
+                                        void* out, int32_t out_layout, int32_t* levels_out, mrcnn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused convolution + bias/BatchNorm affine + residual + ReLU, channels-last, fp32 MFMA implicit
@@ -363,6 +371,16 @@ int mrcnn_conv_bn_act_f32(const float* x, int32_t batch, int32_t height, int32_t
                           int32_t pad_bottom, int32_t pad_right, const float* scale, const float* shift,
                           const float* residual, int32_t res_div, int32_t residual_layout, int32_t activation,
                           float* y, int32_t y_layout, mrcnn_stream_t stream);
+/* mrcnn_conv_bn_act_nhwc_f32 for the heads' GEMMs over [image][RoI slot] rows (Classifier.forward, model.py:782-794, runs on
+ * the rois that survived NMS only — model.py:1366-1374): the output rows (batch * OH * OW of them) come in groups of
+ * rows_per_group slots of which the first row_counts[group] are valid; an M tile without a valid row is skipped — nothing
+ * is read, its output rows are left untouched. Rows are independent in a GEMM, so the valid rows' results are bit-identical to
+ * the unmasked call. row_counts int32 device memory, or NULL (= every row). */
+int mrcnn_conv_bn_act_rows_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin, const float* w,
+                               int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad_top, int32_t pad_left,
+                               int32_t pad_bottom, int32_t pad_right, const float* scale, const float* shift,
+                               int32_t activation, float* y, const int32_t* row_counts, int32_t rows_per_group,
+                               mrcnn_stream_t stream);
 int mrcnn_nhwc_to_kblocked_f32(const float* x, int64_t pixels, int32_t channels, float* y, mrcnn_stream_t stream);
 size_t mrcnn_conv3x3_winograd_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t cin);
 int mrcnn_conv3x3_winograd_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin,

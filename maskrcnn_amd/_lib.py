@@ -33,6 +33,11 @@ _SIGS = {
                                                           ctypes.POINTER(c_i32), c_i32, c_i32, c_vp,
                                                           c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp,
                                                           c_vp]),
+    "mrcnn_roi_align_pyramid_counted_f32": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
+                                                             c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_f32, c_vp,
+                                                             c_i32, c_vp, c_vp]),
+    "mrcnn_conv_bn_act_rows_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                                    c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
     "mrcnn_roi_align_pyramid_f32": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                                      c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32,
                                                      c_vp, c_vp]),

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
 
     int m0, n0, nt;
     if (!tile_origin(p, BM, BN, m0, n0, nt)) return;  // XCD-aware tile order
+    if (p.row_counts && !tile_has_rows(p, m0, BM)) return;   // an M tile of empty RoI slots (uniform: scalar loads)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -515,12 +516,19 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
                         const float* w, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad_top,
                         int32_t pad_left, int32_t pad_bottom, int32_t pad_right, const float* scale,
                         const float* shift, const float* residual, int32_t res_div, int32_t relu,
-                        int32_t out_mode, float* y, mrcnn_stream_t stream, int32_t res_kblocked = 0) {
+                        int32_t out_mode, float* y, mrcnn_stream_t stream, int32_t res_kblocked = 0,
+                        const int32_t* row_counts = nullptr, int32_t rows_per_group = 0) {
     MRCNN_REQUIRE(x && w && y, "conv: null pointer");
     ConvParams p;
     if (int rc = fill_common(p, "conv", x, batch, height, width, cin, 4, cout, kh, kw, stride, pad_top, pad_left,
                              pad_bottom, pad_right, scale, shift, residual, res_div, relu, out_mode, y, 4, res_kblocked))
         return rc;
+    if (row_counts) {
+        MRCNN_REQUIRE(rows_per_group >= 1 && p.M % rows_per_group == 0, "conv: %d output rows are not whole groups of %d",
+                      p.M, rows_per_group);
+        p.row_counts = row_counts;
+        p.rows_per_group = rows_per_group;
+    }
     p.w = w;
     p.w_head = nullptr;
     p.head_n = 0;
@@ -534,7 +542,7 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
     // ResNet C2's 1x1 layers without a residual (conv1 256 -> 64 / 64 -> 64, downsample 64 -> 256) on large maps: the streaming
     // kernel (bit-identical results; chosen by size only because a persistent wave needs several blocks to pipeline)
     static const bool no_stream = getenv("MRCNN_CONV_NO_STREAM") != nullptr;
-    if (pointwise && !no_stream && stride == 1 && !residual && relu <= 1 && out_mode != 1 && p.M >= 131072) {
+    if (pointwise && !no_stream && !row_counts && stride == 1 && !residual && relu <= 1 && out_mode != 1 && p.M >= 131072) {
         if (cin == 256 && cout > 32 && cout <= 64) return launch_pw_stream<32, 2, 2>(p, s);
         if (cin == 64 && cout > 32 && cout <= 64) return launch_pw_stream<8, 2, 2>(p, s);
         if (cin == 64 && cout > 128 && cout <= 256) return launch_pw_stream<8, 8, 4>(p, s);
@@ -586,6 +594,16 @@ extern "C" int mrcnn_conv_bn_act_f32(const float* x, int32_t batch, int32_t heig
                         pad_right, scale, shift, residual, res_div, activation,
                         y_layout == MRCNN_LAYOUT_KBLOCKED ? 2 : 0, y, stream,
                         residual_layout == MRCNN_LAYOUT_KBLOCKED ? 1 : 0);
+}
+
+extern "C" int mrcnn_conv_bn_act_rows_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin,
+                                          const float* w, int32_t cout, int32_t kh, int32_t kw, int32_t stride,
+                                          int32_t pad_top, int32_t pad_left, int32_t pad_bottom, int32_t pad_right,
+                                          const float* scale, const float* shift, int32_t activation, float* y,
+                                          const int32_t* row_counts, int32_t rows_per_group, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(row_counts == nullptr || rows_per_group >= 1, "conv_rows: rows_per_group=%d", rows_per_group);
+    return run_conv_f32(x, batch, height, width, cin, w, cout, kh, kw, stride, pad_top, pad_left, pad_bottom, pad_right, scale,
+                        shift, nullptr, 1, activation, 0, y, stream, 0, row_counts, rows_per_group);
 }
 
 extern "C" int mrcnn_deconv2x2_bias_act_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,

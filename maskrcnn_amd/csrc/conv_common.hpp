@@ -36,7 +36,23 @@ struct ConvCommon {
     int res_kblocked;  // the residual tensor is k-blocked [Cout/8][residual pixels][8] instead of NHWC
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes, y_bytes, r_bytes;  // buffer-descriptor ranges (< 4 GiB each)
+    // Optional row groups (the heads' GEMMs over [image][RoI slot] rows, model.py:1366-1374: an image's rois tensor has only the
+    // proposals that survived NMS — here every image has rows_per_group slots of which the first row_counts[image] hold one):
+    // an M tile none of whose rows holds a RoI is skipped (its output rows are left untouched). Device memory; NULL = all rows.
+    const int* row_counts;
+    int rows_per_group;
 };
+
+// Does the M tile [m0, m0 + BM) hold a valid row? Valid rows are a PREFIX of every group, so only the group of the tile's
+// first row (from that row on) and the group of its last row (from slot 0 on) can contribute; groups in between are whole.
+__device__ __forceinline__ bool tile_has_rows(const ConvCommon& p, int m0, int BM) {
+    const int last = min(m0 + BM, p.M) - 1;
+    const int g0 = m0 / p.rows_per_group, g1 = last / p.rows_per_group;
+    if (m0 - g0 * p.rows_per_group < p.row_counts[g0]) return true;
+    for (int g = g0 + 1; g <= g1; ++g)
+        if (p.row_counts[g] > 0) return true;
+    return false;
+}
 
 // Epilogue variants (template parameter RES of the kernels):
 //   0 plain, 1 residual of the output's size, 2 residual at half size (FPN nearest-upsample-add),
@@ -395,6 +411,7 @@ inline int fill_common(ConvCommon& p, const char* who, const float* x, int batch
     if (!(residual == nullptr || res_div == 1 || res_div == 2))
         return mrcnn::fail(MRCNN_ERR_INVALID_ARGUMENT, "%s: res_div must be 1 or 2", who);
     p.x = x; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.row_counts = nullptr; p.rows_per_group = 0;
     p.B = batch; p.H = height; p.W = width; p.Cin = cin; p.Cout = cout; p.KH = kh; p.KW = kw;
     p.stride = stride; p.pad_t = pad_top; p.pad_l = pad_left;
     p.OH = (height + pad_top + pad_bottom - kh) / stride + 1;

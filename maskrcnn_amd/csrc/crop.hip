@@ -505,11 +505,16 @@ __device__ __forceinline__ int roi_level(float y1, float x1, float y2, float x2,
 __global__ __launch_bounds__(256) void roi_align_pyramid_nhwc(
     PyramidArgs a, int batch, int depth, const float* __restrict__ rois,
     const int* __restrict__ roi_batch, int rois_per_image, int pool, float image_area,
-    float* __restrict__ out, int* __restrict__ levels_out, int out_kblocked, int64_t out_pixels) {
+    float* __restrict__ out, int* __restrict__ levels_out, int out_kblocked, int64_t out_pixels,
+    const int* __restrict__ roi_counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Sample* sy = reinterpret_cast<Sample*>(smem);
     Sample* sx = sy + pool;
     const int r = blockIdx.x;
+    if (roi_counts) {   // slot r of its image holds no RoI (model.py:1366-1374: the reference's rois tensor ends there): no output
+        const int img = r / rois_per_image;
+        if (r - img * rois_per_image >= roi_counts[img]) return;
+    }
     const float y1 = rois[r * 4 + 0], x1 = rois[r * 4 + 1];
     const float y2 = rois[r * 4 + 2], x2 = rois[r * 4 + 3];
     const int level = roi_level(y1, x1, y2, x2, image_area);
@@ -656,10 +661,13 @@ extern "C" int mrcnn_crop_backward_f32(const float* grads, const float* boxes,
     return mrcnn::check_launch("crop_backward_nchw");
 }
 
-extern "C" int mrcnn_roi_align_pyramid_f32(const float* const fm[4], const int32_t fm_h[4], const int32_t fm_w[4],
-                                           int32_t batch, int32_t depth, const float* rois, const int32_t* roi_batch,
-                                           int32_t num_rois, int32_t rois_per_image, int32_t pool, float image_area,
-                                           void* out, int32_t out_layout, int32_t* levels_out, mrcnn_stream_t stream) {
+extern "C" int mrcnn_roi_align_pyramid_counted_f32(const float* const fm[4], const int32_t fm_h[4], const int32_t fm_w[4],
+                                                   int32_t batch, int32_t depth, const float* rois, const int32_t* roi_batch,
+                                                   int32_t num_rois, int32_t rois_per_image, const int32_t* roi_counts,
+                                                   int32_t pool, float image_area, void* out, int32_t out_layout,
+                                                   int32_t* levels_out, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(roi_counts == nullptr || (roi_batch == nullptr && rois_per_image >= 1 && num_rois % rois_per_image == 0),
+                  "roi_align_pyramid: roi_counts needs rois_per_image (no roi_batch) and whole images of slots");
     MRCNN_REQUIRE(fm && fm_h && fm_w && rois && out, "roi_align_pyramid: null pointer");
     MRCNN_REQUIRE(batch >= 1 && depth >= 4 && depth % 4 == 0, "roi_align_pyramid: depth=%d must be a multiple of 4", depth);
     MRCNN_REQUIRE(pool >= 1 && pool <= 1024, "roi_align_pyramid: pool=%d", pool);
@@ -680,8 +688,16 @@ extern "C" int mrcnn_roi_align_pyramid_f32(const float* const fm[4], const int32
                        mrcnn::as_stream(stream), a, batch, depth, rois, roi_batch, rois_per_image,
                        pool, image_area, static_cast<float*>(out), levels_out,
                        out_layout == MRCNN_LAYOUT_KBLOCKED ? 1 : out_layout == MRCNN_LAYOUT_NHWC_F16 ? 2 : 0,
-                       static_cast<int64_t>(num_rois) * pool * pool);
+                       static_cast<int64_t>(num_rois) * pool * pool, roi_counts);
     return mrcnn::check_launch("roi_align_pyramid_nhwc");
+}
+
+extern "C" int mrcnn_roi_align_pyramid_f32(const float* const fm[4], const int32_t fm_h[4], const int32_t fm_w[4],
+                                           int32_t batch, int32_t depth, const float* rois, const int32_t* roi_batch,
+                                           int32_t num_rois, int32_t rois_per_image, int32_t pool, float image_area,
+                                           void* out, int32_t out_layout, int32_t* levels_out, mrcnn_stream_t stream) {
+    return mrcnn_roi_align_pyramid_counted_f32(fm, fm_h, fm_w, batch, depth, rois, roi_batch, num_rois, rois_per_image, nullptr,
+                                               pool, image_area, out, out_layout, levels_out, stream);
 }
 
 extern "C" int mrcnn_roi_align_pyramid_nhwc_f32(const float* const fm[4], const int32_t fm_h[4],

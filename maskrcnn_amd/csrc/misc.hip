@@ -420,6 +420,17 @@ __global__ __launch_bounds__(256) void detection_decode(
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);  // RoI index in [0, B*P)
     if (r >= B * P) return;
     const int b = r / P, slot = r - b * P;
+    if (slot >= roi_counts[b]) {
+        // no RoI in this slot (the reference's tensors simply end before it, model.py:1366-1374). Its logits / bbox rows may
+        // never have been written (the head skips row tiles of empty slots): nothing of them is read; a fixed, excluded record
+        if (lane == 0) {
+            float* o = dets + static_cast<int64_t>(r) * 5;
+            o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = 0.f;
+            class_ids[r] = 0;
+            nms_cls[r] = -(slot + 1);
+        }
+        return;
+    }
     const float* lg = logits + static_cast<int64_t>(r) * logit_stride;
     // max and first argmax over classes
     float best = -INFINITY;

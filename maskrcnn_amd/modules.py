@@ -208,6 +208,10 @@ def winograd4_tiles_per_image(h: int, w: int) -> int:
 # at the RoIAlign inputs (the smoothed pyramid) and at the head outputs. A conv reading an fp16 tensor sees exactly the
 # operand it would have rounded an fp32 tensor to; residual adds, the stem max-pool and the stores see fp16.
 # MRCNN_F16_ACT=0 keeps every activation fp32 (round 1's form of the mode).
+# The classifier head (RoIAlign 7x7 + three GEMMs) skips the RoI slots beyond each image's proposal count — the reference's rois
+# tensor holds only the boxes NMS kept (model.py:1366-1374), this pipeline's has proposal_count slots per image with a count.
+# MRCNN_SKIP_EMPTY_ROI_TILES=0 computes every slot (same valid rows bit for bit; A/B measurements).
+SKIP_EMPTY_ROI_TILES = os.environ.get("MRCNN_SKIP_EMPTY_ROI_TILES", "1") != "0"
 F16_ACT = os.environ.get("MRCNN_F16_ACT", "1") != "0"
 # The large stride-1 layers of the "f16" mode (fp16 NHWC input, Cin % 64 == 0, Cout % 256 == 0) run the pipelined kernel
 # (csrc/conv_f16p.hip: eight waves, LDS-DMA in flight across barriers — 1.4-1.5x the 128x128-tile kernel on the 3x3 layers);
@@ -279,7 +283,7 @@ class ConvWeight:
                                                                      stride)
 
     def conv(self, x, scale, shift, stride=1, pad=(0, 0, 0, 0), relu=False, residual=None, res_div=1,
-             algo_cin=None, out="nhwc", out_f16=False):
+             algo_cin=None, out="nhwc", out_f16=False, row_counts=None, rows_per_group=0):
         """out: "nhwc" (default), or for the f32 mode "kblocked" / "both" (ops.conv3x3_winograd): the layout the next
         Winograd conv reads. x may itself be k-blocked (5-d) when this conv takes the Winograd kernel. "f16" mode only:
         out="f16+f32" returns the pair (fp16 copy, fp32 copy) of the same result."""
@@ -290,8 +294,11 @@ class ConvWeight:
             if self.takes_winograd(hh, ww, stride, pad, residual, relu):
                 return ops.conv3x3_winograd(x, self.u, scale, shift, bool(relu), algo_cin, out)
             assert x.dim() == 4 and out in ("nhwc", "kblocked")
+            # (row groups — the heads' GEMMs skipping tiles of empty RoI slots — exist in the f32 kernel; the fp16 modes
+            # compute every row)
             return ops.conv_bn_act(x, self.w, scale, shift, stride, pad, relu, residual, res_div, None,
-                                   algo_cin, out_kblocked=(out == "kblocked"))
+                                   algo_cin, out_kblocked=(out == "kblocked"), row_counts=row_counts,
+                                   rows_per_group=rows_per_group)
         if self.takes_pipelined(x, stride, pad, relu, residual, res_div, out_f16, out):
             return ops.conv_f16_pipelined(x, self.w_hi, scale, shift, pad, bool(relu), residual,
                                           out_f16=bool(out_f16) or out == "f16+f32", out_f32=(not out_f16) or out == "f16+f32",
@@ -324,10 +331,10 @@ class FusedConv:
     def takes_winograd(self, h, w):
         return self.w.takes_winograd(h, w, self.stride, self.pad_for(h, w), None, self.relu)
 
-    def __call__(self, x, residual=None, res_div=1, out="nhwc"):
+    def __call__(self, x, residual=None, res_div=1, out="nhwc", row_counts=None, rows_per_group=0):
         hh, ww = (x.size(2), x.size(3)) if x.dim() == 5 else (x.size(1), x.size(2))
         return self.w.conv(x, self.scale, self.shift, self.stride, self.pad_for(hh, ww), self.relu, residual, res_div,
-                           self.algo_cin, out, self.out_f16)
+                           self.algo_cin, out, self.out_f16, row_counts, rows_per_group)
 
 
 class FusedBottleneck:
@@ -596,11 +603,15 @@ class FusedClassifier:
         """"f16" mode: RoIAlign may hand over fp16 crops (the rounding conv1 would apply to fp32 ones while staging them)."""
         return self.w1.precision == "f16" and F16_ACT and F16_PIPELINED
 
-    def __call__(self, pooled):
+    def __call__(self, pooled, roi_counts=None, rois_per_image=0):
+        """roi_counts int32 [images] + rois_per_image: only the first roi_counts[i] of image i's slots hold a RoI (the reference
+        runs the head on exactly those, model.py:1366-1374,1174); row tiles without one are skipped by the three GEMMs, and the
+        rows of empty slots hold unspecified values (the detection stage never reads them: validity is slot < roi_counts)."""
         r = pooled.size(0)
-        x = self.w1.conv(pooled.view(r, 1, 1, -1), self.s1, self.t1, relu=True, out_f16=self.conv2.out_f16)
-        x = self.conv2(x)
-        y = self.w_fc.conv(x, None, self.b_fc).view(r, -1)
+        rc = dict(row_counts=roi_counts, rows_per_group=rois_per_image) if (roi_counts is not None and SKIP_EMPTY_ROI_TILES) else {}
+        x = self.w1.conv(pooled.view(r, 1, 1, -1), self.s1, self.t1, relu=True, out_f16=self.conv2.out_f16, **rc)
+        x = self.conv2(x, **rc)
+        y = self.w_fc.conv(x, None, self.b_fc, **rc).view(r, -1)
         logits = y[:, :self.num_classes]
         bbox = y[:, self.num_classes:].reshape(r, self.num_classes, 4)
         return logits, bbox

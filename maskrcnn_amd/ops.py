@@ -223,7 +223,8 @@ _LIB.impl("crop", lambda image, *a: _need_gpu(image), "CPU")
 @_on_device
 def roi_align_pyramid(feature_maps, rois: torch.Tensor, pool: int, image_area: float,
                       rois_per_image: int | None = None, roi_batch: torch.Tensor | None = None,
-                      return_levels: bool = False, out_kblocked: bool = False, out_f16: bool = False):
+                      return_levels: bool = False, out_kblocked: bool = False, out_f16: bool = False,
+                      roi_counts: torch.Tensor | None = None):
     """model.py:276-393 in one launch on channels-last maps.
 
     feature_maps: [P2,P3,P4,P5], each a contiguous fp32 [B, H_l, W_l, C] (NHWC) tensor.
@@ -250,9 +251,13 @@ def roi_align_pyramid(feature_maps, rois: torch.Tensor, pool: int, image_area: f
     ws = (c_i32 * 4)(*[fm.size(2) for fm in feature_maps])
     if roi_batch is not None:
         assert roi_batch.dtype == torch.int32 and roi_batch.is_contiguous()
-    check(lib.mrcnn_roi_align_pyramid_f32(ptrs, hs, ws, b, c, rois.data_ptr(), _ptr(roi_batch), r,
-                                          int(rois_per_image or 0), int(pool), float(image_area), out.data_ptr(),
-                                          1 if out_kblocked else 2 if out_f16 else 0, _ptr(levels), _stream()))
+    if roi_counts is not None:   # only the first roi_counts[image] slots of an image hold a RoI: the others are skipped
+        assert roi_counts.dtype == torch.int32 and roi_counts.is_contiguous() and roi_batch is None and rois_per_image
+        assert roi_counts.numel() * rois_per_image == r
+    check(lib.mrcnn_roi_align_pyramid_counted_f32(ptrs, hs, ws, b, c, rois.data_ptr(), _ptr(roi_batch), r,
+                                                  int(rois_per_image or 0), _ptr(roi_counts), int(pool), float(image_area),
+                                                  out.data_ptr(), 1 if out_kblocked else 2 if out_f16 else 0, _ptr(levels),
+                                                  _stream()))
     return (out, levels) if return_levels else out
 
 
@@ -273,8 +278,12 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
                 shift: torch.Tensor | None, stride: int = 1, pad=(0, 0, 0, 0), relu: bool = False,
                 residual: torch.Tensor | None = None, res_div: int = 1,
                 out: torch.Tensor | None = None, algo_cin: int | None = None,
-                out_kblocked: bool = False) -> torch.Tensor:
+                out_kblocked: bool = False, row_counts: torch.Tensor | None = None,
+                rows_per_group: int = 0) -> torch.Tensor:
     """y = act(scale * conv(x, w) + shift + residual).
+
+    row_counts / rows_per_group: the output rows come in groups of rows_per_group RoI slots of which the first row_counts[g]
+    are valid (int32 device tensor); 128-row tiles without a valid row are skipped and their output rows left untouched.
 
     out_kblocked: write y as [Cout/8,B,OH,OW,8] (what conv3x3_winograd reads) instead of NHWC.
 
@@ -311,10 +320,17 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.mrcnn_conv_bn_act_f32(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout, kh, kw,
-                                    int(stride), pt, pl, pb, pr, _ptr(scale), _ptr(shift),
-                                    _ptr(residual), int(res_div), 1 if res_kblocked else 0, int(relu),
-                                    out.data_ptr(), 1 if out_kblocked else 0, _stream()))
+    if row_counts is not None:
+        assert residual is None and not out_kblocked and row_counts.dtype == torch.int32 and row_counts.is_contiguous()
+        assert rows_per_group >= 1 and row_counts.numel() * rows_per_group == b * oh * ow
+        check(lib.mrcnn_conv_bn_act_rows_f32(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout, kh, kw, int(stride), pt, pl, pb,
+                                             pr, _ptr(scale), _ptr(shift), int(relu), out.data_ptr(), row_counts.data_ptr(),
+                                             int(rows_per_group), _stream()))
+    else:
+        check(lib.mrcnn_conv_bn_act_f32(x.data_ptr(), b, h, wd, cin, w.data_ptr(), cout, kh, kw,
+                                        int(stride), pt, pl, pb, pr, _ptr(scale), _ptr(shift),
+                                        _ptr(residual), int(res_div), 1 if res_kblocked else 0, int(relu),
+                                        out.data_ptr(), 1 if out_kblocked else 0, _stream()))
     if prof is not None:
         e1.record()
         m, k = b * oh * ow, kh * kw * (algo_cin or cin)  # algorithmic: 2*MACs of the un-padded conv

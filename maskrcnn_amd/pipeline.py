@@ -135,9 +135,12 @@ class MaskRCNNInference:
         rois, roi_counts, rpn_dets = self.proposals(scores, deltas)
         p = rois.size(1)
         flat = rois.reshape(-1, 4).contiguous()
+        # slots beyond an image's proposal count hold no RoI: RoIAlign and the head's GEMMs skip them (the reference's rois
+        # tensor has only the surviving rows, model.py:1366-1374); their logits / bbox rows are never read (detections())
+        skip = roi_counts if modules.SKIP_EMPTY_ROI_TILES else None
         pooled = ops.roi_align_pyramid(fms[:4], flat, c.pool_size, self.image_area, rois_per_image=p,
-                                       out_f16=self.classifier.wants_f16())
-        logits, bbox = self.classifier(pooled)
+                                       out_f16=self.classifier.wants_f16(), roi_counts=skip)
+        logits, bbox = self.classifier(pooled, skip, p)
         ids, det_scores, boxes, mrois, counts = self.detections(rois, roi_counts, logits, bbox,
                                                                 windows.to(self.device))
         masks = None
@@ -152,6 +155,10 @@ class MaskRCNNInference:
             masks = m.view(b, d, m.size(1), m.size(2), m.size(3))
         det = Detections(ids, det_scores, boxes, counts, masks)
         if return_intermediates:
+            if skip is not None:   # the head rows of empty RoI slots were never computed: report them as zeros
+                live = (torch.arange(p, device=self.device)[None, :] < roi_counts[:, None]).reshape(-1)
+                logits = torch.where(live[:, None], logits, torch.zeros((), device=self.device))
+                bbox = torch.where(live[:, None, None], bbox, torch.zeros((), device=self.device))
             return det, dict(feature_maps=fms, rpn_scores=scores, rpn_deltas=deltas, rois=rois,
                              roi_counts=roi_counts, rpn_dets=rpn_dets, logits=logits, bbox=bbox)
         return det

@@ -267,3 +267,45 @@ def test_full_size_trunk_and_roialign_one_image(oracle):
     ok = (rois[:, 2] > rois[:, 0]) & (rois[:, 3] > rois[:, 1])
     want_p = oracle.roi_align(rois[ok], maps_cpu, 7, (1024, 1024, 3))
     assert torch.equal(got.permute(0, 3, 1, 2).cpu()[ok], want_p)
+
+
+def test_head_skips_empty_roi_slots_without_changing_a_valid_row(monkeypatch):
+    """Round 4: RoIAlign 7x7 and the classifier's three GEMMs skip the RoI slots beyond each image's proposal count (the
+    reference's rois tensor holds only the boxes NMS kept, model.py:1366-1374; this pipeline has proposal_count slots + a count).
+    Rows are independent in those kernels: every valid row, the detections and the masks are bit-identical with the skip on and
+    off — also when the skipped rows' memory held NaNs before (nothing of an empty slot is ever read)."""
+    from maskrcnn_amd import modules, ops
+    from maskrcnn_amd.config import InferenceConfig
+    from maskrcnn_amd.pipeline import MaskRCNNInference
+    dev = torch.device("cuda:0")
+    cfg = InferenceConfig(image_height=256, image_width=256, backbone="resnet50", pre_nms_limit=600, proposal_count=600,
+                          detection_max_instances=20)
+    sd = modules.synthetic_state_dict("resnet50", seed=0, bn_seed=1)
+    g = torch.Generator().manual_seed(11)
+    sd["rpn.conv_class.weight"] = sd["rpn.conv_class.weight"] * 0.05
+    sd["rpn.conv_bbox.weight"] = sd["rpn.conv_bbox.weight"] * 0.05
+    sd["classifier.linear_class.weight"] = torch.randn(81, 1024, generator=g) * 0.05
+    sd["classifier.linear_bbox.weight"] = torch.randn(324, 1024, generator=g) * 0.02
+    images = (torch.randint(0, 256, (3, 256, 256, 3), generator=g).float() - torch.tensor(cfg.mean_pixel))
+    images = images.permute(0, 3, 1, 2).contiguous().to(dev)
+    windows = torch.tensor([[0., 0., 256., 256.]] * 3, device=dev)
+    outs = {}
+    for on in (True, False):
+        monkeypatch.setattr(modules, "SKIP_EMPTY_ROI_TILES", on)
+        net = MaskRCNNInference(sd, cfg, dev)
+        if on:   # poison the allocator's free blocks: what the skipped rows will be "left untouched" as
+            junk = [torch.full((600 * 3, 1024), float("nan"), device=dev) for _ in range(4)]
+            del junk
+        outs[on] = net.predict(images, windows, return_intermediates=True)
+        torch.cuda.synchronize()
+    (d1, m1), (d0, m0) = outs[True], outs[False]
+    counts = m1["roi_counts"].tolist()
+    assert counts == m0["roi_counts"].tolist() and min(counts) < 600 - 128, counts   # at least one whole tile of empty slots
+    p = m1["rois"].size(1)
+    for b, n in enumerate(counts):
+        assert torch.equal(m1["logits"][b * p:b * p + n], m0["logits"][b * p:b * p + n])
+        assert torch.equal(m1["bbox"][b * p:b * p + n], m0["bbox"][b * p:b * p + n])
+        assert bool((m1["logits"][b * p + n:(b + 1) * p] == 0).all())
+    assert torch.equal(d1.class_ids, d0.class_ids) and torch.equal(d1.boxes, d0.boxes) and torch.equal(d1.scores, d0.scores)
+    assert torch.equal(d1.counts, d0.counts) and torch.equal(d1.masks, d0.masks)
+    assert int(d1.counts.sum()) > 0 and not bool(torch.isnan(d1.masks).any())
