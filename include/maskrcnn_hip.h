@@ -405,6 +405,13 @@ int mrcnn_stem_conv7x7_s2_nchw_f32(const float* x_nchw, int32_t batch, int32_t h
 int mrcnn_stem_conv7x7_s2_nchw_f16out(const float* x_nchw, int32_t batch, int32_t height, int32_t width, const float* w,
                                       const float* scale, const float* shift, int32_t activation, void* y_f16,
                                       mrcnn_stream_t stream);
+/* The "f16" mode's stem in ONE launch on the fp16 MFMA: conv 7x7 s2 p3 + affine + ReLU + SamePad2d(3, 2) + MaxPool2d(3, 2)
+ * (model.py:223-229) — x_nchw fp32 [batch][3][H][W] (H, W multiples of 4), w fp32 OHWI [64][7][7][4] (channel 3 zero; rounded to fp16
+ * inside), y_f16 fp16 NHWC [batch][ceil(H/4)][ceil(W/4)][64]. Image and weights are rounded to fp16 once, products accumulate
+ * in fp32, the conv output is rounded to fp16 once before the max (as the two-launch form stores it). The full-resolution
+ * 64-channel map never reaches memory. ReLU is part of the contract (the pool's zero padding is neutral only for values >= 0). */
+int mrcnn_stem_conv7x7_s2_pool_f16(const float* x_nchw, int32_t batch, int32_t height, int32_t width, const float* w,
+                                   const float* scale, const float* shift, void* y_f16, mrcnn_stream_t stream);
 
 /* ---- selection steps of the two refine stages (no library sort / top-k / gather in the step) --------------------
  * Total, deterministic order everywhere: descending score, ties by ascending index (ATen's sort, which the

@@ -552,6 +552,11 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
     // measured 3-20 % faster on the C2 layers. The stem (generic K) keeps BK = 32.
     if (cout <= 64) return (generic || force == 4) ? launch_conv<256, 64, 4, 1, 32>(p, mode, s)
                                                    : launch_conv<256, 64, 4, 1, 16>(p, mode, s);
+    // 64 < Cout <= 96 (the mask head's conv5, 256 -> 81 + sigmoid on 313 600 pixels, model.py:913-914): a 128x96 tile — four
+    // waves of 32 rows x 96 columns — instead of a 128-column tile of which 37 % would be padding (MFMA-bound at the padded
+    // width: 0.189 ms). MRCNN_CONV_N96=0 keeps the 128x128 tile (same products in the same order: bit-identical).
+    static const bool n96 = !(getenv("MRCNN_CONV_N96") && getenv("MRCNN_CONV_N96")[0] == '0');
+    if (!generic && n96 && force == 0 && cout > 64 && cout <= 96) return launch_conv<128, 96, 4, 1, 32>(p, mode, s);
     // (a 256x128 BK16 tile — 25% fewer LDS/global bytes per MFMA — was measured in round 1: no gain over 128x128 even on
     // the largest layers, 133.5 vs 133.2 TFLOP/s, and a loss on mid-size ones; removed)
     // 128x128 with BK = 16 (41 KB of LDS: three workgroups per CU) for the shortest K (<= 128) with wide outputs — C3 conv3

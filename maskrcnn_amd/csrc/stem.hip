@@ -188,6 +188,207 @@ __global__ __launch_bounds__(256, 2) void stem7x7_s2_f32(const StemParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The "f16" mode's stem (BASELINE configs[4], "fp16 MFMA path"): conv 7x7 s2 + BN + ReLU + SamePad(3,2) + MaxPool 3x3 s2
+// (model.py:223-229) in ONE kernel on the fp16 MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate) — round 4. The exact-fp32 stem
+// above plus the separate max-pool cost 0.33 + 0.09 ms of that mode's ~10 ms step, nearly all of it fp32-MFMA time for a
+// layer whose fp16-MFMA time is ~16x smaller; with fp16 operands the layer is bound by its bytes: the fp32 NCHW image in
+// (read once) and the POOLED fp16 map out — the 64-channel full-resolution map (the largest tensor of the step) never exists.
+//   tile      a persistent workgroup of eight waves owns 8 x 16 POOLED pixels = 17 x 33 conv outputs (one row / column of
+//             overlap with the next tile: 1.10x the MFMA work, which does not matter here) x all 64 channels
+//   K         per filter row ky: (kx, c) with kx padded 7 -> 8 and c padded 3 -> 4: 32 halves = two MFMA k steps. A conv
+//             pixel's A fragment for (ky, step, lane half h) is the 16 contiguous bytes of patch pixels 2 ox + 4 step + 2 h, + 1
+//             (8 bytes per pixel) — one ds_read_b128, conflict-free for 32 consecutive ox
+//   patch     39 x 72 pixels x 4 halves staged from the NCHW fp32 image (4-byte loads, consecutive lanes = consecutive x),
+//             rounded to fp16 once; the weights ([ky][n][32 halves], 16-byte chunks XOR-swizzled by (n >> 2) & 3) are converted
+//             once per workgroup
+//   epilogue  affine + ReLU in fp32, one rounding to fp16 into an LDS image [conv pixel][64] with zeros where the conv pixel
+//             lies outside the conv map (the pool's zero padding; ReLU'd values are >= 0); then every thread takes a channel
+//             pair of eight pooled pixels: nine 4-byte LDS reads and v_pk_max_f16 each, 128-byte output rows
+// Requires the ReLU (zero padding is only neutral for non-negative values) and H, W multiples of 4 (even conv sizes: SamePad2d
+// (3, 2) then pads bottom / right only).
+typedef _Float16 sp_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sp_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 sp_f16x4 __attribute__((ext_vector_type(4)));
+
+struct StemPoolParams {
+    const float* x;      // [B][3][H][W]
+    const float* w;      // [64][7][7][4] fp32 OHWI (channel 3 zero)
+    const float* scale;
+    const float* shift;
+    _Float16* y;         // [B][POH][POW][64]
+    int B, H, W, OH, OW, POH, POW, tiles_x, tiles_y, tiles;
+    unsigned x_bytes, y_bytes;
+};
+
+constexpr int SP_PH = 8, SP_PW = 16;                       // pooled pixels per tile
+constexpr int SP_CH = 2 * SP_PH + 1, SP_CW = 2 * SP_PW + 1;  // conv outputs per tile: 17 x 33
+constexpr int SP_NPX = SP_CH * SP_CW;                      // 561
+constexpr int SP_NRT = (SP_NPX + 31) / 32;                 // 18 MFMA row tiles
+constexpr int SP_IH = (SP_CH - 1) * 2 + 7;                 // 39 patch rows
+constexpr int SP_IW = 72;                                  // patch columns: (33 - 1) * 2 + 7 = 71, + the zero-weight tap kx = 7
+constexpr int SP_W_HALVES = 7 * 64 * 32;
+constexpr int SP_P_HALVES = SP_IH * SP_IW * 4;
+constexpr int SP_C_HALVES = SP_NRT * 32 * 64;
+constexpr size_t STEM_POOL_LDS = sizeof(_Float16) * (SP_W_HALVES + SP_P_HALVES + SP_C_HALVES);
+static_assert(STEM_POOL_LDS <= 160 * 1024, "LDS");
+
+__global__ __launch_bounds__(512, 1) void stem7x7_s2_pool_f16(const StemPoolParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16* Wl = reinterpret_cast<_Float16*>(smem_raw);    // [7][64][32] (chunk-swizzled)
+    _Float16* Pl = Wl + SP_W_HALVES;                          // [39][72][4]
+    _Float16* Cl = Pl + SP_P_HALVES;                          // [576][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ln = lane & 31, lh = lane >> 5;
+
+    // the filter, once per workgroup: fp32 [n][ky][kx][4] -> fp16 [ky][n][kx 0..7][4], kx = 7 zero
+    for (int i = tid; i < 7 * 64 * 8; i += 512) {
+        const int kx = i & 7, n = (i >> 3) & 63, ky = i >> 9;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kx < 7) v = reinterpret_cast<const float4*>(p.w)[(n * 7 + ky) * 7 + kx];
+        const int chunk = (kx >> 1) ^ ((n >> 2) & 3);   // 16-byte chunk = two taps
+        sp_f16x4 h4 = {static_cast<_Float16>(v.x), static_cast<_Float16>(v.y), static_cast<_Float16>(v.z), static_cast<_Float16>(v.w)};
+        *reinterpret_cast<sp_f16x4*>(Wl + (ky * 64 + n) * 32 + chunk * 8 + (kx & 1) * 4) = h4;
+    }
+    // channel 3 of every patch pixel and the last patch column (only ever multiplied by zero weights) stay zero
+    for (int i = tid; i < SP_IH * SP_IW; i += 512) *reinterpret_cast<sp_f16x4*>(Pl + i * 4) = sp_f16x4{0, 0, 0, 0};
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    float sc[2], sh[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        sc[ct] = p.scale ? p.scale[ct * 32 + ln] : 1.0f;
+        sh[ct] = p.shift ? p.shift[ct * 32 + ln] : 0.0f;
+    }
+    // this wave's row tiles: wave, wave + 8, wave + 16 (the last only for waves 0, 1). A-fragment base (halves) of conv pixel
+    // q = 32 rt + ln: patch pixel (2 oy, 2 ox + 2 lh); pixels beyond the 561 of the tile read pixel 560's (discarded)
+    constexpr int NRW = 3;
+    int a_base[NRW];
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+        const int q = min((wave + 8 * i) * 32 + ln, SP_NPX - 1);
+        const int oy = q / SP_CW, ox = q - oy * SP_CW;
+        a_base[i] = ((2 * oy) * SP_IW + 2 * ox + 2 * lh) * 4;
+    }
+    const bool third = wave + 16 < SP_NRT;   // wave-uniform
+    // B fragment of channel ct * 32 + ln, k step s: chunk 2 s + lh, swizzled by the channel
+    int b_off[2][2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int n = ct * 32 + ln;
+            b_off[ct][s2] = n * 32 + ((2 * s2 + lh) ^ ((n >> 2) & 3)) * 8;
+        }
+
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        const int b = tile / (p.tiles_y * p.tiles_x), rem = tile - b * p.tiles_y * p.tiles_x;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int cy0 = ty * 2 * SP_PH, cx0 = tx * 2 * SP_PW;   // first conv output of the tile
+        const int iy0 = cy0 * 2 - 3, ix0 = cx0 * 2 - 3;
+        __syncthreads();  // the previous tile's patch and conv image are no longer read (first trip: the filter / zero stores)
+        // an opaque copy of the thread id per tile: the staging / epilogue / pool index arithmetic below is invariant across
+        // tiles, and computed once ahead of this loop it costs ~100 registers that the allocator then spills
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const int ln_ = t_ & 31, lh_ = (t_ >> 5) & 1, wave_ = t_ >> 6;
+        {
+            constexpr int NE = 3 * SP_IH * (SP_IW - 1);          // 39 x 71 pixels x 3 planes
+            constexpr int NL = (NE + 511) / 512;                 // 17 loads per thread, all issued before the first LDS store
+            unsigned v[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int i = t_ + 512 * j;
+                const int c = i / (SP_IH * (SP_IW - 1)), r = i - c * (SP_IH * (SP_IW - 1));
+                const int py = r / (SP_IW - 1), px = r - py * (SP_IW - 1);
+                const int iy = iy0 + py, ix = ix0 + px;
+                const bool ok = i < NE && static_cast<unsigned>(iy) < static_cast<unsigned>(p.H) &&
+                                static_cast<unsigned>(ix) < static_cast<unsigned>(p.W);
+                const unsigned off = ok ? static_cast<unsigned>(((b * 3 + c) * p.H + iy) * p.W + ix) * 4u : OOB;
+                v[j] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, static_cast<int>(off), 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int i = t_ + 512 * j;
+                const int c = i / (SP_IH * (SP_IW - 1)), r = i - c * (SP_IH * (SP_IW - 1));
+                const int py = r / (SP_IW - 1), px = r - py * (SP_IW - 1);
+                if (i < NE) Pl[(py * SP_IW + px) * 4 + c] = static_cast<_Float16>(__uint_as_float(v[j]));
+            }
+        }
+        __syncthreads();
+
+        f32x16 acc[NRW][2];
+#pragma unroll
+        for (int i = 0; i < NRW; ++i)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][ct][r] = 0.f;
+        // (one filter row per trip: fully unrolled, the compiler hoists all 70 fragment reads — 280 registers — to the top)
+#pragma unroll 1
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                sp_f16x8 bf[2], af[NRW];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) bf[ct] = *reinterpret_cast<const sp_f16x8*>(Wl + ky * 64 * 32 + b_off[ct][s2]);
+#pragma unroll
+                for (int i = 0; i < NRW; ++i)
+                    if (i < 2 || third) af[i] = *reinterpret_cast<const sp_f16x8*>(Pl + a_base[i] + (ky * SP_IW + 4 * s2) * 4);
+#pragma unroll
+                for (int i = 0; i < NRW; ++i)
+                    if (i < 2 || third) {
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+                            acc[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[ct], acc[i][ct], 0, 0, 0);
+                    }
+            }
+        // conv image: affine + ReLU, zero outside the conv map, one rounding to fp16
+#pragma unroll
+        for (int i = 0; i < NRW; ++i)
+            if (i < 2 || third) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = (wave_ + 8 * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh_;
+                    const int oy = (q * 1986) >> 16, ox = q - oy * SP_CW;   // q / 33 for q < 576
+                    const bool in = q < SP_NPX && cy0 + oy < p.OH && cx0 + ox < p.OW;
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        float v = acc[i][ct][r] * sc[ct] + sh[ct];
+                        v = v > 0.f ? v : 0.f;
+                        v = in ? v : 0.f;
+                        asm volatile("" : "+v"(v));   // fp32 first, then ONE rounding to fp16 (no fused mixed-precision fma)
+                        Cl[q * 64 + ct * 32 + ln_] = static_cast<_Float16>(v);
+                    }
+                }
+            }
+        __syncthreads();
+        // pool: thread = (channel pair, 8 pooled pixels)
+        {
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+            const int cp = t2 & 31, g = t2 >> 5;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pp = g * 8 + j, py = pp >> 4, px = pp & 15;
+                sp_f16x2 m = {0, 0};   // the values are >= 0
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const sp_f16x2 v = *reinterpret_cast<const sp_f16x2*>(Cl + ((2 * py + dy) * SP_CW + 2 * px + dx) * 64 + 2 * cp);
+                        m = __builtin_elementwise_max(m, v);
+                    }
+                const int gy = ty * SP_PH + py, gx = tx * SP_PW + px;
+                const bool ok = gy < p.POH && gx < p.POW;
+                const unsigned off = ok ? static_cast<unsigned>(((b * p.POH + gy) * p.POW + gx) * 64 + 2 * cp) * 2u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), y_rsrc, static_cast<int>(off), 0, 0);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -238,4 +439,28 @@ extern "C" int mrcnn_stem_conv7x7_s2_nchw_f16out(const float* x_nchw, int32_t ba
                                                  const float* w, const float* scale, const float* shift,
                                                  int32_t activation, void* y_f16, mrcnn_stream_t stream) {
     return run_stem(true, x_nchw, batch, height, width, w, scale, shift, activation, static_cast<float*>(y_f16), stream, true);
+}
+
+extern "C" int mrcnn_stem_conv7x7_s2_pool_f16(const float* x_nchw, int32_t batch, int32_t height, int32_t width, const float* w,
+                                              const float* scale, const float* shift, void* y_f16, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x_nchw && w && y_f16, "stem_pool: null pointer");
+    // (an odd conv size would give SamePad2d(3, 2) a top / left component — model.py:64-87 — and shift the pooling windows)
+    MRCNN_REQUIRE(batch >= 1 && height >= 4 && width >= 4 && height % 4 == 0 && width % 4 == 0,
+                  "stem_pool: B=%d H=%d W=%d (multiples of 4 required)", batch, height, width);
+    MRCNN_REQUIRE(1LL * batch * height * width * 3 < (1LL << 30), "stem_pool: tensor too large (32-bit buffer byte offsets)");
+    StemPoolParams p;
+    p.x = x_nchw; p.w = w; p.scale = scale; p.shift = shift; p.y = static_cast<_Float16*>(y_f16);
+    p.B = batch; p.H = height; p.W = width; p.OH = height / 2; p.OW = width / 2;
+    p.POH = (p.OH + 1) / 2; p.POW = (p.OW + 1) / 2;   // SamePad2d(3, 2) + MaxPool2d(3, 2): ceil(n / 2) (model.py:64-87,227-228)
+    p.tiles_x = (p.POW + SP_PW - 1) / SP_PW;
+    p.tiles_y = (p.POH + SP_PH - 1) / SP_PH;
+    p.tiles = batch * p.tiles_x * p.tiles_y;
+    p.x_bytes = static_cast<unsigned>(12LL * batch * height * width);
+    p.y_bytes = static_cast<unsigned>(128LL * batch * p.POH * p.POW);
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(stem7x7_s2_pool_f16), STEM_POOL_LDS, "stem_pool")) return rc;
+    const int num_cu = mrcnn::device_cu_count();
+    if (num_cu <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "stem_pool: cannot query the device");
+    const int grid = p.tiles < num_cu ? p.tiles : num_cu;   // persistent: one eight-wave workgroup per CU
+    hipLaunchKernelGGL(stem7x7_s2_pool_f16, dim3(grid), dim3(512), STEM_POOL_LDS, mrcnn::as_stream(stream), p);
+    return mrcnn::check_launch("stem7x7_s2_pool_f16");
 }

@@ -217,6 +217,9 @@ F16_ACT = os.environ.get("MRCNN_F16_ACT", "1") != "0"
 # (csrc/conv_f16p.hip: eight waves, LDS-DMA in flight across barriers — 1.4-1.5x the 128x128-tile kernel on the 3x3 layers);
 # MRCNN_F16_PIPELINED=0 keeps them on conv_igemm_f16.
 F16_PIPELINED = os.environ.get("MRCNN_F16_PIPELINED", "1") != "0"
+# "f16" mode: the stem's conv + BN + ReLU + max-pool as one fp16-MFMA launch (csrc/stem.hip: stem7x7_s2_pool_f16). 0 = the
+# exact-fp32 stem with an fp16 store + the separate fp16 max-pool (rounds 2-3).
+F16_STEM_POOL = os.environ.get("MRCNN_F16_STEM_POOL", "1") != "0"
 # the RPN heads run inside that kernel on levels of at least this many pixels PER IMAGE (never a function of the batch: the two
 # forms round differently, and image i of a batch must equal image i alone); below it the 18-channel conv is a launch of its own
 F16_HEADS_MIN_PIXELS = int(os.environ.get("MRCNN_F16_HEADS_MIN_PIXELS", "4096"))
@@ -465,17 +468,26 @@ class FusedBackbone:
 
     def __call__(self, image_nchw):
         st = self.stem                                          # conv7x7 s2 p3 + BN + ReLU
+        pooled = False
         if (st.w.precision == "f32" and st.w.shape == (64, 7, 7, 4) and image_nchw.size(2) % 2 == 0
                 and image_nchw.size(3) % 2 == 0 and STEM_KERNEL):
             # dedicated kernel (csrc/stem.hip), reading the NCHW image itself: no layout pass over the image
             x = ops.stem_conv(image_nchw.contiguous(), st.w.w, st.scale, st.shift, True, st.algo_cin, nchw=True)
         elif (self.stem_w32 is not None and STEM_KERNEL and F16_PIPELINED and image_nchw.size(2) % 2 == 0
               and image_nchw.size(3) % 2 == 0):
-            x = ops.stem_conv(image_nchw.contiguous(), self.stem_w32, st.scale, st.shift, True, st.algo_cin, nchw=True,
-                              out_f16=True)
+            if F16_STEM_POOL and image_nchw.size(2) % 4 == 0 and image_nchw.size(3) % 4 == 0:
+                # round 4: conv + BN + ReLU + max-pool in ONE launch on the fp16 MFMA: the 64-channel full-resolution map
+                # never reaches memory (csrc/stem.hip: stem7x7_s2_pool_f16)
+                x = ops.stem_pool_f16(image_nchw.contiguous(), self.stem_w32, st.scale, st.shift, st.algo_cin)
+            else:
+                x = ops.stem_conv(image_nchw.contiguous(), self.stem_w32, st.scale, st.shift, True, st.algo_cin, nchw=True,
+                                  out_f16=True)
+                x = ops.maxpool(x, 3, 2, ops.same_pad(x.size(1), x.size(2), 3, 2))
+            pooled = True
         else:
             x = st(ops.nchw_to_nhwc(image_nchw.contiguous(), self.cin_pad))   # 3 → 4 (8) channels, zero-padded
-        x = ops.maxpool(x, 3, 2, ops.same_pad(x.size(1), x.size(2), 3, 2))
+        if not pooled:
+            x = ops.maxpool(x, 3, 2, ops.same_pad(x.size(1), x.size(2), 3, 2))
         cs = []
         for blocks in self.stages:
             for blk in blocks:

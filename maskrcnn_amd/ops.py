@@ -1264,3 +1264,26 @@ def stem_conv(x: torch.Tensor, w: torch.Tensor, scale, shift, relu: bool = True,
         m, k = y.numel() // 64, 49 * (algo_cin or 4)
         prof.append((e0, e1, 2.0 * m * 64 * k, (m, 64, k), 4.0 * (x.numel() + w.numel()) + y.numel() * y.element_size(), "stem"))
     return y
+
+
+@_on_device
+def stem_pool_f16(x: torch.Tensor, w: torch.Tensor, scale, shift, algo_cin: int | None = None) -> torch.Tensor:
+    """The "f16" mode's stem + max-pool in one launch on the fp16 MFMA (model.py:223-229): x the molded NCHW image [B,3,H,W]
+    fp32, w OHWI [64,7,7,4] fp32 → fp16 NHWC [B, ceil(H/4), ceil(W/4), 64]."""
+    _need_gpu(x, w, scale, shift)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.size(1) == 3
+    assert w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (64, 7, 7, 4)
+    b, _, h, wd = x.shape
+    assert h % 4 == 0 and wd % 4 == 0
+    poh, pow_ = h // 4, wd // 4
+    y = torch.empty(b, poh, pow_, 64, dtype=torch.float16, device=x.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mrcnn_stem_conv7x7_s2_pool_f16(x.data_ptr(), b, h, wd, w.data_ptr(), _ptr(scale), _ptr(shift), y.data_ptr(), _stream()))
+    if prof is not None:
+        e1.record()
+        m, k = b * (h // 2) * (wd // 2), 49 * (algo_cin or 4)
+        prof.append((e0, e1, 2.0 * m * 64 * k, (m, 64, k), 4.0 * (x.numel() + w.numel()) + y.numel() * 2, "stem"))
+    return y

@@ -1055,3 +1055,47 @@ def test_streaming_1x1_kernel_bit_identical_to_tiled(dev, cin, cout, relu, kbloc
     assert torch.equal(y, ref)
     want = _ref_conv(x.permute(0, 3, 1, 2).cpu(), wt.permute(0, 3, 1, 2).cpu(), sc.cpu(), sh.cpu(), 1, (0, 0, 0, 0), relu)
     assert (y_nhwc.permute(0, 3, 1, 2).cpu() - want).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 256, 256), (1, 72, 40), (3, 16, 16), (1, 4, 4), (1, 832, 1344)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+def test_stem_pool_f16_one_launch(shape):
+    """Round 4, the "f16" mode's stem: conv 7x7 s2 + affine + ReLU + SamePad(3,2) + MaxPool(3,2) (model.py:223-229) as ONE launch
+    on the fp16 MFMA (stem7x7_s2_pool_f16). Against torch-CPU on the SAME fp16-rounded image and weights (fp32 accumulation,
+    one rounding of the conv output to fp16, then the max): equal up to the summation order — at most one fp16 ulp on a few
+    values; and against the two-launch form it replaces (exact-fp32 products + fp16 store, then the fp16 max-pool): within the
+    fp16 mode's tolerance, 2e-2 of the range. Ragged tiles, odd pooled sizes, several images; H or W not a multiple of 4 is refused
+    (odd conv sizes give SamePad2d(3, 2) a top / left pad: the pipeline keeps the two launches there)."""
+    from maskrcnn_amd import ops
+    dev = torch.device("cuda:0")
+    b, h, w = shape
+    g = torch.Generator().manual_seed(h * 7 + w)
+    img = torch.randint(0, 256, (b, 3, h, w), generator=g).float() - torch.tensor([123.7, 116.8, 103.9]).view(1, 3, 1, 1)
+    wt = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    scale = torch.rand(64, generator=g) + 0.5
+    shift = torch.randn(64, generator=g) * 0.1
+    w_ohwi = torch.zeros(64, 7, 7, 4)
+    w_ohwi[..., :3] = wt.permute(0, 2, 3, 1)
+    got = ops.stem_pool_f16(img.to(dev), w_ohwi.to(dev), scale.to(dev), shift.to(dev)).float().cpu()
+    # reference on the operands the kernel sees
+    x16, w16 = img.half().float(), wt.half().float()
+    conv = F.conv2d(x16.double(), w16.double(), None, stride=2, padding=3).float()
+    conv = F.relu(conv * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).half().float()
+    oh, ow = conv.shape[2:]
+    from oracle import oracle
+    ref = F.max_pool2d(oracle.same_pad(conv, 3, 2), kernel_size=3, stride=2).permute(0, 2, 3, 1)
+    assert tuple(got.shape) == tuple(ref.shape) == (b, (oh + 1) // 2, (ow + 1) // 2, 64)
+    rng = ref.abs().max().item()
+    # one fp16 ulp at the value — or 1e-4 absolute where the 147-term sum cancels to almost nothing (measured at 832 x 1344: five
+    # values of 4.5 M, all below 1e-2, differ by up to 8e-6: the fp32 summation order against terms of magnitude ~30)
+    ulp = torch.maximum(ref.abs() * 2.0 ** -10, torch.tensor(1e-4))
+    diff = (got - ref).abs()
+    assert bool((diff <= ulp).all()), f"max diff {diff.max().item():.3e} at range {rng:.1f}"
+    assert float((diff > 0).float().mean()) < 0.02          # the rounding boundary is crossed rarely
+    # the two launches it replaces
+    two = ops.maxpool(ops.stem_conv(img.to(dev), w_ohwi.to(dev), scale.to(dev), shift.to(dev), True, nchw=True, out_f16=True), 3, 2,
+                      ops.same_pad(oh, ow, 3, 2)).float().cpu()
+    assert tuple(two.shape) == tuple(got.shape)
+    assert (got - two).abs().max().item() <= 2e-2 * rng
+    with pytest.raises(Exception):
+        ops.stem_pool_f16(torch.zeros(1, 3, 70, 40, device=dev), w_ohwi.to(dev), None, None)
