@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measure
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 
 
-TRAFFIC_PROFILE = "r03_hbm_traffic.json"
+TRAFFIC_PROFILE = "r04_hbm_traffic.json"
 
 
 def log(*a):
