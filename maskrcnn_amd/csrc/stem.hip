@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void stem7x7_s2_f32(const StemParams p) {
 // above plus the separate max-pool cost 0.33 + 0.09 ms of that mode's ~10 ms step, nearly all of it fp32-MFMA time for a
 // layer whose fp16-MFMA time is ~16x smaller; with fp16 operands the layer is bound by its bytes: the fp32 NCHW image in
 // (read once) and the POOLED fp16 map out — the 64-channel full-resolution map (the largest tensor of the step) never exists.
-//   tile      a persistent workgroup of eight waves owns 8 x 16 POOLED pixels = 17 x 33 conv outputs (one row / column of
+//   tile      a persistent workgroup of NINE waves (two of the 18 MFMA row tiles each) owns 8 x 16 POOLED pixels = 17 x 33 conv outputs (one row / column of
 //             overlap with the next tile: 1.10x the MFMA work, which does not matter here) x all 64 channels
 //   K         per filter row ky: (kx, c) with kx padded 7 -> 8 and c padded 3 -> 4: 32 halves = two MFMA k steps. A conv
 //             pixel's A fragment for (ky, step, lane half h) is the 16 contiguous bytes of patch pixels 2 ox + 4 step + 2 h, + 1
@@ -234,7 +234,8 @@ constexpr int SP_C_HALVES = SP_NRT * 32 * 64;
 constexpr size_t STEM_POOL_LDS = sizeof(_Float16) * (SP_W_HALVES + SP_P_HALVES + SP_C_HALVES);
 static_assert(STEM_POOL_LDS <= 160 * 1024, "LDS");
 
-__global__ __launch_bounds__(512, 1) void stem7x7_s2_pool_f16(const StemPoolParams p) {
+constexpr int SP_THREADS = 576;   // nine waves: two of the tile's 18 MFMA row tiles each
+__global__ __launch_bounds__(SP_THREADS, 1) void stem7x7_s2_pool_f16(const StemPoolParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16* Wl = reinterpret_cast<_Float16*>(smem_raw);    // [7][64][32] (chunk-swizzled)
     _Float16* Pl = Wl + SP_W_HALVES;                          // [39][72][4]
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(512, 1) void stem7x7_s2_pool_f16(const StemPoolPara
     const int ln = lane & 31, lh = lane >> 5;
 
     // the filter, once per workgroup: fp32 [n][ky][kx][4] -> fp16 [ky][n][kx 0..7][4], kx = 7 zero
-    for (int i = tid; i < 7 * 64 * 8; i += 512) {
+    for (int i = tid; i < 7 * 64 * 8; i += SP_THREADS) {
         const int kx = i & 7, n = (i >> 3) & 63, ky = i >> 9;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (kx < 7) v = reinterpret_cast<const float4*>(p.w)[(n * 7 + ky) * 7 + kx];
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(512, 1) void stem7x7_s2_pool_f16(const StemPoolPara
         *reinterpret_cast<sp_f16x4*>(Wl + (ky * 64 + n) * 32 + chunk * 8 + (kx & 1) * 4) = h4;
     }
     // channel 3 of every patch pixel and the last patch column (only ever multiplied by zero weights) stay zero
-    for (int i = tid; i < SP_IH * SP_IW; i += 512) *reinterpret_cast<sp_f16x4*>(Pl + i * 4) = sp_f16x4{0, 0, 0, 0};
+    for (int i = tid; i < SP_IH * SP_IW; i += SP_THREADS) *reinterpret_cast<sp_f16x4*>(Pl + i * 4) = sp_f16x4{0, 0, 0, 0};
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     float sc[2], sh[2];
@@ -261,17 +262,16 @@ __global__ __launch_bounds__(512, 1) void stem7x7_s2_pool_f16(const StemPoolPara
         sc[ct] = p.scale ? p.scale[ct * 32 + ln] : 1.0f;
         sh[ct] = p.shift ? p.shift[ct * 32 + ln] : 0.0f;
     }
-    // this wave's row tiles: wave, wave + 8, wave + 16 (the last only for waves 0, 1). A-fragment base (halves) of conv pixel
-    // q = 32 rt + ln: patch pixel (2 oy, 2 ox + 2 lh); pixels beyond the 561 of the tile read pixel 560's (discarded)
-    constexpr int NRW = 3;
+    // this wave's row tiles: wave and wave + 9. A-fragment base (halves) of conv pixel q = 32 rt + ln: patch pixel
+    // (2 oy, 2 ox + 2 lh); pixels beyond the 561 of the tile read pixel 560's (discarded)
+    constexpr int NRW = 2;
     int a_base[NRW];
 #pragma unroll
     for (int i = 0; i < NRW; ++i) {
-        const int q = min((wave + 8 * i) * 32 + ln, SP_NPX - 1);
+        const int q = min((wave + 9 * i) * 32 + ln, SP_NPX - 1);
         const int oy = q / SP_CW, ox = q - oy * SP_CW;
         a_base[i] = ((2 * oy) * SP_IW + 2 * ox + 2 * lh) * 4;
     }
-    const bool third = wave + 16 < SP_NRT;   // wave-uniform
     // B fragment of channel ct * 32 + ln, k step s: chunk 2 s + lh, swizzled by the channel
     int b_off[2][2];
 #pragma unroll
@@ -282,41 +282,68 @@ __global__ __launch_bounds__(512, 1) void stem7x7_s2_pool_f16(const StemPoolPara
             b_off[ct][s2] = n * 32 + ((2 * s2 + lh) ^ ((n >> 2) & 3)) * 8;
         }
 
+    // the patch of a tile: 39 x 71 pixels x 3 planes as 4-byte loads (consecutive lanes = consecutive x of one plane), 15 per
+    // thread. They are issued ONE TILE AHEAD — right after the current tile's patch has been written to LDS — and ride in
+    // registers through its MFMAs, conv image and pool. Which element a thread's j-th load is never changes: its offset relative
+    // to the tile's origin and its place in the LDS patch are computed once (30 registers) — recomputed per tile, the divisions
+    // by 39 * 71 and 71 made the kernel VALU-bound.
+    // barriers are LDS-only: __syncthreads() also waits for vector memory (vmcnt(0)), i.e. for the prefetched patch and for the
+    // pool's stores
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    constexpr int NE = 3 * SP_IH * (SP_IW - 1);
+    constexpr int NL = (NE + SP_THREADS - 1) / SP_THREADS;   // 15
+    int s_rel[NL];        // (c * H + py) * W + px
+    unsigned s_pk[NL];    // LDS index (py * 72 + px) * 4 + c | py << 14 | px << 20; element beyond the patch: all ones
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int i = tid + SP_THREADS * j;
+        const int c = i / (SP_IH * (SP_IW - 1)), r = i - c * (SP_IH * (SP_IW - 1));
+        const int py = r / (SP_IW - 1), px = r - py * (SP_IW - 1);
+        s_rel[j] = (c * p.H + py) * p.W + px;
+        s_pk[j] = i < NE ? static_cast<unsigned>((py * SP_IW + px) * 4 + c) | (py << 14) | (px << 20) : 0xFFFFFFFFu;
+    }
+    unsigned pv[NL];
+    auto load_patch = [&](int tile_) {
+        const bool live = tile_ < p.tiles;
+        const int b_ = tile_ / (p.tiles_y * p.tiles_x), rem_ = tile_ - b_ * p.tiles_y * p.tiles_x;
+        const int ty_ = rem_ / p.tiles_x, tx_ = rem_ - ty_ * p.tiles_x;
+        const int iy0 = ty_ * 2 * SP_PH * 2 - 3, ix0 = tx_ * 2 * SP_PW * 2 - 3;
+        const int base = (b_ * 3 * p.H + iy0) * p.W + ix0;                    // wave-uniform; may be negative at the borders
+        // a tile whose whole patch lies inside the image needs no per-element test (most tiles)
+        const bool inside = live && iy0 >= 0 && ix0 >= 0 && iy0 + SP_IH <= p.H && ix0 + SP_IW - 1 <= p.W;
+        if (inside) {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const unsigned off = s_pk[j] != 0xFFFFFFFFu ? static_cast<unsigned>(base + s_rel[j]) * 4u : OOB;
+                pv[j] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, static_cast<int>(off), 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int iy = iy0 + static_cast<int>((s_pk[j] >> 14) & 63), ix = ix0 + static_cast<int>((s_pk[j] >> 20) & 127);
+                const bool ok = live && s_pk[j] != 0xFFFFFFFFu && static_cast<unsigned>(iy) < static_cast<unsigned>(p.H) &&
+                                static_cast<unsigned>(ix) < static_cast<unsigned>(p.W);
+                const unsigned off = ok ? static_cast<unsigned>(base + s_rel[j]) * 4u : OOB;
+                pv[j] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, static_cast<int>(off), 0, 0);
+            }
+        }
+    };
+    load_patch(blockIdx.x);
     for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
         const int b = tile / (p.tiles_y * p.tiles_x), rem = tile - b * p.tiles_y * p.tiles_x;
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
         const int cy0 = ty * 2 * SP_PH, cx0 = tx * 2 * SP_PW;   // first conv output of the tile
-        const int iy0 = cy0 * 2 - 3, ix0 = cx0 * 2 - 3;
-        __syncthreads();  // the previous tile's patch and conv image are no longer read (first trip: the filter / zero stores)
-        // an opaque copy of the thread id per tile: the staging / epilogue / pool index arithmetic below is invariant across
-        // tiles, and computed once ahead of this loop it costs ~100 registers that the allocator then spills
+        lds_barrier();  // the previous tile's patch and conv image are no longer read (first trip: the filter / zero stores)
+        // an opaque copy of the thread id per tile: the epilogue / pool index arithmetic below is invariant across tiles, and
+        // computed once ahead of this loop it costs ~100 registers that the allocator then spills
         int t_ = tid;
         asm volatile("" : "+v"(t_));
         const int ln_ = t_ & 31, lh_ = (t_ >> 5) & 1, wave_ = t_ >> 6;
-        {
-            constexpr int NE = 3 * SP_IH * (SP_IW - 1);          // 39 x 71 pixels x 3 planes
-            constexpr int NL = (NE + 511) / 512;                 // 17 loads per thread, all issued before the first LDS store
-            unsigned v[NL];
 #pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                const int i = t_ + 512 * j;
-                const int c = i / (SP_IH * (SP_IW - 1)), r = i - c * (SP_IH * (SP_IW - 1));
-                const int py = r / (SP_IW - 1), px = r - py * (SP_IW - 1);
-                const int iy = iy0 + py, ix = ix0 + px;
-                const bool ok = i < NE && static_cast<unsigned>(iy) < static_cast<unsigned>(p.H) &&
-                                static_cast<unsigned>(ix) < static_cast<unsigned>(p.W);
-                const unsigned off = ok ? static_cast<unsigned>(((b * 3 + c) * p.H + iy) * p.W + ix) * 4u : OOB;
-                v[j] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, static_cast<int>(off), 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                const int i = t_ + 512 * j;
-                const int c = i / (SP_IH * (SP_IW - 1)), r = i - c * (SP_IH * (SP_IW - 1));
-                const int py = r / (SP_IW - 1), px = r - py * (SP_IW - 1);
-                if (i < NE) Pl[(py * SP_IW + px) * 4 + c] = static_cast<_Float16>(__uint_as_float(v[j]));
-            }
-        }
-        __syncthreads();
+        for (int j = 0; j < NL; ++j)
+            if (s_pk[j] != 0xFFFFFFFFu) Pl[s_pk[j] & 0x3FFF] = static_cast<_Float16>(__uint_as_float(pv[j]));
+        load_patch(tile + gridDim.x);   // the next tile's, in flight from here
+        lds_barrier();
 
         f32x16 acc[NRW][2];
 #pragma unroll
@@ -335,43 +362,49 @@ __global__ __launch_bounds__(512, 1) void stem7x7_s2_pool_f16(const StemPoolPara
                 for (int ct = 0; ct < 2; ++ct) bf[ct] = *reinterpret_cast<const sp_f16x8*>(Wl + ky * 64 * 32 + b_off[ct][s2]);
 #pragma unroll
                 for (int i = 0; i < NRW; ++i)
-                    if (i < 2 || third) af[i] = *reinterpret_cast<const sp_f16x8*>(Pl + a_base[i] + (ky * SP_IW + 4 * s2) * 4);
+                    af[i] = *reinterpret_cast<const sp_f16x8*>(Pl + a_base[i] + (ky * SP_IW + 4 * s2) * 4);
 #pragma unroll
                 for (int i = 0; i < NRW; ++i)
-                    if (i < 2 || third) {
 #pragma unroll
-                        for (int ct = 0; ct < 2; ++ct)
-                            acc[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[ct], acc[i][ct], 0, 0, 0);
-                    }
+                    for (int ct = 0; ct < 2; ++ct)
+                        acc[i][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[ct], acc[i][ct], 0, 0, 0);
             }
-        // conv image: affine + ReLU, zero outside the conv map, one rounding to fp16
+        // conv image: affine + ReLU, zero outside the conv map, one rounding to fp16. Row r of a 32-pixel row tile is pixel
+        // q0 + d_r with d_r a compile-time constant (<= 27 < 33: at most one wrap into the next conv row); the LDS address is
+        // one base + immediates
+        const bool interior = cy0 + SP_CH <= p.OH && cx0 + SP_CW <= p.OW;   // wave-uniform: no per-pixel test but q < 561
 #pragma unroll
-        for (int i = 0; i < NRW; ++i)
-            if (i < 2 || third) {
+        for (int i = 0; i < NRW; ++i) {
+            const int q0 = (wave_ + 9 * i) * 32 + 4 * lh_;
+            const int oy0 = (q0 * 1986) >> 16, ox0 = q0 - oy0 * SP_CW;   // q0 / 33 for q0 < 576
+            _Float16* crow = Cl + q0 * 64 + ln_;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int q = (wave_ + 8 * i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh_;
-                    const int oy = (q * 1986) >> 16, ox = q - oy * SP_CW;   // q / 33 for q < 576
-                    const bool in = q < SP_NPX && cy0 + oy < p.OH && cx0 + ox < p.OW;
+            for (int r = 0; r < 16; ++r) {
+                const int d = (r & 3) + 8 * (r >> 2);
+                bool in = q0 + d < SP_NPX;
+                if (!interior) {
+                    const int oxr = ox0 + d, wrap = oxr >= SP_CW ? 1 : 0;
+                    in = in && cy0 + oy0 + wrap < p.OH && cx0 + oxr - wrap * SP_CW < p.OW;
+                }
 #pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
-                        float v = acc[i][ct][r] * sc[ct] + sh[ct];
-                        v = v > 0.f ? v : 0.f;
-                        v = in ? v : 0.f;
-                        asm volatile("" : "+v"(v));   // fp32 first, then ONE rounding to fp16 (no fused mixed-precision fma)
-                        Cl[q * 64 + ct * 32 + ln_] = static_cast<_Float16>(v);
-                    }
+                for (int ct = 0; ct < 2; ++ct) {
+                    float v = acc[i][ct][r] * sc[ct] + sh[ct];
+                    v = v > 0.f ? v : 0.f;
+                    v = in ? v : 0.f;
+                    asm volatile("" : "+v"(v));   // fp32 first, then ONE rounding to fp16 (no fused mixed-precision fma)
+                    crow[d * 64 + ct * 32] = static_cast<_Float16>(v);
                 }
             }
-        __syncthreads();
-        // pool: thread = (channel pair, 8 pooled pixels)
+        }
+        lds_barrier();
+        // pool: thread = (channel pair, 7 or 8 pooled pixels)
         {
             int t2 = tid;
             asm volatile("" : "+v"(t2));
-            const int cp = t2 & 31, g = t2 >> 5;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int pp = g * 8 + j, py = pp >> 4, px = pp & 15;
+            const int cp = t2 & 31, g = t2 >> 5;   // 18 groups of 32 lanes over the 128 pooled pixels
+#pragma unroll 1
+            for (int pp = g; pp < SP_PH * SP_PW; pp += SP_THREADS / 32) {
+                const int py = pp >> 4, px = pp & 15;
                 sp_f16x2 m = {0, 0};   // the values are >= 0
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
@@ -461,6 +494,6 @@ extern "C" int mrcnn_stem_conv7x7_s2_pool_f16(const float* x_nchw, int32_t batch
     const int num_cu = mrcnn::device_cu_count();
     if (num_cu <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "stem_pool: cannot query the device");
     const int grid = p.tiles < num_cu ? p.tiles : num_cu;   // persistent: one eight-wave workgroup per CU
-    hipLaunchKernelGGL(stem7x7_s2_pool_f16, dim3(grid), dim3(512), STEM_POOL_LDS, mrcnn::as_stream(stream), p);
+    hipLaunchKernelGGL(stem7x7_s2_pool_f16, dim3(grid), dim3(SP_THREADS), STEM_POOL_LDS, mrcnn::as_stream(stream), p);
     return mrcnn::check_launch("stem7x7_s2_pool_f16");
 }

@@ -24,7 +24,16 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     # on a single GPU (MRCNN_FORCE_COLLECTIVE=1 makes the helpers below issue the collectives there too)
     if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            # every launcher (torchrun, bench.py's own self-launch) sets it; a fixed default would make two jobs on one node
+            # collide. Alone (world 1) any free port will do; several ranks must be TOLD the same one.
+            if world > 1:
+                raise RuntimeError("maskrcnn_amd.dist: MASTER_PORT is not set (launch with torch.distributed.run, or "
+                                   "`python bench.py --gpus N`, which picks a free port)")
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             # MRCNN_DIST_REHEARSAL=1: several ranks on ONE GPU box (all on cuda:0, gloo moves the detections block): RCCL refuses
