@@ -406,6 +406,38 @@ def test_full_size_batch8_independence(full):
     REPORT[s["tag"] + "/batch8_independence"] = "bit-identical (images 0 and 5; trunk, RPN, proposals, classifier, detections, masks)"
 
 
+def test_full_size_kernel_routing_is_the_documented_one_and_independent_of_the_batch(full):
+    """modules.py's routing — which kernel every conv of the step takes — as a table: at 1024^2 the R50-FPN step is 75 conv
+    launches (direct implicit GEMM 45 incl. the streaming 1x1 kernel, F(4x4) Winograd 19, F(2x2) linear tiles 4 =
+    the mask head, F(2x2) spatial tiles 6, stem 1), and the SAME sequence of (kernel, N, K) for one image as for eight: a layer's
+    kernel is chosen by the image size, never by the batch (which is what makes image i of a batch equal image i alone)."""
+    from maskrcnn_amd import ops
+    s = full
+    if s["precision"] != "f32":
+        pytest.skip("the routing table is the f32 mode's")
+    net, dev = s["net"], s["net"].device
+    g = torch.Generator().manual_seed(3)
+    images = (torch.randint(0, 256, (8, 1024, 1024, 3), generator=g).float() - torch.tensor(s["cfg"].mean_pixel))
+    images = images.permute(0, 3, 1, 2).contiguous().to(dev)
+    windows = torch.tensor([[0., 0., 1024., 1024.]] * 8, device=dev)
+    seqs = {}
+    for b in (1, 8):
+        ops.CONV_PROFILE = []
+        try:
+            net.predict(images[:b], windows[:b])
+            torch.cuda.synchronize()
+            prof = ops.CONV_PROFILE
+        finally:
+            ops.CONV_PROFILE = None
+        seqs[b] = [(r[5] if len(r) > 5 else "direct", r[3][1], r[3][2]) for r in prof]
+    assert seqs[1] == seqs[8], [(i, a, c) for i, (a, c) in enumerate(zip(seqs[1], seqs[8])) if a != c][:5]
+    counts = {}
+    for tag, _, _ in seqs[8]:
+        counts[tag] = counts.get(tag, 0) + 1
+    REPORT["config3/kernel_routing"] = counts
+    assert counts == {"stem": 1, "direct": 45, "winograd4": 19, "winograd": 4, "winograd_spatial": 6}, counts
+
+
 # ------------------------------------------------------------------------------------------------------------
 # config 5 at full size: ResNet-101-FPN, 832 x 1344
 # ------------------------------------------------------------------------------------------------------------
