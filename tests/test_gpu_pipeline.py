@@ -310,3 +310,35 @@ def test_head_skips_empty_roi_slots_without_changing_a_valid_row(monkeypatch):
     assert torch.equal(d1.class_ids, d0.class_ids) and torch.equal(d1.boxes, d0.boxes) and torch.equal(d1.scores, d0.scores)
     assert torch.equal(d1.counts, d0.counts) and torch.equal(d1.masks, d0.masks)
     assert int(d1.counts.sum()) > 0 and not bool(torch.isnan(d1.masks).any())
+
+
+def test_predict_splits_oversized_batches_into_equal_sub_batches():
+    """pipeline.max_batch_per_launch: past it (31 images at 1024^2) a tensor would exceed the kernels' 2^30-element limit and a layer
+    would fall to another kernel, i.e. image i of a batch would no longer equal image i alone. predict() runs such a batch as
+    equal sub-batches instead: forced here with a limit of 2 on five images — every output equals the one-launch result bit for
+    bit, and return_intermediates (whose tensors cannot be concatenated across sub-batches) is refused."""
+    from maskrcnn_amd import modules
+    from maskrcnn_amd.config import InferenceConfig
+    from maskrcnn_amd.pipeline import MaskRCNNInference
+    dev = torch.device("cuda:0")
+    cfg = InferenceConfig(image_height=128, image_width=192, backbone="resnet50", pre_nms_limit=200, proposal_count=100,
+                          detection_max_instances=10)
+    sd = modules.synthetic_state_dict("resnet50", seed=0, bn_seed=1)
+    g = torch.Generator().manual_seed(4)
+    sd["rpn.conv_class.weight"] = sd["rpn.conv_class.weight"] * 0.05
+    sd["classifier.linear_class.weight"] = torch.randn(81, 1024, generator=g) * 0.05
+    sd["classifier.linear_bbox.weight"] = torch.randn(324, 1024, generator=g) * 0.02
+    images = (torch.randint(0, 256, (5, 128, 192, 3), generator=g).float() - torch.tensor(cfg.mean_pixel))
+    images = images.permute(0, 3, 1, 2).contiguous().to(dev)
+    windows = torch.tensor([[0., 0., 128., 192.]] * 5, device=dev)
+    net = MaskRCNNInference(sd, cfg, dev)
+    assert net.max_batch >= 5
+    whole = net.predict(images, windows)
+    net.max_batch = 2
+    split = net.predict(images, windows)
+    torch.cuda.synchronize()
+    for f in ("class_ids", "scores", "boxes", "counts", "masks"):
+        assert torch.equal(getattr(whole, f), getattr(split, f)), f
+    assert tuple(split.masks.shape) == (5, 10, 28, 28, 81) and int(split.counts.sum()) > 0
+    with pytest.raises(AssertionError):
+        net.predict(images, windows, return_intermediates=True)
