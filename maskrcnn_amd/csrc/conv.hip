@@ -562,7 +562,10 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
     // 128x128 with BK = 16 (41 KB of LDS: three workgroups per CU) for the shortest K (<= 128) with wide outputs — C3 conv3
     // (K = 128 -> 512 + residual) and the C2 downsample (K = 64 -> 256): measured in the pipeline against the 128x64 / 128x128 BK32
     // tiles they used to take, 0.766 -> 0.723 ms over the four C3 layers, 0.199 -> 0.190; every longer-K layer is slower on it
-    if (!generic && (force == 3 || (force == 0 && p.K <= 128 && cout >= 256))) return launch_conv<128, 128, 2, 2, 16>(p, mode, s);
+    // round 4 (in-pipeline per-launch events, MRCNN_CONV_TILE sweeps): the same tile for the mask head's transposed conv (K = 256
+    // -> 4 x 256 channels scattered 2x2: its epilogue is store-bound, three workgroups per CU overlap it better) 0.371 -> 0.351 ms
+    if (!generic && (force == 3 || (force == 0 && ((p.K <= 128 && cout >= 256) || (out_mode == 1 && p.K <= 256 && cout >= 256)))))
+        return launch_conv<128, 128, 2, 2, 16>(p, mode, s);
     // Bottleneck conv3 (1x1 expansion + residual, K = planes <= 256): latency-bound on load -> MFMA -> residual -> store
     // per tile; a 128x64 BK16 tile (30 KB of LDS, 32 accumulator registers) keeps five workgroups per CU in flight
     // instead of two: 7 % faster on those layers, slower on everything else (measured per layer, round 1)
