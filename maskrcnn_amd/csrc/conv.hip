@@ -573,6 +573,12 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
     // 94 us). Same products in the same order per output: the choice never changes a result.
     const long long tiles128 = ((p.M + 127) / 128) * static_cast<long long>((cout + 127) / 128);
     const bool underfilled = cout >= 128 && tiles128 < mrcnn::device_cu_count();
+    // ... and when even 128x64 tiles give a CU only one workgroup with a long K to walk alone (P5 lateral at batch 8: 256 tiles,
+    // K = 2048: 0.104 ms at 0.56 of its MFMA floor), 128x32 tiles put two on every CU (MRCNN_CONV_N32=0: off)
+    static const bool n32 = !(getenv("MRCNN_CONV_N32") && getenv("MRCNN_CONV_N32")[0] == '0');
+    if (!generic && n32 && force == 0 && underfilled && p.K >= 1024 &&
+        ((p.M + 127) / 128) * static_cast<long long>((cout + 63) / 64) <= mrcnn::device_cu_count())
+        return launch_conv<128, 32, 4, 1, 32>(p, mode, s);
     if (!generic && force != 1 &&
         (force == 5 || underfilled || (p.K <= 256 && p.residual && p.res_div == 1 && cout >= 128)))
         return launch_conv<128, 64, 2, 2, 16>(p, mode, s);

@@ -139,6 +139,8 @@ FULL_1X1 = [
     (1, 64, 64, 1024, 256, 1, True, False),     # C4 conv1
     (1, 32, 32, 512, 2048, 1, True, True),      # C5 conv3 + residual
     (1, 256, 256, 512, 18, 1, False, False),    # RPN heads on P2
+    (8, 32, 32, 2048, 256, 1, False, False),    # P5 lateral at batch 8: the under-filled long-K case (128x32 tiles, round 4)
+    (8, 28, 28, 256, 81, 1, False, False),      # 64 < Cout <= 96: the 128x96 tile (mask head conv5's shape class, round 4)
 ]
 
 
