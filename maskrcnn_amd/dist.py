@@ -43,7 +43,26 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == "nccl":
+            _create_communicator_quietly(local)
     return rank, local, world
+
+
+def _create_communicator_quietly(local: int) -> None:
+    """RCCL creates a group's communicator at its first collective, and with NCCL_DEBUG=VERSION (set on this pool's boxes) it
+    prints its version banner there — on STDOUT, from C. A benchmark's stdout is one JSON line: run that first collective
+    here, with file descriptor 1 pointing at stderr for its duration."""
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        t = torch.zeros(1, device=torch.device("cuda", local))
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def rehearsal() -> bool:

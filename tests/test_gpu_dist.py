@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _env(**kw):
-    env = dict(os.environ, MRCNN_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MRCNN_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="VERSION")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
     env.update(kw)
@@ -52,6 +52,8 @@ def test_bench_under_torchrun_reports_rccl(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1
+    # stdout is the JSON line and nothing else: RCCL's version banner (NCCL_DEBUG=VERSION on this pool) goes to stderr
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines, r.stdout[:600]
     line = json.loads(lines[0])
     assert line["dist_backend"] == "nccl" and line["rccl_ranks"] == 1 and line["n_gpus"] == 1
     assert line["value"] > 0 and line["config"]["global_batch"] == 2
