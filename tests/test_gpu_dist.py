@@ -57,3 +57,22 @@ def test_bench_under_torchrun_reports_rccl(tmp_path):
     line = json.loads(lines[0])
     assert line["dist_backend"] == "nccl" and line["rccl_ranks"] == 1 and line["n_gpus"] == 1
     assert line["value"] > 0 and line["config"]["global_batch"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` with no WORLD_SIZE — how the driver may call it — launches its own torch.distributed.run child with
+    two ranks. On the one-GPU box both ranks drive cuda:0 and gloo moves the detections block (MRCNN_DIST_REHEARSAL=1: RCCL refuses
+    two ranks on one device; never a measurement): the CONTROL FLOW of N > 1 end to end — rendezvous on a free port, per-rank
+    shards and seeds, barrier-bracketed timing, MAX over ranks, one all-gather per step, rank 0 alone printing, clean exit."""
+    env = _env(MRCNN_DIST_REHEARSAL="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reps", "1",
+           "--size", "256", "--batch", "2", "--proposals", "200", "--cpu-images", "0", "--roofline-steps", "0",
+           "--alt-precision", "none", "--alt-config5", "0", "--measure-traffic", "0", "--in-flight", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), r.stdout[:600]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["dist_backend"] == "gloo" and line["rccl_ranks"] == 0
+    assert "REHEARSAL" in line["config"]["parallelism"] and line["value"] > 0
