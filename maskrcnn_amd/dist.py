@@ -42,27 +42,33 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
             backend = "gloo" if (rehearsal() or not torch.cuda.is_available()) else "nccl"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-        if backend == "nccl":
-            _create_communicator_quietly(local)
+            # RCCL creates a group's communicator at init (device_id given: eager) or at its first collective, and with
+            # NCCL_DEBUG=VERSION (exported on this pool's boxes) it prints its version banner there — on STDOUT, from C. A
+            # benchmark's stdout is one JSON line: both happen here, with file descriptor 1 pointing at stderr meanwhile.
+            with _stdout_to_stderr():
+                # device_id binds the group to this rank's GPU (barrier() then needs no guess about "the current device")
+                dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+                t = torch.zeros(1, device=torch.device("cuda", local))
+                dist.all_reduce(t)
+                torch.cuda.synchronize()
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
 
 
-def _create_communicator_quietly(local: int) -> None:
-    """RCCL creates a group's communicator at its first collective, and with NCCL_DEBUG=VERSION (set on this pool's boxes) it
-    prints its version banner there — on STDOUT, from C. A benchmark's stdout is one JSON line: run that first collective
-    here, with file descriptor 1 pointing at stderr for its duration."""
-    import sys
-    sys.stdout.flush()
-    saved = os.dup(1)
-    try:
+class _stdout_to_stderr:
+    """File descriptor 1 → 2 for the duration (C-level writes included); Python's own buffer is flushed first."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
         os.dup2(2, 1)
-        t = torch.zeros(1, device=torch.device("cuda", local))
-        dist.all_reduce(t)
-        torch.cuda.synchronize()
-    finally:
-        os.dup2(saved, 1)
-        os.close(saved)
+
+    def __exit__(self, *exc):
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
 
 
 def rehearsal() -> bool:
