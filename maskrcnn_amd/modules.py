@@ -194,8 +194,8 @@ RPN_HEADS_MIN_TILES = 64
 # are fused into it from WINOGRAD4_HEADS_MIN_TILES per image. MRCNN_WINOGRAD4=0 keeps F(2x2) everywhere.
 WINOGRAD4 = os.environ.get("MRCNN_WINOGRAD4", "1") != "0"
 WINOGRAD4_TRUNK = os.environ.get("MRCNN_WINOGRAD4_TRUNK", "1") != "0"   # also the Bottleneck conv2 layers (C2-C4 sizes)
-WINOGRAD4_MIN_TILES = 8
-WINOGRAD4_HEADS_MIN_TILES = 32
+WINOGRAD4_MIN_TILES = int(os.environ.get("MRCNN_W4_MIN_TILES", "8"))             # (the environment forms: tuning sweeps only)
+WINOGRAD4_HEADS_MIN_TILES = int(os.environ.get("MRCNN_W4_HEADS_MIN_TILES", "32"))
 # Bottlenecks with planes = 64 (ResNet C2) whose conv2 takes the F(4x4) kernel: conv3 (1x1 expansion + BN + residual + ReLU)
 # runs inside that kernel's epilogue (ops.conv3x3_winograd4_conv3) — the 64-channel map between them never reaches HBM and
 # one launch per block is gone; bit-identical to the two launches it replaces. MRCNN_FUSED_CONV3=0 keeps them apart.
