@@ -554,9 +554,8 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
                                                    : launch_conv<256, 64, 4, 1, 16>(p, mode, s);
     // 64 < Cout <= 96 (the mask head's conv5, 256 -> 81 + sigmoid on 313 600 pixels, model.py:913-914): a 128x96 tile — four
     // waves of 32 rows x 96 columns — instead of a 128-column tile of which 37 % would be padding (MFMA-bound at the padded
-    // width: 0.189 ms). MRCNN_CONV_N96=0 keeps the 128x128 tile (same products in the same order: bit-identical).
-    static const bool n96 = !(getenv("MRCNN_CONV_N96") && getenv("MRCNN_CONV_N96")[0] == '0');
-    if (!generic && n96 && force == 0 && cout > 64 && cout <= 96) return launch_conv<128, 96, 4, 1, 32>(p, mode, s);
+    // width: 0.189 -> 0.151 ms). Same products in the same order: bit-identical (MRCNN_CONV_TILE=1 keeps the 128x128 tile).
+    if (!generic && force == 0 && cout > 64 && cout <= 96) return launch_conv<128, 96, 4, 1, 32>(p, mode, s);
     // (a 256x128 BK16 tile — 25% fewer LDS/global bytes per MFMA — was measured in round 1: no gain over 128x128 even on
     // the largest layers, 133.5 vs 133.2 TFLOP/s, and a loss on mid-size ones; removed)
     // 128x128 with BK = 16 (41 KB of LDS: three workgroups per CU) for the shortest K (<= 128) with wide outputs — C3 conv3
@@ -574,9 +573,8 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
     const long long tiles128 = ((p.M + 127) / 128) * static_cast<long long>((cout + 127) / 128);
     const bool underfilled = cout >= 128 && tiles128 < mrcnn::device_cu_count();
     // ... and when even 128x64 tiles give a CU only one workgroup with a long K to walk alone (P5 lateral at batch 8: 256 tiles,
-    // K = 2048: 0.104 ms at 0.56 of its MFMA floor), 128x32 tiles put two on every CU (MRCNN_CONV_N32=0: off)
-    static const bool n32 = !(getenv("MRCNN_CONV_N32") && getenv("MRCNN_CONV_N32")[0] == '0');
-    if (!generic && n32 && force == 0 && underfilled && p.K >= 1024 &&
+    // K = 2048: 0.104 ms at 0.56 of its MFMA floor), 128x32 tiles put two on every CU: 0.072 ms (MRCNN_CONV_TILE=5: 128x64)
+    if (!generic && force == 0 && underfilled && p.K >= 1024 &&
         ((p.M + 127) / 128) * static_cast<long long>((cout + 63) / 64) <= mrcnn::device_cu_count())
         return launch_conv<128, 32, 4, 1, 32>(p, mode, s);
     if (!generic && force != 1 &&
