@@ -261,10 +261,11 @@ def _fp64_truth(oracle, image, sd, arch):
         return oracle.fpn_forward(image.double(), sd64, arch)
 
 
-def _fp64_rows(key, truth, got, want32, factor=2.5):
+def _fp64_rows(key, truth, got, want32, factor=3.0):
     """Per level: max / rms of |HIP - fp64| and |oracle_fp32 - fp64| → REPORT. Asserted: max|HIP - fp64| <= factor x max|oracle_fp32
-    - fp64| and the same for the rms (or 1e-4 abs, whichever is larger); factor 2.5 in exact fp32, 3 for the f32+f16x3 alt mode
-    (22-bit-significand products on the long-K layers: measured 2.2 - 2.6 x). Measured on the MI355X (profiles/r04_fp64_truth.jsonl): the
+    - fp64| and the same for the rms (or 1e-4 abs, whichever is larger); factor 3 in exact fp32 (measured 1.8 - 2.2 x; the
+    oracle's own distance depends on the host's oneDNN blocking, so the bar leaves room for another CPU), 3.5 for the f32+f16x3
+    alt mode (22-bit-significand products on the long-K layers: measured 2.2 - 2.6 x). Measured on the MI355X (profiles/r04_fp64_truth.jsonl): the
     reference's own arithmetic (torch-CPU fp32) is 6 - 9 ulps of the activation range from the truth (1.6e-4 abs at |act| 210,
     7.2e-4 at 650: ABOVE 1e-4 abs on its own), the HIP trunk 13 - 17 ulps = 1.8 - 2.2 x that (rms 1.8 - 2.0 x) — and the exact
     direct kernel everywhere (MRCNN_WINOGRAD=0, bitwise one fmaf chain over K per output) 25 - 35 ulps: the distance is the
@@ -295,7 +296,7 @@ def test_full_size_trunk_against_fp64_truth(full, oracle):
     truth = _fp64_truth(oracle, img, s["sd"], "resnet50")
     want32 = oracle.fpn_forward(img, s["sd"], "resnet50")
     got = [m[0].permute(2, 0, 1).cpu() for m in s["mid"]["feature_maps"]]
-    _fp64_rows(f"{s['tag']}/fp64_truth/img0", truth, got, want32, 2.5 if s["precision"] == "f32" else 3.0)
+    _fp64_rows(f"{s['tag']}/fp64_truth/img0", truth, got, want32, 3.0 if s["precision"] == "f32" else 3.5)
 
 
 def test_full_size_proposals(full, oracle):
