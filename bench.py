@@ -170,6 +170,9 @@ def conv_roofline(prof, args, H, W, modules, measured=None, measured_reason=None
         al = sum(r[2] for r, k in zip(prof, sel) if k)
         return {"launches_per_step": n // steps, "ms_per_step": round(ms / steps, 3),
                 "avg_launch_us": round(ms / n * 1e3, 2),
+                # frac of any set of families = sum(executed_gflop_per_step) / sum(ms_per_step) / peak: recomputable from here
+                "executed_gflop_per_step": round(ex / steps / 1e9, 3),
+                "algorithmic_gflop_per_step": round(al / steps / 1e9, 3),
                 "executed_tflops": round(ex / (ms * 1e-3) / 1e12, 2),
                 "executed_frac": round(ex / (ms * 1e-3) / 1e12 / peak, 4),
                 "algorithmic_tflops": round(al / (ms * 1e-3) / 1e12, 2),
@@ -199,6 +202,8 @@ def conv_roofline(prof, args, H, W, modules, measured=None, measured_reason=None
                          "executed_tflops": round(executed[i] / (t * 1e-3) / 1e12, 1), "gflop": round(f / 1e9, 2),
                          "algorithmic_MB": round(prof[i][4] / 1e6, 1),
                          "algorithmic_GBps": round(prof[i][4] / (t * 1e-3) / 1e9, 0)})
+            if len(prof[i]) > 7 and isinstance(prof[i][7], dict):
+                rows[-1].update(prof[i][7])
         with open(args.dump_conv, "w") as fh:
             json.dump(rows, fh, indent=0)
     # HBM traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, summarised per kernel by
@@ -254,6 +259,17 @@ def conv_roofline(prof, args, H, W, modules, measured=None, measured_reason=None
                 traffic_src = "profiles/" + TRAFFIC_PROFILE
         except (OSError, ValueError, KeyError):
             traffic = None
+    # the heads' GEMMs over [image][RoI slot] rows: rows of the tiles that ran / all slots / valid rows (ops.rows_executed)
+    rows_rows = [r[7] for r in prof if len(r) > 7 and isinstance(r[7], dict) and "rows_slots" in r[7]]
+    heads_rows = None
+    if rows_rows:
+        per = max(1, len(rows_rows) // steps)
+        heads_rows = {"launches_per_step": per,
+                      "rows_slots": rows_rows[0]["rows_slots"], "rows_executed": rows_rows[0]["rows_executed"],
+                      "rows_valid": rows_rows[0]["rows_valid"],
+                      "note": "first row-group GEMM of a step (the classifier's K = 12544 layer); FLOPs / bytes of these launches are "
+                              "booked on rows_executed (MFMA work that ran: whole 128-row tiles with at least one valid RoI), their "
+                              "algorithmic FLOPs on rows_valid; tiles of empty RoI slots return at once (csrc/conv.hip)"}
     co = []
     for t in dom_tags:
         row = dict(family=t, kernel=" + ".join(members_of(t)), **by_tag[t])
@@ -285,6 +301,7 @@ def conv_roofline(prof, args, H, W, modules, measured=None, measured_reason=None
                              f" ({measured_reason}); null unless the profile's mode flags, launch count and csrc/ source hash "
                              "equal this run's"),
             "algorithmic_bytes": dom["algorithmic_bytes_per_step"],
+            "heads_rows": heads_rows,
             "conv_path": dict(whole, conv_gflop_per_image=round(sum(r[2] for r in prof) / steps / args.batch / 1e9, 1)),
             "by_kernel": by_tag}
 
@@ -473,6 +490,8 @@ def main():
                     help="N=1 only: measure roofline.traffic in this run (two rocprofv3 --pmc child passes of tools/profile_step.py, "
                          "about a minute); 0 = report the committed profile's figure instead")
     ap.add_argument("--traffic-timeout", type=int, default=120, help="seconds allowed per counter pass")
+    ap.add_argument("--alt-injected", type=int, default=1,
+                    help="also time the headline step with SURVEY 8(d)'s injected proposals (every RoI slot valid), N=1 only")
     ap.add_argument("--alt-config5", type=int, default=1,
                     help="also time BASELINE configs[4]'s geometry (R101-FPN, 832x1344, fp16 MFMA path) on this GPU, N=1 only")
     args = ap.parse_args()
@@ -524,7 +543,8 @@ def main():
 
     def step():
         det = net.predict(images, windows, with_masks=True)
-        return mdist.all_gather_detections(det.packed(), det.counts, global_batch=world * args.batch), det
+        return mdist.all_gather_detections(det.packed(), det.counts, global_batch=world * args.batch,
+                                           max_detections=cfg.detection_max_instances), det
 
     runner = step
     if args.graph:
@@ -543,7 +563,7 @@ def main():
     # Three timed repetitions of EXACTLY --steps steps, each bracketed by a barrier + synchronize on both sides and reduced
     # with MAX over ranks; `value` is the MEDIAN repetition (run-to-run spread of one repetition on this pool: ~4 %), the
     # fastest and slowest are reported beside it.
-    reps = []
+    reps, own_max, own_min = [], [], []
     for _ in range(max(1, args.reps)):
         mdist.barrier()
         torch.cuda.synchronize()
@@ -551,8 +571,11 @@ def main():
         for _ in range(args.steps):
             out = runner()
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0          # this rank's K steps, before it waits for the others
         mdist.barrier()
         reps.append(mdist.max_over_ranks(time.perf_counter() - t0, dev))
+        own_max.append(mdist.max_over_ranks(own, dev))
+        own_min.append(-mdist.max_over_ranks(-own, dev))   # a straggler shows as max >> min the first time SCALE runs
     elapsed = sorted(reps)[len(reps) // 2]
     (gathered, gcounts), det = out
     n_images = world * args.batch * args.steps
@@ -608,7 +631,8 @@ def main():
 
         def step_alt():
             d = net_alt.predict(images, windows, with_masks=True)
-            return mdist.all_gather_detections(d.packed(), d.counts, global_batch=world * args.batch)
+            return mdist.all_gather_detections(d.packed(), d.counts, global_batch=world * args.batch,
+                                               max_detections=cfg.detection_max_instances)
         for _ in range(args.warmup):
             step_alt()
         mdist.barrier()
@@ -639,14 +663,20 @@ def main():
     # ---- BASELINE configs[4] geometry on this GPU (ResNet-101-FPN, 832 x 1344 = 1333 x 800 padded to /64, plain-fp16 MFMA
     # path with fp16 activations in HBM), after the headline and never part of `value` -------------------------------
     alt_configs = None
+    if rank == 0 and world == 1 and args.alt_injected:
+        try:
+            alt_configs = [injected_entry(net, images, windows, args, cfg, dev, ops)]
+        except Exception as e:
+            log(f"[bench] ERROR: injected-proposals entry failed: {e!r}")
+            alt_configs = [{"config": "configs[2] with injected proposals", "error": repr(e)}]
     if rank == 0 and world == 1 and args.alt_config5:
         del net
         torch.cuda.empty_cache()
         try:
-            alt_configs = [config5_entry(dev, args, ops, modules, InferenceConfig, MaskRCNNInference)]
+            alt_configs = (alt_configs or []) + [config5_entry(dev, args, ops, modules, InferenceConfig, MaskRCNNInference)]
         except Exception as e:
             log(f"[bench] ERROR: alt_configs failed: {e!r}")
-            alt_configs = [{"config": "configs[4] geometry", "error": repr(e)}]
+            alt_configs = (alt_configs or []) + [{"config": "configs[4] geometry", "error": repr(e)}]
 
     cpu, cpu_failed = None, False
     if rank == 0 and world == 1 and args.cpu_images > 0:
@@ -670,6 +700,11 @@ def main():
             "timed_repetitions": {"count": len(reps), "steps_each": args.steps, "value_is": "median",
                                   "images_per_s": [round(n_images / t, 2) for t in reps],
                                   "min": round(n_images / max(reps), 2), "max": round(n_images / min(reps), 2)},
+            "per_rank_ms_per_step": {"max": [round(t / args.steps * 1e3, 3) for t in own_max],
+                                     "min": [round(t / args.steps * 1e3, 3) for t in own_min],
+                                     "note": "slowest / fastest rank's OWN K steps (clock stopped after its synchronize, before the "
+                                             "closing barrier) per timed repetition; `value` / `ms_per_step` are barrier to barrier, "
+                                             "MAX over ranks"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dist_backend": dist_backend, "rccl_ranks": rccl_ranks,
             "dtype": {"f32": "f32", "f16x3": "f16x3 split operands, f32 accumulate",
@@ -701,6 +736,58 @@ def main():
         torch.distributed.destroy_process_group()
     if cpu_failed:
         raise SystemExit(3)
+
+
+def injected_proposals(batch, count, seed=1234):
+    """SURVEY.md 8(d) "synthetic input - proposals": `count` seeded proposals per image — centres U(0,1)^2, h and w log-uniform in
+    [0.02, 0.6], clipped to [0,1] — for throughput runs with random weights. → (rois [batch,count,4] normalised (y1,x1,y2,x2),
+    counts int32 [batch] == count)."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    c = torch.rand(batch, count, 2, generator=g)
+    hw = torch.exp(torch.rand(batch, count, 2, generator=g) * (math.log(0.6) - math.log(0.02)) + math.log(0.02))
+    rois = torch.cat([c - hw / 2, c + hw / 2], -1).clamp(0.0, 1.0).contiguous()
+    return rois, torch.full((batch,), count, dtype=torch.int32)
+
+
+def injected_entry(net, images, windows, args, cfg, dev, ops):
+    """The headline step with every RoI slot live: the metric says "1000 proposals/img", the RPN of random weights leaves
+    ~790 after NMS (config.mean_valid_proposals), and the heads skip the empty slots as the reference does (model.py:1366-1374).
+    Here the proposal stage still runs, then the heads get SURVEY 8(d)'s injected proposals: proposal_count valid RoIs per image.
+    Same timing discipline as the headline; never `value`."""
+    p = min(cfg.proposal_count, cfg.pre_nms_limit)
+    rois, counts = injected_proposals(images.size(0), p)
+    ro = (rois.to(dev), counts.to(dev))
+    for _ in range(args.warmup):
+        net.predict(images, windows, with_masks=True, rois_override=ro)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        det = net.predict(images, windows, with_masks=True, rois_override=ro)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {"config": f"configs[2] per GPU with {p} VALID proposals per image injected after the proposal stage (SURVEY 8d: seed 1234, "
+                     "centres U(0,1)^2, h / w log-uniform in [0.02, 0.6]); the proposal stage itself still runs",
+           "precision": args.precision, "value": round(images.size(0) * args.steps / el, 2), "unit": "images/s",
+           "ms_per_step": round(el / args.steps * 1e3, 3), "steps": args.steps,
+           "mean_detections": round(float(det.counts.float().mean().item()), 1)}
+    if args.roofline_steps > 0:
+        ops.CONV_PROFILE = []
+        for _ in range(args.roofline_steps):
+            net.predict(images, windows, with_masks=True, rois_override=ro)
+        torch.cuda.synchronize()
+        prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+        rows = [r for r in prof if len(r) > 7]
+        peak = F32_MFMA_PEAK_TFLOPS if args.precision == "f32" else F16_MFMA_PEAK_TFLOPS
+        if rows:
+            per = len(rows) // args.roofline_steps
+            fc1 = [rows[i * per] for i in range(args.roofline_steps)]
+            ms = sum(r[0].elapsed_time(r[1]) for r in fc1) / len(fc1)
+            out["heads_rows"] = {k: fc1[0][7][k] for k in ("rows_slots", "rows_executed", "rows_valid")}
+            out["classifier_fc1"] = {"ms": round(ms, 4), "executed_tflops": round(fc1[0][6] / (ms * 1e-3) / 1e12, 1),
+                                     "executed_frac": round(fc1[0][6] / (ms * 1e-3) / 1e12 / peak, 4)}
+        out["conv_ms_per_step"] = round(sum(r[0].elapsed_time(r[1]) for r in prof) / args.roofline_steps, 3)
+    return out
 
 
 def config5_entry(dev, args, ops, modules, InferenceConfig, MaskRCNNInference):

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 14
+#define MRCNN_ABI_VERSION 15
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -381,6 +381,9 @@ int mrcnn_conv_bn_act_rows_f32(const float* x, int32_t batch, int32_t height, in
                                int32_t pad_bottom, int32_t pad_right, const float* scale, const float* shift,
                                int32_t activation, float* y, const int32_t* row_counts, int32_t rows_per_group,
                                mrcnn_stream_t stream);
+/* Rows of the M tile mrcnn_conv_bn_act_rows_f32 gives a layer with `cout` output channels (the skip rule's granularity: a caller
+ * that accounts for the work that ran — bench.py's roofline pass — counts tiles of this many rows). */
+int32_t mrcnn_conv_rows_tile_m(int32_t cout);
 int mrcnn_nhwc_to_kblocked_f32(const float* x, int64_t pixels, int32_t channels, float* y, mrcnn_stream_t stream);
 size_t mrcnn_conv3x3_winograd_workspace_bytes(int32_t batch, int32_t height, int32_t width, int32_t cin);
 int mrcnn_conv3x3_winograd_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t cin,
@@ -405,6 +408,13 @@ int mrcnn_stem_conv7x7_s2_nchw_f32(const float* x_nchw, int32_t batch, int32_t h
 int mrcnn_stem_conv7x7_s2_nchw_f16out(const float* x_nchw, int32_t batch, int32_t height, int32_t width, const float* w,
                                       const float* scale, const float* shift, int32_t activation, void* y_f16,
                                       mrcnn_stream_t stream);
+/* The exact-fp32 stem with its max-pool in ONE launch (round 5): conv 7x7 s2 p3 + affine + ReLU + SamePad2d(3, 2) + MaxPool2d(3, 2)
+ * (model.py:223-229) on the fp32 MFMA — x_nchw fp32 [batch][3][H][W] (H, W multiples of 4), w fp32 OHWI [64][7][7][4] (channel 3
+ * zero, never multiplied: K = 7 x 21 real values), y fp32 NHWC [batch][ceil(H/4)][ceil(W/4)][64]. Exact fp32 products, fp32
+ * accumulation in the order (ky, kx, c); the max is exact, so the result equals conv-then-pool of the same sums. The
+ * full-resolution 64-channel map never reaches memory. ReLU is part of the contract (zero padding of the pool). */
+int mrcnn_stem_conv7x7_s2_pool_f32(const float* x_nchw, int32_t batch, int32_t height, int32_t width, const float* w,
+                                   const float* scale, const float* shift, float* y, mrcnn_stream_t stream);
 /* The "f16" mode's stem in ONE launch on the fp16 MFMA: conv 7x7 s2 p3 + affine + ReLU + SamePad2d(3, 2) + MaxPool2d(3, 2)
  * (model.py:223-229) — x_nchw fp32 [batch][3][H][W] (H, W multiples of 4), w fp32 OHWI [64][7][7][4] (channel 3 zero; rounded to fp16
  * inside), y_f16 fp16 NHWC [batch][ceil(H/4)][ceil(W/4)][64]. Image and weights are rounded to fp16 once, products accumulate

@@ -38,6 +38,7 @@ _SIGS = {
                                                              c_i32, c_vp, c_vp]),
     "mrcnn_conv_bn_act_rows_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
                                                     c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
+    "mrcnn_conv_rows_tile_m": (c_i32, [c_i32]),
     "mrcnn_roi_align_pyramid_f32": (ctypes.c_int, [ctypes.POINTER(c_vp), ctypes.POINTER(c_i32), ctypes.POINTER(c_i32),
                                                      c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_i32,
                                                      c_vp, c_vp]),
@@ -110,6 +111,7 @@ _SIGS = {
     "mrcnn_nhwc_to_kblocked_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "mrcnn_stem_conv7x7_s2_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "mrcnn_stem_conv7x7_s2_nchw_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "mrcnn_stem_conv7x7_s2_pool_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mrcnn_stem_conv7x7_s2_pool_f16": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mrcnn_stem_conv7x7_s2_nchw_f16out": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "mrcnn_topk_workspace_bytes": (ctypes.c_size_t, [c_i32]),

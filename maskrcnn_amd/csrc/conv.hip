@@ -534,8 +534,9 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
     p.head_n = 0;
     const long long M = p.M;
     const bool generic = (cin % 32) != 0;
+    static const bool no_pw = getenv("MRCNN_CONV_NO_PW") != nullptr;   // tuning aid, read once per process
     const bool pointwise = !generic && kh == 1 && kw == 1 && pad_top == 0 && pad_left == 0 && pad_bottom == 0 &&
-                           pad_right == 0 && getenv("MRCNN_CONV_NO_PW") == nullptr;
+                           pad_right == 0 && !no_pw;
     const int mode = generic ? 1 : pointwise ? 2 : 0;
     hipStream_t s = mrcnn::as_stream(stream);
     static const int force = getenv("MRCNN_CONV_TILE") ? atoi(getenv("MRCNN_CONV_TILE")) : 0;  // tuning aid
@@ -617,6 +618,10 @@ extern "C" int mrcnn_conv_bn_act_rows_f32(const float* x, int32_t batch, int32_t
     return run_conv_f32(x, batch, height, width, cin, w, cout, kh, kw, stride, pad_top, pad_left, pad_bottom, pad_right, scale,
                         shift, nullptr, 1, activation, 0, y, stream, 0, row_counts, rows_per_group);
 }
+
+// BM of the tile run_conv_f32 picks for a row-group call (row_counts != NULL: never the streaming kernel): 256 x 64 tiles for
+// 32 < Cout <= 64, 128-row tiles for every other width (128x32 / 128x64 / 128x96 / 128x128 above).
+extern "C" int32_t mrcnn_conv_rows_tile_m(int32_t cout) { return (cout > 32 && cout <= 64) ? 256 : 128; }
 
 extern "C" int mrcnn_deconv2x2_bias_act_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_t width,
                                                  int32_t cin, const float* w, int32_t cout, const float* bias4,

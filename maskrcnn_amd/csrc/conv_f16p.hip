@@ -552,12 +552,19 @@ extern "C" int mrcnn_conv_f16_pipelined(const void* x_f16, int32_t batch, int32_
     // Rows: pick_rows for 256 columns, 128 otherwise.
     const int cus = mrcnn::device_cu_count() > 0 ? mrcnn::device_cu_count() : 256;
     const bool few_tiles = static_cast<long long>(p.M) * cout < 3LL * cus * 65536;
-    // tuning (in-pipeline sweeps, read per call): MRCNN_F16P_TILE="rows x cols[:Mmin-Mmax]" forces a tile for the automatic
+    // tuning (in-pipeline sweeps, read once per process): MRCNN_F16P_TILE="rows x cols[:Mmin-Mmax]" forces a tile for the automatic
     // choices (optionally only for layers with Mmin <= M <= Mmax), e.g. "192x256:30000-40000"
-    if (const char* e = getenv("MRCNN_F16P_TILE")) {
-        int r = 0, c = 0;
+    struct ForcedTile {   // parsed once per process (a getenv per launch walks the whole environment)
+        int got = 0, r = 0, c = 0;
         long long mlo = 0, mhi = 1LL << 40;
-        const int got = sscanf(e, "%dx%d:%lld-%lld", &r, &c, &mlo, &mhi);
+        ForcedTile() {
+            if (const char* e = getenv("MRCNN_F16P_TILE")) got = sscanf(e, "%dx%d:%lld-%lld", &r, &c, &mlo, &mhi);
+        }
+    };
+    static const ForcedTile forced;
+    if (forced.got >= 2) {
+        const int r = forced.r, c = forced.c, got = forced.got;
+        const long long mlo = forced.mlo, mhi = forced.mhi;
         if (got >= 2 && c > 0 && tile_rows == 0 && tile_cols == 0 && p.M >= mlo && p.M <= mhi && cout % c == 0 &&
             ((c == 256 && (r == 128 || r == 160 || r == 192 || r == 256)) || ((c == 128 || c == 64) && (r == 128 || r == 256)))) {
             tile_rows = r;

@@ -565,10 +565,28 @@ __global__ __launch_bounds__(256) void roi_align_pyramid_nhwc(
 }
 
 // MRCNN_CROP_STAGED=0 keeps every call on the gather kernel (tuning / A-B measurements; results are identical)
-bool crop_staged_enabled() {
-    const char* e = getenv("MRCNN_CROP_STAGED");
-    return !(e && e[0] == '0');
+// The tuning switches of the launch path, read ONCE per process (a getenv walks the whole environment: not per launch).
+struct CropTuning {
+    bool staged;      // MRCNN_CROP_STAGED=0: gather kernel only
+    int cpw;          // MRCNN_CROP_CPW=n: channels per wave (0 = automatic)
+    bool linear_map;  // MRCNN_CROP_MAP=0: plain (box, slab) grid
+    int ring_slots;   // MRCNN_CROP_RING=n: DMA ring size (0 = default)
+    CropTuning() {
+        const char* e = getenv("MRCNN_CROP_STAGED");
+        staged = !(e && e[0] == '0');
+        e = getenv("MRCNN_CROP_CPW");
+        cpw = (e && atoi(e) > 0) ? atoi(e) : 0;
+        e = getenv("MRCNN_CROP_MAP");
+        linear_map = e && atoi(e) == 0;
+        e = getenv("MRCNN_CROP_RING");
+        ring_slots = (e && atoi(e) >= 512 && atoi(e) % 256 == 0 && atoi(e) <= 4096) ? atoi(e) : 0;
+    }
+};
+const CropTuning& crop_tuning() {
+    static const CropTuning t;
+    return t;
 }
+bool crop_staged_enabled() { return crop_tuning().staged; }
 
 }  // namespace
 
@@ -596,18 +614,18 @@ extern "C" int mrcnn_crop_forward_f32(const float* image, int32_t batch, int32_t
         // channels: P2 39 -> 30.5 us, P3 21.9 vs 21.1) —, fewer when that leaves the chip short of waves
         int cpw = static_cast<int64_t>(height) * width >= 256 * 256 ? 8 : 16;
         while (cpw > 2 && static_cast<int64_t>(num_boxes) * ((depth + cpw - 1) / cpw) < 4096) cpw >>= 1;
-        if (const char* e = getenv("MRCNN_CROP_CPW")) cpw = atoi(e) > 0 ? atoi(e) : cpw;
+        if (crop_tuning().cpw) cpw = crop_tuning().cpw;
         const int slabs = (depth + cpw - 1) / cpw;
         // workgroup numbering that keeps a channel slab on one XCD (or on 8 / slabs of them)
         int mode = slabs % 8 == 0 ? 1 : (slabs < 8 && 8 % slabs == 0) ? 2 : 0;
-        if (const char* e = getenv("MRCNN_CROP_MAP")) mode = atoi(e) == 0 ? 0 : mode;
+        if (crop_tuning().linear_map) mode = 0;
         int64_t wgs = mode == 1 ? static_cast<int64_t>(num_boxes) * slabs
                     : mode == 2 ? 8ll * ((num_boxes + 8 / slabs - 1) / (8 / slabs)) : 0;
         if (mode != 0 && wgs > 0x7FFFFFFF) mode = 0;
         if (mode != 0 || slabs <= 65535) {
             const dim3 grid = mode == 0 ? dim3(num_boxes, slabs) : dim3(static_cast<unsigned>(wgs));
             int ring_slots = CS_RING_SLOTS;
-            if (const char* e = getenv("MRCNN_CROP_RING")) ring_slots = atoi(e) >= 512 && atoi(e) % 256 == 0 && atoi(e) <= 4096 ? atoi(e) : ring_slots;
+            if (crop_tuning().ring_slots) ring_slots = crop_tuning().ring_slots;
             // + the dword a (lo, lo+1) pair may read past the last slot; and never less than the in-launch gather fallback
             // (footprints of more than 256 slots) writes from the start of LDS: its sample table + one Tap per crop position
             // (16 x 16 crops: 512 + 8192 B, more than the default ring)

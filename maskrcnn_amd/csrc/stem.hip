@@ -422,6 +422,217 @@ __global__ __launch_bounds__(SP_THREADS, 1) void stem7x7_s2_pool_f16(const StemP
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The exact-fp32 stem WITH its max-pool (round 5): conv 7x7 s2 p3 + BN + ReLU + SamePad2d(3, 2) + MaxPool2d(3, 2)
+// (model.py:223-229) in ONE launch on the fp32 MFMA. The two-launch form writes the 64-channel full-resolution map (537 MB per
+// batch of eight 1024^2 images: the largest tensor of the step) and reads it back in the pool; here it never exists.
+//   K         THREE real channels: per filter row ky the 21 values (kx, c) are contiguous in a patch row stored [py][px][3], so a
+//             conv pixel's A operand for k quad j of row ky is the 8 bytes at patch float 6 ox + 4 j + 2 h — five quads of two MFMAs
+//             (k = 4 j + s | 4 j + 2 + s) + one single MFMA (k = 20 | 21, the latter with a zero weight) = 77 MFMAs per 32 x 32
+//             output block instead of the 98 the four-channel taps of stem7x7_s2_f32 need.
+//   tile      a persistent four-wave workgroup (one wave per SIMD, all 512 registers) owns 7 x 16 POOLED pixels = 15 x 33 conv
+//             outputs (one row / column of overlap with the next tile) = 495 pixels = 16 MFMA row tiles, four per wave, and walks
+//             the two 32-channel halves one after the other (pass ct): 64 accumulator registers, the conv image of a pass goes to
+//             LDS as fp32 [512 pixels][32 channels], zero where the conv pixel lies outside the conv map (the pool's zero padding:
+//             ReLU'd values are >= 0), and every thread pools (pooled pixel, four channels): nine 16-byte LDS reads, 16-byte stores.
+//   LDS       filter [7][6][64][4] 43 KB (once per workgroup) + patch [35][240] floats 33.6 KB (pitch = 16 mod 32 floats: the
+//             8-byte operand reads of 32 consecutive conv pixels, 24 bytes apart, are conflict-free) + conv image 64 KB.
+//   patch     staged from the NCHW fp32 image with 4-byte loads (consecutive lanes = consecutive x of one plane), issued ONE TILE
+//             AHEAD and riding in registers through the current tile's MFMAs and pools (as stem7x7_s2_pool_f16).
+// Requires the ReLU and H, W multiples of 4 (even conv sizes: SamePad2d(3, 2) then pads bottom / right only).
+struct StemPool32Params {
+    const float* x;      // [B][3][H][W]
+    const float* w;      // [64][7][7][4] fp32 OHWI (channel 3 zero)
+    const float* scale;
+    const float* shift;
+    float* y;            // [B][POH][POW][64]
+    int B, H, W, OH, OW, POH, POW, tiles_x, tiles_y, tiles;
+    unsigned x_bytes, y_bytes;
+};
+
+constexpr int S3_PH = 7, S3_PW = 16;                          // pooled pixels per tile
+constexpr int S3_CH = 2 * S3_PH + 1, S3_CW = 2 * S3_PW + 1;   // conv outputs per tile: 15 x 33
+constexpr int S3_NPX = S3_CH * S3_CW;                         // 495
+constexpr int S3_NRT = (S3_NPX + 31) / 32;                    // 16 MFMA row tiles
+constexpr int S3_IH = (S3_CH - 1) * 2 + 7;                    // 35 patch rows
+constexpr int S3_IW = (S3_CW - 1) * 2 + 7;                    // 71 patch pixels per row
+constexpr int S3_PITCH = 240;                                 // floats per patch row (213 used; = 16 mod 32)
+constexpr int S3_KQ = 6;                                      // k quads per filter row (the sixth holds k = 20 only)
+constexpr int S3_W_FLOATS = 7 * S3_KQ * 64 * 4;
+constexpr int S3_P_FLOATS = S3_IH * S3_PITCH;
+constexpr int S3_CP = 32;                                     // floats per conv-image pixel (one 32-channel half)
+constexpr int S3_C_FLOATS = S3_NRT * 32 * S3_CP;
+constexpr size_t STEM_POOL32_LDS = sizeof(float) * (S3_W_FLOATS + S3_P_FLOATS + S3_C_FLOATS);
+static_assert(S3_NRT == 16 && STEM_POOL32_LDS <= 160 * 1024, "tile / LDS");
+static_assert(S3_PITCH % 32 == 16 && S3_PITCH >= 3 * S3_IW + 3, "patch pitch");
+
+__global__ __launch_bounds__(256, 1) void stem7x7_s2_pool_f32(const StemPool32Params p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                   // [7 rows][6 quads][64 channels][4]
+    float* Pl = Wl + S3_W_FLOATS;       // [35][240]: pixel px, channel c at float 3 px + c
+    float* Cl = Pl + S3_P_FLOATS;       // [512 conv pixels][32 channels]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ln = lane & 31, lh = lane >> 5;
+
+    // the filter, once per workgroup: global [n][ky][kx][4] -> LDS [ky][quad][n][e], k = 4 quad + e = 3 kx + c (k >= 21: zero)
+    for (int i = tid; i < S3_W_FLOATS; i += 256) {
+        const int e = i & 3, n = (i >> 2) & 63, slot = i >> 8;
+        const int ky = slot / S3_KQ, j = slot - ky * S3_KQ, k = 4 * j + e;
+        float v = 0.f;
+        if (k < 21) {
+            const int kx = k / 3, c = k - 3 * kx;
+            v = p.w[((n * 7 + ky) * 7 + kx) * 4 + c];
+        }
+        Wl[i] = v;
+    }
+    // the pad floats of every patch row (read by the last quads of the last conv column against zero weights) stay zero
+    for (int i = tid; i < S3_P_FLOATS; i += 256) Pl[i] = 0.f;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+
+    // this wave's row tiles: wave + 4 i. A-operand base (floats) of conv pixel q = 32 rt + ln: patch row 2 oy, float 6 ox + 2 lh;
+    // pixels beyond the 495 of the tile read the last pixel's (discarded)
+    constexpr int NRW = 4;
+    int a_base[NRW];
+#pragma unroll
+    for (int i = 0; i < NRW; ++i) {
+        const int q = min((wave + 4 * i) * 32 + ln, S3_NPX - 1);
+        const int oy = q / S3_CW, ox = q - oy * S3_CW;
+        a_base[i] = (2 * oy) * S3_PITCH + 6 * ox + 2 * lh;
+    }
+    const int b_base = ln * 4 + lh * 2;   // + 32 * 4 for the second channel half
+
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // patch elements of a thread: fixed offsets relative to the tile's origin and fixed places in the LDS patch (computed once)
+    constexpr int NE = 3 * S3_IH * S3_IW;                     // 7455
+    constexpr int NL = (NE + 255) / 256;                      // 30
+    // Only the last of a thread's NL elements can lie beyond the patch (NE = 29 * 256 + 31): it then loads nothing (offset out of
+    // range -> 0) and writes that zero to a pad float of patch row 0 — no per-element branch anywhere.
+    static_assert((NL - 1) * 256 < NE, "every element but a thread's last is inside the patch");
+    const bool tail_ok = tid + 256 * (NL - 1) < NE;
+    int s_rel[NL];        // (c * H + py) * W + px
+    unsigned s_pk[NL];    // LDS float index py * 240 + 3 px + c | py << 14 | px << 20
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int i = tid + 256 * j;
+        const int c = i / (S3_IH * S3_IW), r = i - c * (S3_IH * S3_IW);
+        const int py = r / S3_IW, px = r - py * S3_IW;
+        s_rel[j] = (c * p.H + py) * p.W + px;
+        s_pk[j] = i < NE ? static_cast<unsigned>(py * S3_PITCH + 3 * px + c) | (py << 14) | (px << 20)
+                         : static_cast<unsigned>(S3_PITCH - 1);
+    }
+    unsigned pv[NL];
+    auto load_patch = [&](int tile_) {
+        // the per-element tables are made opaque once per call: everything derived from them (the (py, px) bit fields, LDS
+        // addresses) is otherwise hoisted out of the tile loop — ~150 loop-invariant values that the allocator then spills
+        // (SGPR pairs to VGPR lanes: 1 400 v_readlane / v_writelane in the first build)
+#pragma unroll
+        for (int j = 0; j < NL; ++j) asm volatile("" : "+v"(s_pk[j]), "+v"(s_rel[j]));
+        const bool live = tile_ < p.tiles;
+        const int b_ = tile_ / (p.tiles_y * p.tiles_x), rem_ = tile_ - b_ * p.tiles_y * p.tiles_x;
+        const int ty_ = rem_ / p.tiles_x, tx_ = rem_ - ty_ * p.tiles_x;
+        const int iy0 = ty_ * 2 * S3_PH * 2 - 3, ix0 = tx_ * 2 * S3_PW * 2 - 3;
+        const int base = (b_ * 3 * p.H + iy0) * p.W + ix0;                    // wave-uniform; may be negative at the borders
+        const bool inside = live && iy0 >= 0 && ix0 >= 0 && iy0 + S3_IH <= p.H && ix0 + S3_IW <= p.W;
+        if (inside) {   // a tile whose whole patch lies inside the image needs no per-element test (most tiles)
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                unsigned off = static_cast<unsigned>(base + s_rel[j]) * 4u;
+                if (j == NL - 1) off = tail_ok ? off : OOB;
+                pv[j] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, static_cast<int>(off), 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int iy = iy0 + static_cast<int>((s_pk[j] >> 14) & 63), ix = ix0 + static_cast<int>((s_pk[j] >> 20) & 127);
+                bool ok = static_cast<int>(live) & static_cast<int>(static_cast<unsigned>(iy) < static_cast<unsigned>(p.H)) &
+                          static_cast<int>(static_cast<unsigned>(ix) < static_cast<unsigned>(p.W));
+                if (j == NL - 1) ok = static_cast<int>(ok) & static_cast<int>(tail_ok);
+                const unsigned off = ok ? static_cast<unsigned>(base + s_rel[j]) * 4u : OOB;
+                pv[j] = __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, static_cast<int>(off), 0, 0);
+            }
+        }
+    };
+    load_patch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        const int b = tile / (p.tiles_y * p.tiles_x), rem = tile - b * p.tiles_y * p.tiles_x;
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        lds_barrier();  // the previous tile's patch and conv image are no longer read (first trip: the filter / zero stores)
+#pragma unroll
+        for (int j = 0; j < NL; ++j) Pl[s_pk[j] & 0x3FFF] = __uint_as_float(pv[j]);
+        load_patch(tile + gridDim.x);   // the next tile's, in flight from here
+        lds_barrier();
+
+#pragma unroll 1
+        for (int ct = 0; ct < 2; ++ct) {
+            f32x16 acc[NRW];
+#pragma unroll
+            for (int i = 0; i < NRW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            const float* wl = Wl + b_base + ct * 32 * 4;
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                for (int j = 0; j < S3_KQ; ++j) {
+                    f32x2 a[NRW];
+                    const f32x2 bw = *reinterpret_cast<const f32x2*>(wl + (ky * S3_KQ + j) * 64 * 4);
+#pragma unroll
+                    for (int i = 0; i < NRW; ++i)
+                        a[i] = *reinterpret_cast<const f32x2*>(Pl + a_base[i] + ky * S3_PITCH + 4 * j);
+#pragma unroll
+                    for (int i = 0; i < NRW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, bw.x, acc[i], 0, 0, 0);
+                    if (j < S3_KQ - 1) {
+#pragma unroll
+                        for (int i = 0; i < NRW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, bw.y, acc[i], 0, 0, 0);
+                    }
+                }
+            // conv image of this channel half: affine + ReLU. Row r of a 32-pixel row tile is pixel q0 + d_r, d_r a compile-time
+            // constant: one LDS base + immediates. (Conv pixels beyond the conv map hold whatever the zero-filled patch gives; the
+            // pool below never lets them through.)
+            const float sc = p.scale ? p.scale[ct * 32 + ln] : 1.0f, sh = p.shift ? p.shift[ct * 32 + ln] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < NRW; ++i) {
+                float* crow = Cl + ((wave + 4 * i) * 32 + 4 * lh) * S3_CP + ln;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][r] * sc + sh;
+                    crow[((r & 3) + 8 * (r >> 2)) * S3_CP] = v > 0.f ? v : 0.f;
+                }
+            }
+            lds_barrier();
+            // pool: thread = (pooled pixel, four channels). SamePad2d(3, 2) on an even conv size pads ONE zero row / column at the
+            // bottom / right (model.py:64-87): the only window taps outside the conv map are dy = 2 of the last pooled row and
+            // dx = 2 of the last pooled column — they count as 0 (a multiplication by 0 or 1: the values are finite and >= 0).
+#pragma unroll 1
+            for (int it = tid; it < S3_PH * S3_PW * 8; it += 256) {
+                const int cq = it & 7, pp = it >> 3;
+                const int py = pp >> 4, px = pp & 15;
+                const int gy = ty * S3_PH + py, gx = tx * S3_PW + px;
+                const float fy = 2 * gy + 2 < p.OH ? 1.f : 0.f, fx = 2 * gx + 2 < p.OW ? 1.f : 0.f;
+                float4 m = make_float4(0.f, 0.f, 0.f, 0.f);   // the values are >= 0
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        float4 v = *reinterpret_cast<const float4*>(Cl + ((2 * py + dy) * S3_CW + 2 * px + dx) * S3_CP + 4 * cq);
+                        if (dy == 2 || dx == 2) {
+                            const float f = dy == 2 && dx == 2 ? fy * fx : dy == 2 ? fy : fx;
+                            v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+                        }
+                        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                    }
+                const bool ok = gy < p.POH && gx < p.POW;
+                const unsigned off = ok ? static_cast<unsigned>(((b * p.POH + gy) * p.POW + gx) * 64 + ct * 32 + 4 * cq) * 4u : OOB;
+                const u32x4 o = {__float_as_uint(m.x), __float_as_uint(m.y), __float_as_uint(m.z), __float_as_uint(m.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(o, y_rsrc, static_cast<int>(off), 0, 0);
+            }
+            if (ct == 0) lds_barrier();   // the second half's conv image overwrites the first's
+        }
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -496,4 +707,28 @@ extern "C" int mrcnn_stem_conv7x7_s2_pool_f16(const float* x_nchw, int32_t batch
     const int grid = p.tiles < num_cu ? p.tiles : num_cu;   // persistent: one eight-wave workgroup per CU
     hipLaunchKernelGGL(stem7x7_s2_pool_f16, dim3(grid), dim3(SP_THREADS), STEM_POOL_LDS, mrcnn::as_stream(stream), p);
     return mrcnn::check_launch("stem7x7_s2_pool_f16");
+}
+
+extern "C" int mrcnn_stem_conv7x7_s2_pool_f32(const float* x_nchw, int32_t batch, int32_t height, int32_t width, const float* w,
+                                              const float* scale, const float* shift, float* y, mrcnn_stream_t stream) {
+    MRCNN_REQUIRE(x_nchw && w && y, "stem_pool_f32: null pointer");
+    // (an odd conv size would give SamePad2d(3, 2) a top / left component — model.py:64-87 — and shift the pooling windows)
+    MRCNN_REQUIRE(batch >= 1 && height >= 4 && width >= 4 && height % 4 == 0 && width % 4 == 0,
+                  "stem_pool_f32: B=%d H=%d W=%d (multiples of 4 required)", batch, height, width);
+    MRCNN_REQUIRE(1LL * batch * height * width * 3 < (1LL << 30), "stem_pool_f32: tensor too large (32-bit buffer byte offsets)");
+    StemPool32Params p;
+    p.x = x_nchw; p.w = w; p.scale = scale; p.shift = shift; p.y = y;
+    p.B = batch; p.H = height; p.W = width; p.OH = height / 2; p.OW = width / 2;
+    p.POH = (p.OH + 1) / 2; p.POW = (p.OW + 1) / 2;   // SamePad2d(3, 2) + MaxPool2d(3, 2): ceil(n / 2) (model.py:64-87,227-228)
+    p.tiles_x = (p.POW + S3_PW - 1) / S3_PW;
+    p.tiles_y = (p.POH + S3_PH - 1) / S3_PH;
+    p.tiles = batch * p.tiles_x * p.tiles_y;
+    p.x_bytes = static_cast<unsigned>(12LL * batch * height * width);
+    p.y_bytes = static_cast<unsigned>(256LL * batch * p.POH * p.POW);
+    if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(stem7x7_s2_pool_f32), STEM_POOL32_LDS, "stem_pool_f32")) return rc;
+    const int num_cu = mrcnn::device_cu_count();
+    if (num_cu <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "stem_pool_f32: cannot query the device");
+    const int grid = p.tiles < num_cu ? p.tiles : num_cu;   // persistent: one four-wave workgroup per CU
+    hipLaunchKernelGGL(stem7x7_s2_pool_f32, dim3(grid), dim3(256), STEM_POOL32_LDS, mrcnn::as_stream(stream), p);
+    return mrcnn::check_launch("stem7x7_s2_pool_f32");
 }

@@ -97,7 +97,10 @@ def all_gather_detections(packed: torch.Tensor, counts: torch.Tensor, global_bat
     shard_range(G, r, world) images, which differ by one image when G % world != 0 — all_gather_into_tensor needs
     identical shapes, so every rank pads its block to ceil(G / world) images (count 0) and the padding is stripped
     after the gather. Without `global_batch` every rank must hold the same B_local (G = world * B_local).
-    `max_detections` (D) is what every rank EXPECTS; without it the first healthy call fixes it for the process."""
+    `max_detections` (D = cfg.detection_max_instances) is what every rank EXPECTS — pass it: it is what lets a rank whose
+    block is malformed still send a (poisoned) block of the right shape instead of hanging its peers. Without it the block's
+    own D is taken at face value, and a malformed block raises before the collective. Nothing is remembered between calls:
+    two pipelines with different D in one process are two independent callers."""
     if not _collectives_on():
         return packed, counts
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -106,13 +109,13 @@ def all_gather_detections(packed: torch.Tensor, counts: torch.Tensor, global_bat
     # ranks would sit in all_gather_into_tensor until the backend's timeout — nor send a block of another shape. It sends a
     # poisoned block of the EXPECTED shape (count rows = -1) and EVERY rank raises after the gather.
     well_formed = packed.dim() == 3 and packed.size(2) == 6 and counts.dim() == 1
-    d_exp = max_detections if max_detections is not None else _EXPECTED_D.get("d")
+    d_exp = max_detections
     if d_exp is None:
         if not well_formed:
-            raise RuntimeError("all_gather_detections: first call with a malformed block and no max_detections: the "
-                               "expected shape is unknown (pass max_detections=)")
+            raise RuntimeError("all_gather_detections: a malformed block and no max_detections: the expected shape is "
+                               "unknown (pass max_detections=cfg.detection_max_instances)")
         d_exp = packed.size(1)
-    b = packed.size(0) if packed.dim() >= 1 else -1
+    b = packed.size(0) if packed.dim() >= 1 else 0   # never negative: it shapes the (possibly poisoned) block below
     if global_batch is None:
         # every rank claims its own b: nothing to check it against, b IS the expectation
         sizes = [b] * world
@@ -123,7 +126,6 @@ def all_gather_detections(packed: torch.Tensor, counts: torch.Tensor, global_bat
     d = d_exp
     block = torch.zeros(b_max, d + 1, 6, dtype=torch.float32, device=counts.device if not well_formed else packed.device)
     if ok:
-        _EXPECTED_D.setdefault("d", d)
         block[:b, :d] = packed
         block[:b, d, 0] = counts.to(block.dtype)
     else:
@@ -147,9 +149,13 @@ def all_gather_detections(packed: torch.Tensor, counts: torch.Tensor, global_bat
             raise RuntimeError(f"all_gather_detections: rank(s) {bad} hold a shard that disagrees with "
                                f"shard_range({global_batch}, r, {world})")
         _VALIDATED.add(layout)
+        # the device-side flag of the later steps is allocated HERE — this step reads the device (so it is never inside a
+        # hipGraph capture), and a flag created during a capture would live in the capture's private pool
+        if str(out.device) not in _ERR_FLAG:
+            _ERR_FLAG[str(out.device)] = torch.zeros(world, dtype=torch.int32, device=out.device)
     else:
-        flag = _ERR_FLAG.get(str(out.device))
-        if flag is None:
+        flag = _ERR_FLAG[str(out.device)]
+        if flag.numel() != world:   # another process group since: a fresh flag (outside any capture: sizes only change at set-up)
             flag = _ERR_FLAG[str(out.device)] = torch.zeros(world, dtype=torch.int32, device=out.device)
         flag += bad_rows.view(world, b_max).any(dim=1).to(torch.int32)   # per rank; no host read
     if min(sizes) != b_max:  # strip the padding rows (index list cached per layout: no per-step host-to-device copy)
@@ -169,7 +175,6 @@ def check_gather_errors() -> None:
                                f"({[hits[r] for r in bad]} step(s)) since the last check")
 
 
-_EXPECTED_D: dict = {}
 _ERR_FLAG: dict = {}
 _VALIDATED: set = set()
 _STRIP_CACHE: dict = {}

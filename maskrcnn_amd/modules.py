@@ -213,6 +213,9 @@ def winograd4_tiles_per_image(h: int, w: int) -> int:
 # MRCNN_SKIP_EMPTY_ROI_TILES=0 computes every slot (same valid rows bit for bit; A/B measurements).
 SKIP_EMPTY_ROI_TILES = os.environ.get("MRCNN_SKIP_EMPTY_ROI_TILES", "1") != "0"
 F16_ACT = os.environ.get("MRCNN_F16_ACT", "1") != "0"
+# f32 mode: the stem's conv + BN + ReLU + SamePad + max-pool as ONE exact-fp32 launch on three real channels (csrc/stem.hip:
+# stem7x7_s2_pool_f32, round 5) when H and W are multiples of 4; MRCNN_STEM_POOL=0 keeps the stem kernel + the separate max-pool.
+STEM_POOL = os.environ.get("MRCNN_STEM_POOL", "1") != "0"
 # The large stride-1 layers of the "f16" mode (fp16 NHWC input, Cin % 64 == 0, Cout % 256 == 0) run the pipelined kernel
 # (csrc/conv_f16p.hip: eight waves, LDS-DMA in flight across barriers — 1.4-1.5x the 128x128-tile kernel on the 3x3 layers);
 # MRCNN_F16_PIPELINED=0 keeps them on conv_igemm_f16.
@@ -471,8 +474,13 @@ class FusedBackbone:
         pooled = False
         if (st.w.precision == "f32" and st.w.shape == (64, 7, 7, 4) and image_nchw.size(2) % 2 == 0
                 and image_nchw.size(3) % 2 == 0 and STEM_KERNEL):
-            # dedicated kernel (csrc/stem.hip), reading the NCHW image itself: no layout pass over the image
-            x = ops.stem_conv(image_nchw.contiguous(), st.w.w, st.scale, st.shift, True, st.algo_cin, nchw=True)
+            if STEM_POOL and image_nchw.size(2) % 4 == 0 and image_nchw.size(3) % 4 == 0:
+                # round 5: conv + BN + ReLU + max-pool in one launch: the 64-channel full-resolution map never reaches memory
+                x = ops.stem_pool_f32(image_nchw.contiguous(), st.w.w, st.scale, st.shift, st.algo_cin)
+                pooled = True
+            else:
+                # dedicated kernel (csrc/stem.hip), reading the NCHW image itself: no layout pass over the image
+                x = ops.stem_conv(image_nchw.contiguous(), st.w.w, st.scale, st.shift, True, st.algo_cin, nchw=True)
         elif (self.stem_w32 is not None and STEM_KERNEL and F16_PIPELINED and image_nchw.size(2) % 2 == 0
               and image_nchw.size(3) % 2 == 0):
             if F16_STEM_POOL and image_nchw.size(2) % 4 == 0 and image_nchw.size(3) % 4 == 0:
@@ -615,12 +623,18 @@ class FusedClassifier:
         """"f16" mode: RoIAlign may hand over fp16 crops (the rounding conv1 would apply to fp32 ones while staging them)."""
         return self.w1.precision == "f16" and F16_ACT and F16_PIPELINED
 
+    def honours_row_counts(self) -> bool:
+        """Do the three GEMMs skip row tiles of empty RoI slots (mrcnn_conv_bn_act_rows_f32)? Only the exact-fp32 kernel has the
+        row-group form; a caller must not hand the other modes crops whose empty slots were left unwritten."""
+        return self.w1.precision == "f32" and self.conv2.w.precision == "f32" and self.w_fc.precision == "f32"
+
     def __call__(self, pooled, roi_counts=None, rois_per_image=0):
         """roi_counts int32 [images] + rois_per_image: only the first roi_counts[i] of image i's slots hold a RoI (the reference
         runs the head on exactly those, model.py:1366-1374,1174); row tiles without one are skipped by the three GEMMs, and the
         rows of empty slots hold unspecified values (the detection stage never reads them: validity is slot < roi_counts)."""
         r = pooled.size(0)
-        rc = dict(row_counts=roi_counts, rows_per_group=rois_per_image) if (roi_counts is not None and SKIP_EMPTY_ROI_TILES) else {}
+        rc = dict(row_counts=roi_counts, rows_per_group=rois_per_image) \
+            if (roi_counts is not None and SKIP_EMPTY_ROI_TILES and self.honours_row_counts()) else {}
         x = self.w1.conv(pooled.view(r, 1, 1, -1), self.s1, self.t1, relu=True, out_f16=self.conv2.out_f16, **rc)
         x = self.conv2(x, **rc)
         y = self.w_fc.conv(x, None, self.b_fc, **rc).view(r, -1)

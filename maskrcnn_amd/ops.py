@@ -8,8 +8,11 @@ Signatures mirror the reference's pybind module c++ext/maskrcnn/csrc/vision.cpp:
 plus functional / batched forms used by the sync-free pipeline.
 
 PyTorch is plumbing here: device memory, the current HIP stream, and the dispatcher. All arithmetic
-happens in libmaskrcnn_hip.so. CPU tensors are rejected (mirror of the reference's "Not compiled with
-GPU support", nms.h:24): this build is GPU-only by design.
+happens in libmaskrcnn_hip.so. The three reference entry points also take CPU tensors, as the reference's dispatch
+does (nms.h:15-30, crop.h:14-53: CPU in -> CPU out): they are staged host -> device, run the SAME HIP kernels and
+come back as CPU tensors — there is no CPU arithmetic in this build, and without a visible GPU such a call raises
+(the mirror of the reference's "Not compiled with GPU support", nms.h:24). The ops without a reference counterpart
+(conv_bn_act, bottleneck_forward, the batched forms) take GPU tensors only.
 """
 from __future__ import annotations
 
@@ -62,6 +65,15 @@ def _on_device(fn):
         with torch.cuda.device(dev):
             return fn(*args, **kwargs)
     return guarded
+
+
+def _staging_device() -> torch.device:
+    """Where a CPU-tensor call of a reference entry point is computed: the current GPU. No GPU → the call fails loudly; there
+    is no CPU kernel to fall back to."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("maskrcnn_amd: Not compiled with CPU support — CPU tensors are staged to the GPU and run the HIP "
+                           "kernels, and no GPU is visible")
+    return torch.device("cuda", torch.cuda.current_device())
 
 
 def _need_gpu(*tensors):
@@ -141,14 +153,26 @@ def _nms(dets: torch.Tensor, threshold: float) -> torch.Tensor:
 
 _LIB.define("nms(Tensor dets, float threshold) -> Tensor")
 _LIB.impl("nms", _nms, "CUDA")
-_LIB.impl("nms", lambda dets, threshold: _need_gpu(dets), "CPU")
+
+
+def _nms_cpu(dets: torch.Tensor, threshold: float) -> torch.Tensor:
+    """CPU tensor in → CPU int64 out (nms.h:26-29 → nms_cpu, cpu/nms_cpu.cpp:69: ascending input indices): H2D, the HIP kernel,
+    D2H. float32 / float64 in their own arithmetic like the reference's AT_DISPATCH_FLOATING_TYPES (cpu/nms_cpu.cpp:73-79)."""
+    dev = _staging_device()
+    if dets.numel() == 0:   # nms_cpu.cpp:16-18
+        return torch.empty(0, dtype=torch.int64)
+    return _nms(dets.to(dev), threshold).cpu()
+
+
+_LIB.impl("nms", _nms_cpu, "CPU")
 
 
 # --------------------------------------------------------------------------------------------------
 # crop_and_resize
 # --------------------------------------------------------------------------------------------------
-def _check_crop_inputs(image, boxes, box_index):
-    _need_gpu(image, boxes, box_index)
+def _check_crop_inputs(image, boxes, box_index, gpu: bool = True):
+    if gpu:
+        _need_gpu(image, boxes, box_index)
     if image.dtype != torch.float32 or boxes.dtype != torch.float32:
         raise RuntimeError("crop: expected scalar type Float for image and boxes")
     if box_index.dtype != torch.int32:
@@ -210,14 +234,49 @@ def _crop_backward(grads, boxes, box_index, grads_image):
 _LIB.define("crop_forward(Tensor image, Tensor boxes, Tensor box_index, float extrapolation_value, "
             "int crop_height, int crop_width, Tensor(a!) crops) -> ()")
 _LIB.impl("crop_forward", _crop_forward, "CUDA")
-_LIB.impl("crop_forward", lambda image, *a: _need_gpu(image), "CPU")
+
+
+def _crop_forward_cpu(image, boxes, box_index, extrapolation_value, crop_height, crop_width, crops):
+    """crop.h:24-33 with CPU tensors: staged through the GPU; `crops` (a CPU float tensor of any shape) is resized in place
+    to [N,C,h,w] and overwritten, as crop_cpu.cpp:141-143 does. (A box_index outside [0, B) makes the reference exit(-1),
+    crop_cpu.cpp:47-50; here that box's crop is extrapolation_value, as on the GPU path.)"""
+    _check_crop_inputs(image, boxes, box_index, gpu=False)
+    if crops.dtype != torch.float32:
+        raise RuntimeError("crop_forward: expected scalar type Float for crops")
+    dev = _staging_device()
+    out = crop(image.to(dev), boxes.to(dev), box_index.to(dev), extrapolation_value, crop_height, crop_width)
+    crops.resize_(out.shape)
+    crops.copy_(out)
+
+
+_LIB.impl("crop_forward", _crop_forward_cpu, "CPU")
 _LIB.define("crop_backward(Tensor grads, Tensor boxes, Tensor box_index, Tensor(a!) grads_image) -> ()")
 _LIB.impl("crop_backward", _crop_backward, "CUDA")
-_LIB.impl("crop_backward", lambda grads, *a: _need_gpu(grads), "CPU")
+
+
+def _crop_backward_cpu(grads, boxes, box_index, grads_image):
+    """crop.h:43-52 with CPU tensors: grads_image [B,C,H,W] is zeroed and accumulated on the GPU, then copied back in place."""
+    dev = _staging_device()
+    if not grads_image.is_contiguous() or grads_image.dim() != 4:
+        raise RuntimeError("crop_backward: grads_image must be a contiguous [B,C,H,W] tensor")
+    gi = torch.empty(grads_image.shape, dtype=grads_image.dtype, device=dev)
+    _crop_backward(grads.to(dev), boxes.to(dev), box_index.to(dev), gi)
+    grads_image.copy_(gi)
+
+
+_LIB.impl("crop_backward", _crop_backward_cpu, "CPU")
 _LIB.define("crop(Tensor image, Tensor boxes, Tensor box_index, float extrapolation_value, "
             "int crop_height, int crop_width) -> Tensor")
 _LIB.impl("crop", crop, "CUDA")
-_LIB.impl("crop", lambda image, *a: _need_gpu(image), "CPU")
+
+
+def _crop_cpu(image, boxes, box_index, extrapolation_value, crop_height, crop_width):
+    _check_crop_inputs(image, boxes, box_index, gpu=False)
+    dev = _staging_device()
+    return crop(image.to(dev), boxes.to(dev), box_index.to(dev), extrapolation_value, crop_height, crop_width).cpu()
+
+
+_LIB.impl("crop", _crop_cpu, "CPU")
 
 
 @_on_device
@@ -230,7 +289,10 @@ def roi_align_pyramid(feature_maps, rois: torch.Tensor, pool: int, image_area: f
     feature_maps: [P2,P3,P4,P5], each a contiguous fp32 [B, H_l, W_l, C] (NHWC) tensor.
     rois [R,4] normalised. Returns [R, pool, pool, C] (NHWC) in roi order (+ int32 levels); out_kblocked=True returns
     [C/8, R, pool, pool, 8] instead (the layout conv3x3_winograd reads: no layout pass before the mask head); out_f16=True
-    returns the NHWC result rounded to fp16 (the "f16" mode's heads: what their first conv would round the values to)."""
+    returns the NHWC result rounded to fp16 (the "f16" mode's heads: what their first conv would round the values to).
+    roi_counts int32 [images] (with rois_per_image): only the first roi_counts[i] slots of image i hold a RoI; the others are
+    skipped and their rows of the output (and of `levels`) are left UNWRITTEN — unspecified values, possibly NaN bit patterns:
+    hand such a tensor only to consumers that skip the same rows (conv_bn_act(row_counts=...))."""
     assert len(feature_maps) == 4
     _need_gpu(rois, roi_batch, *feature_maps)
     rois = rois.contiguous()
@@ -334,9 +396,35 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | None,
     if prof is not None:
         e1.record()
         m, k = b * oh * ow, kh * kw * (algo_cin or cin)  # algorithmic: 2*MACs of the un-padded conv
+        if row_counts is not None:
+            # Book what RAN: the kernel returns early for M tiles without a valid row (conv.hip), so the MFMA work is the
+            # executed tiles' rows and the problem the reference poses is the valid rows only (model.py:1366-1374). The host
+            # read of row_counts synchronises — profiling pass only, after the end event is on the stream.
+            bm = int(lib.mrcnn_conv_rows_tile_m(cout))
+            rows_exec, rows_valid = rows_executed(row_counts.tolist(), int(rows_per_group), m, bm)
+            kk = kh * kw * cin
+            nbytes = 4 * (rows_exec * (kk + cout) + w.numel())
+            prof.append((e0, e1, 2.0 * rows_valid * k * cout, (rows_valid, cout, k), nbytes, "direct",
+                         2.0 * rows_exec * k * cout, {"rows_slots": m, "rows_executed": rows_exec, "rows_valid": rows_valid}))
+            return out
         nbytes = 4 * (x.numel() + w.numel() + out.numel() + (residual.numel() if residual is not None else 0))
         prof.append((e0, e1, 2.0 * m * k * cout, (m, cout, k), nbytes, "direct"))
     return out
+
+
+def rows_executed(counts, rows_per_group: int, m: int, bm: int):
+    """Host restatement of conv_common.hpp::tile_has_rows for the profiling pass: output rows come in groups of rows_per_group
+    slots of which the first counts[g] are valid; an M tile [t*bm, (t+1)*bm) runs iff it holds a valid row. → (rows of the
+    tiles that run — what the MFMA pipe computes, capped at m —, valid rows — the problem the reference poses)."""
+    assert rows_per_group >= 1 and len(counts) * rows_per_group == m and bm >= 1
+    rows = 0
+    for t in range(-(-m // bm)):
+        m0, last = t * bm, min((t + 1) * bm, m) - 1
+        g0, g1 = m0 // rows_per_group, last // rows_per_group
+        live = (m0 - g0 * rows_per_group) < counts[g0] or any(counts[g] > 0 for g in range(g0 + 1, g1 + 1))
+        if live:
+            rows += last + 1 - m0
+    return rows, int(sum(min(max(int(c), 0), rows_per_group) for c in counts))
 
 
 def split_f16(w: torch.Tensor):
@@ -1286,4 +1374,30 @@ def stem_pool_f16(x: torch.Tensor, w: torch.Tensor, scale, shift, algo_cin: int 
         e1.record()
         m, k = b * (h // 2) * (wd // 2), 49 * (algo_cin or 4)
         prof.append((e0, e1, 2.0 * m * 64 * k, (m, 64, k), 4.0 * (x.numel() + w.numel()) + y.numel() * 2, "stem"))
+    return y
+
+
+@_on_device
+def stem_pool_f32(x: torch.Tensor, w: torch.Tensor, scale, shift, algo_cin: int | None = None) -> torch.Tensor:
+    """The exact-fp32 stem + max-pool in one launch (model.py:223-229; csrc/stem.hip: stem7x7_s2_pool_f32): x the molded NCHW
+    image [B,3,H,W] fp32 (H, W multiples of 4), w OHWI [64,7,7,4] fp32 (channel 3 zero) → fp32 NHWC [B, H/4, W/4, 64]."""
+    _need_gpu(x, w, scale, shift)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.size(1) == 3
+    assert w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (64, 7, 7, 4)
+    b, _, h, wd = x.shape
+    assert h % 4 == 0 and wd % 4 == 0
+    y = torch.empty(b, h // 4, wd // 4, 64, dtype=torch.float32, device=x.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mrcnn_stem_conv7x7_s2_pool_f32(x.data_ptr(), b, h, wd, w.data_ptr(), _ptr(scale), _ptr(shift), y.data_ptr(), _stream()))
+    if prof is not None:
+        e1.record()
+        m, k = b * (h // 2) * (wd // 2), 49 * (algo_cin or 3)
+        # executed: 77 MFMAs of K = 2 per 32 x 32 block (k = 22 per filter row) on 15 x 33 conv pixels per 7 x 16 pooled ones,
+        # padded to 512 GEMM rows
+        tiles = b * -(-(h // 4) // 7) * -(-(wd // 4) // 16)
+        prof.append((e0, e1, 2.0 * m * 64 * k, (m, 64, k), 4.0 * (x.numel() + 64 * 147 + y.numel()), "stem",
+                     2.0 * tiles * 512 * 64 * 154))
     return y

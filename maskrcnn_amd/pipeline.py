@@ -40,11 +40,20 @@ class Detections:
 
 
 def max_batch_per_launch(cfg: InferenceConfig) -> int:
-    """Largest per-GPU batch one pass of the step takes: every activation tensor stays under the kernels' 2^30-element limit
-    (32-bit byte offsets), so that no layer's kernel choice depends on the batch. The largest tensor per image is the RPN's
-    512-channel shared activation on P2, (H/4)(W/4) x 512 = 32 HW elements (the stem's output is 16 HW): 31 images at 1024^2,
-    29 at 832 x 1344. predict() splits larger batches into equal sub-batches."""
-    return max(1, ((1 << 30) - 1) // (32 * cfg.image_height * cfg.image_width))
+    """Largest per-GPU batch one pass of the step takes: EVERY batch-scaled tensor stays under the kernels' 2^30-element limit
+    (32-bit byte offsets), so that no layer's kernel choice depends on the batch and no launch is refused. Per image: the RPN's
+    512-channel shared activation on P2, (H/4)(W/4) x 512 = 32 HW elements (the stem's output is 16 HW) — what bounds large
+    images: 31 at 1024^2, 29 at 832 x 1344 —, and the RoI heads' tensors, which bound small images with many proposals: the
+    pooled crops P x pool^2 x 256, the classifier's P x 1024 activations, the mask head's D x (2 mask_pool)^2 x 256 up-sampled
+    map and its D x (2 mask_pool)^2 x classes output (256^2 with 1000 proposals: 85, not 511). predict() splits larger
+    batches into equal sub-batches."""
+    p = min(cfg.proposal_count, cfg.pre_nms_limit)
+    d = min(cfg.detection_max_instances, p)
+    up = (2 * cfg.mask_pool_size) ** 2
+    per_image = max(32 * cfg.image_height * cfg.image_width,
+                    p * cfg.pool_size * cfg.pool_size * 256, p * 1024, p * cfg.num_classes * 5,
+                    d * up * 256, d * up * cfg.num_classes)
+    return max(1, ((1 << 30) - 1) // per_image)
 
 
 class MaskRCNNInference:
@@ -113,9 +122,12 @@ class MaskRCNNInference:
     # ---------------------------------------------------------------- whole step
     @torch.no_grad()
     def predict(self, images: torch.Tensor, windows: torch.Tensor, with_masks: bool = True,
-                return_intermediates: bool = False):
+                return_intermediates: bool = False, rois_override=None):
         """images [B,3,H,W] fp32 NCHW, already molded (resized/padded, mean-subtracted: model.py:1102-1110);
-        windows [B,4] pixel (y1,x1,y2,x2) of the un-padded image area."""
+        windows [B,4] pixel (y1,x1,y2,x2) of the un-padded image area.
+        rois_override = (rois [B,P,4] normalised, counts int32 [B]): measurement aid (SURVEY.md §8d "synthetic input —
+        proposals"): the proposal stage still runs — its launches stay in the step — but the heads see these RoIs instead of
+        its output, e.g. proposal_count VALID proposals per image whatever random weights make of the RPN."""
         c = self.cfg
         assert images.is_cuda and images.dtype == torch.float32
         b = images.size(0)
@@ -127,17 +139,27 @@ class MaskRCNNInference:
             assert not return_intermediates, f"return_intermediates needs batch <= {self.max_batch} at this image size"
             n = -(-b // self.max_batch)
             step = -(-b // n)
-            parts = [self.predict(images[i:i + step], windows[i:i + step], with_masks) for i in range(0, b, step)]
+            ro = rois_override
+            parts = [self.predict(images[i:i + step], windows[i:i + step], with_masks,
+                                  rois_override=None if ro is None else (ro[0][i:i + step], ro[1][i:i + step]))
+                     for i in range(0, b, step)]
             cat = lambda f: torch.cat([getattr(p_, f) for p_ in parts], 0)
             return Detections(cat("class_ids"), cat("scores"), cat("boxes"), cat("counts"), cat("masks") if with_masks else None)
         fms = self.backbone(images)                                        # [P2..P6] NHWC
         scores, deltas = self.rpn_heads(fms)
         rois, roi_counts, rpn_dets = self.proposals(scores, deltas)
+        if rois_override is not None:
+            o_rois, o_counts = rois_override
+            assert tuple(o_rois.shape) == tuple(rois.shape) and o_rois.dtype == torch.float32 and o_rois.is_cuda
+            assert tuple(o_counts.shape) == (b,) and o_counts.dtype == torch.int32 and o_counts.is_cuda
+            rois, roi_counts = o_rois.contiguous(), o_counts.contiguous()
         p = rois.size(1)
         flat = rois.reshape(-1, 4).contiguous()
         # slots beyond an image's proposal count hold no RoI: RoIAlign and the head's GEMMs skip them (the reference's rois
         # tensor has only the surviving rows, model.py:1366-1374); their logits / bbox rows are never read (detections())
-        skip = roi_counts if modules.SKIP_EMPTY_ROI_TILES else None
+        # (only when the head's GEMMs honour the counts — the exact-fp32 kernel: the fp16-MFMA modes compute every row, so for
+        # them RoIAlign fills every slot too and no uninitialised row ever enters a GEMM)
+        skip = roi_counts if (modules.SKIP_EMPTY_ROI_TILES and self.classifier.honours_row_counts()) else None
         pooled = ops.roi_align_pyramid(fms[:4], flat, c.pool_size, self.image_area, rois_per_image=p,
                                        out_f16=self.classifier.wants_f16(), roi_counts=skip)
         logits, bbox = self.classifier(pooled, skip, p)

@@ -69,13 +69,20 @@ def test_dropin_surface_matches_reference():
     assert (f.crop_height, f.crop_width, f.extrapolation_value) == (14, 14, 0)
 
 
-def test_cpu_tensors_are_rejected_loudly():
+def test_cpu_tensors_without_a_gpu_fail_loudly():
+    """CPU tensors are staged through the GPU (tests/test_gpu_ops.py::test_cpu_tensors_through_the_dropin); there is no CPU
+    arithmetic in the product, so without a visible GPU the call must raise — never fall back to anything."""
     import maskrcnn
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the staged path runs (covered under -m gpu)")
     with pytest.raises(RuntimeError, match="Not compiled with CPU support"):
-        maskrcnn.nms(torch.zeros(4, 5), 0.5)
+        maskrcnn.nms(torch.rand(4, 5), 0.5)
     with pytest.raises(RuntimeError, match="Not compiled with CPU support"):
         maskrcnn.CropFunction(2, 2)(torch.zeros(1, 1, 4, 4), torch.zeros(1, 4),
                                     torch.zeros(1, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="Not compiled with CPU support"):
+        torch.ops.maskrcnn.conv_bn_act(torch.zeros(1, 4, 4, 32), torch.zeros(32, 1, 1, 32), None, None, 1, [0, 0, 0, 0], False,
+                                       None, 1)
 
 
 def test_product_never_imports_oracle():

@@ -1099,3 +1099,52 @@ def test_stem_pool_f16_one_launch(shape):
     assert (got - two).abs().max().item() <= 2e-2 * rng
     with pytest.raises(Exception):
         ops.stem_pool_f16(torch.zeros(1, 3, 70, 40, device=dev), w_ohwi.to(dev), None, None)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 256, 256), (1, 72, 40), (3, 16, 16), (1, 4, 4), (1, 60, 132), (2, 1024, 1024),
+                                   (1, 832, 1344)], ids=lambda s: "x".join(str(v) for v in s))
+def test_stem_pool_f32_one_launch(shape):
+    """Round 5, the exact-fp32 stem: conv 7x7 s2 + affine + ReLU + SamePad(3,2) + MaxPool(3,2) (model.py:223-229) as ONE launch on
+    the fp32 MFMA with K = 7 x 21 real values (stem7x7_s2_pool_f32). Against the two launches it replaces (stem7x7_s2_f32 +
+    maxpool_nhwc: the same exact fp32 products summed in another order, then the same exact max): equal to rounding of the
+    147-term sums; against torch-CPU fp32 conv + BN + ReLU + pad + max-pool at the pipeline's bar 1e-4 * max(1, max|act|) and
+    against a float64 evaluation at a few ulps of the range. Ragged tiles (pooled heights that are not multiples of 7, widths
+    not multiples of 16), several images, the 1 x 1 pooled map; H or W not a multiple of 4 is refused."""
+    from maskrcnn_amd import ops
+    from oracle import oracle
+    dev = torch.device("cuda:0")
+    b, h, w = shape
+    g = torch.Generator().manual_seed(h * 7 + w)
+    img = torch.randint(0, 256, (b, 3, h, w), generator=g).float() - torch.tensor([123.7, 116.8, 103.9]).view(1, 3, 1, 1)
+    wt = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    scale = torch.rand(64, generator=g) + 0.5
+    shift = torch.randn(64, generator=g) * 0.1
+    w_ohwi = torch.zeros(64, 7, 7, 4)
+    w_ohwi[..., :3] = wt.permute(0, 2, 3, 1)
+    got = ops.stem_pool_f32(img.to(dev), w_ohwi.to(dev), scale.to(dev), shift.to(dev))
+    oh, ow = h // 2, w // 2
+    two = ops.maxpool(ops.stem_conv(img.to(dev), w_ohwi.to(dev), scale.to(dev), shift.to(dev), True, nchw=True), 3, 2,
+                      ops.same_pad(oh, ow, 3, 2))
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == tuple(two.shape) == (b, (oh + 1) // 2, (ow + 1) // 2, 64)
+    rng = two.abs().max().item()
+    assert (got - two).abs().max().item() <= 4e-6 * max(1.0, rng), ((got - two).abs().max().item(), rng)
+    if b * h * w <= 2 * 1024 * 1024:
+        conv = F.conv2d(img, wt, None, stride=2, padding=3)
+        ref = F.relu(conv * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+        ref = F.max_pool2d(oracle.same_pad(ref, 3, 2), kernel_size=3, stride=2).permute(0, 2, 3, 1)
+        assert (got.cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    if b * h * w <= 256 * 256:
+        c64 = F.conv2d(img.double(), wt.double(), None, stride=2, padding=3)
+        r64 = F.relu(c64 * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+        r64 = F.max_pool2d(oracle.same_pad(r64, 3, 2), kernel_size=3, stride=2).permute(0, 2, 3, 1)
+        assert (got.cpu().double() - r64).abs().max().item() <= 8 * 2.0 ** -23 * max(1.0, r64.abs().max().item())
+    # nothing is written outside the output (guard rows) and a second call gives the same bits (persistent tiles, prefetch)
+    again = ops.stem_pool_f32(img.to(dev), w_ohwi.to(dev), scale.to(dev), shift.to(dev))
+    assert torch.equal(again, got)
+    # without the affine vectors
+    plain = ops.stem_pool_f32(img.to(dev), w_ohwi.to(dev), None, None)
+    two_p = ops.maxpool(ops.stem_conv(img.to(dev), w_ohwi.to(dev), None, None, True, nchw=True), 3, 2, ops.same_pad(oh, ow, 3, 2))
+    assert (plain - two_p).abs().max().item() <= 4e-6 * max(1.0, two_p.abs().max().item())
+    with pytest.raises(Exception):
+        ops.stem_pool_f32(torch.zeros(1, 3, 70, 40, device=dev), w_ohwi.to(dev), None, None)

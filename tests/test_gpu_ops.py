@@ -170,6 +170,46 @@ def test_crop_forward_golden(dev):
         assert np.array_equal(crops.cpu().numpy(), z[f"c{i}_crops"]), tag
 
 
+def test_cpu_tensors_through_the_dropin(dev):
+    """The reference's dispatch takes CPU tensors and returns CPU tensors (nms.h:15-30, crop.h:14-53; SURVEY 8b "CPU in -> CPU
+    out"). Here they are staged through the GPU — same HIP kernels, never the oracle — so the reference-generated golden
+    vectors must come back bit for bit as CPU tensors: nms int64 ascending; `crops` resized in place; crop_backward in place."""
+    import maskrcnn
+    z = load_golden("nms")
+    for i, tag in _cases(z):
+        dets = torch.from_numpy(z[f"c{i}_dets"])
+        keep = maskrcnn.nms(dets, float(z[f"c{i}_thr"]))
+        assert keep.dtype == torch.int64 and keep.device.type == "cpu"
+        assert np.array_equal(keep.numpy(), z[f"c{i}_keep"]), tag
+    empty = maskrcnn.nms(torch.zeros(0, 5), 0.5)
+    assert empty.numel() == 0 and empty.dtype == torch.int64 and empty.device.type == "cpu"
+    z = load_golden("crop_forward")
+    for i, tag in _cases(z):
+        extrap, ch, cw = z[f"c{i}_args"]
+        img, boxes, ind = (torch.from_numpy(z[f"c{i}_{k}"]) for k in ("image", "boxes", "ind"))
+        got = maskrcnn.CropFunction(int(ch), int(cw), float(extrap))(img, boxes, ind)
+        assert got.device.type == "cpu" and np.array_equal(got.numpy(), z[f"c{i}_crops"]), tag
+        crops = torch.zeros_like(img)                       # model.py-shaped caller: __init__.py:36
+        maskrcnn._C.crop_forward(img, boxes, ind, float(extrap), int(ch), int(cw), crops)
+        assert crops.device.type == "cpu" and np.array_equal(crops.numpy(), z[f"c{i}_crops"]), tag
+    # backward on CPU tensors == backward on device tensors (same kernel; the atomics' order may differ: 1e-5 as elsewhere)
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(2, 5, 12, 10, generator=g, requires_grad=True)
+    boxes = torch.rand(6, 4, generator=g)
+    boxes = torch.cat([torch.minimum(boxes[:, :2], boxes[:, 2:]), torch.maximum(boxes[:, :2], boxes[:, 2:])], 1)
+    ind = torch.randint(0, 2, (6,), generator=g, dtype=torch.int32)
+    out = maskrcnn.CropFunction(3, 4, 0)(img, boxes, ind)
+    out.backward(torch.ones_like(out))
+    img_d = img.detach().to(dev).requires_grad_(True)
+    out_d = maskrcnn.CropFunction(3, 4, 0)(img_d, boxes.to(dev), ind.to(dev))
+    out_d.backward(torch.ones_like(out_d))
+    assert img.grad.device.type == "cpu" and torch.equal(out.detach(), out_d.detach().cpu())
+    assert (img.grad - img_d.grad.cpu()).abs().max().item() <= 1e-5
+    # dtype errors are the reference's on either device
+    with pytest.raises(RuntimeError):
+        maskrcnn._C.crop_forward(img.detach(), boxes, ind.long(), 0.0, 3, 4, torch.zeros(1))
+
+
 def _rand_boxes(g, n, lo, hi, spill=False):
     c = torch.rand(n, 2, generator=g)
     hw = torch.exp(torch.rand(n, 2, generator=g) * (np.log(hi) - np.log(lo)) + np.log(lo))

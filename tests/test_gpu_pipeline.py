@@ -342,3 +342,34 @@ def test_predict_splits_oversized_batches_into_equal_sub_batches():
     assert tuple(split.masks.shape) == (5, 10, 28, 28, 81) and int(split.counts.sum()) > 0
     with pytest.raises(AssertionError):
         net.predict(images, windows, return_intermediates=True)
+
+
+def test_small_images_large_batch_is_split_by_the_roi_head_tensors():
+    """for small images the RoI heads' tensors reach the kernels' 2^30-element limit before the trunk's do — 64 x 64
+    images with 1000 proposals: the pooled crops [B*1000, 7, 7, 256] pass it at B = 86 while the trunk alone would allow 8191.
+    max_batch_per_launch takes the minimum over every batch-scaled tensor, so predict() splits such a batch instead of raising
+    'tensor too large' from a launch; the split result equals the images run alone."""
+    from maskrcnn_amd import modules
+    from maskrcnn_amd.config import InferenceConfig
+    from maskrcnn_amd.pipeline import MaskRCNNInference
+    dev = torch.device("cuda:0")
+    cfg = InferenceConfig(image_height=64, image_width=64, backbone="resnet50", pre_nms_limit=1000, proposal_count=1000,
+                          detection_max_instances=5)
+    sd = modules.synthetic_state_dict("resnet50", seed=0, bn_seed=1)
+    g = torch.Generator().manual_seed(6)
+    sd["rpn.conv_class.weight"] = sd["rpn.conv_class.weight"] * 0.05
+    sd["classifier.linear_class.weight"] = torch.randn(81, 1024, generator=g) * 0.05
+    sd["classifier.linear_bbox.weight"] = torch.randn(324, 1024, generator=g) * 0.02
+    net = MaskRCNNInference(sd, cfg, dev)
+    assert net.max_batch == 85
+    n = 87
+    images = (torch.randint(0, 256, (n, 64, 64, 3), generator=g).float() - torch.tensor(cfg.mean_pixel))
+    images = images.permute(0, 3, 1, 2).contiguous().to(dev)
+    windows = torch.tensor([[0., 0., 64., 64.]] * n, device=dev)
+    det = net.predict(images, windows)
+    torch.cuda.synchronize()
+    assert tuple(det.masks.shape) == (n, 5, 28, 28, 81) and int(det.counts.sum()) > 0
+    for i in (0, 43, 44, 86):   # either side of the split point
+        one = net.predict(images[i:i + 1], windows[i:i + 1])
+        for f in ("class_ids", "scores", "boxes", "counts", "masks"):
+            assert torch.equal(getattr(det, f)[i:i + 1], getattr(one, f)), (i, f)
