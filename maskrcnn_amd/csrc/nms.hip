@@ -259,13 +259,16 @@ __global__ __launch_bounds__(T) void nms_kernel(const float* __restrict__ dets, 
 // over the whole chip; only the inherently serial greedy scan stays on one wave per segment.
 //   K1 nms_sort_kernel   1 workgroup / segment : LDS bitonic sort, sorted boxes + areas + classes + input
 //                                                indices to the workspace
-//   K2 nms_mask_kernel   1 wave / 64x64 tile   : lane = column box, 64 row boxes broadcast by readlane,
-//                                                one __ballot per row → mask[row][column word] (upper triangle)
-//   K3 nms_scan_kernel   1 workgroup / segment : mask rows of the segment pulled into LDS (N <= 1024) or read
-//                                                from L2; wave 0 keeps the "removed" bitset one 64-bit word per
-//                                                lane, resolves each 64-box chunk serially over its alive boxes
-//                                                (readlane), ORs the survivors' rows into the bitset; then
-//                                                ballot/popcount compaction to ascending input indices.
+//   K2 nms_mask_kernel   1 wave / 64x64 tile   : lane = column box j, the tile's 64 row boxes broadcast by readlane: bit i of
+//                                                the lane's word = "earlier box i of row block rb suppresses j" →
+//                                                col[rb][j] (column-oriented, upper triangle of tiles; no ballot)
+//   K3 nms_scan_kernel   1 workgroup / segment : the column words of the segment pulled into LDS (N <= 1024) or read
+//                                                from L2; wave 0 walks the 64-box chunks in score order: lane j of chunk c
+//                                                is removed iff col[rb][j] & kept[rb] != 0 for an earlier chunk rb (c word
+//                                                reads per lane — round 5; rounds 1-4 OR-ed the 64 ROWS of every chunk's
+//                                                survivors into a removed set: 64 reads per lane and chunk, 48 us per
+//                                                8 x 1000 boxes), then resolves the chunk itself as a fixpoint of ballots on
+//                                                the diagonal word; then ballot/popcount compaction to ascending input indices.
 // Identical arithmetic (iou_ge) and identical visiting order → identical keep set to path 1 and the CPU path.
 // =====================================================================================================
 struct NmsWs {
@@ -273,8 +276,7 @@ struct NmsWs {
     float* area;    // [S][Np]
     int* cls;       // [S][Np]
     int* idx;       // [S][Np] input index, -1 for padding
-    u64* mask;      // [S][Np][NB]   row-oriented: word cb of row p = later boxes of chunk cb suppressed by p
-    u64* diagcol;   // [S][Np]       column-oriented, diagonal tiles only: earlier boxes of p's own chunk that suppress p
+    u64* col;       // [S][NB][Np]   column-oriented: word rb of box p = earlier boxes of chunk rb that suppress p (rb <= p / 64)
     int np, nb;
 };
 
@@ -350,7 +352,6 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsWs ws, float thr) {
     const float4 bi4 = ws.box[base + pi0 + lane];
     const float ai = ws.area[base + pi0 + lane];
     const int ci = ws.cls[base + pi0 + lane];
-    u64 mine = 0;  // lane i ends up holding row i's word
     u64 col = 0;   // lane j: rows of this tile that suppress column box j
     for (int i = 0; i < 64; ++i) {
         Box bi;
@@ -361,17 +362,13 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(NmsWs ws, float thr) {
         bi.area = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ai), i));
         const int cri = __builtin_amdgcn_readlane(ci, i);
         const bool hit = jvalid && (pj > pi0 + i) && (cri == cj) && iou_ge(bi, bj, thr);
-        const u64 m = __ballot(hit);
-        if (lane == i) mine = m;
         col |= hit ? (1ull << i) : 0ull;
     }
-    ws.mask[(base + pi0 + lane) * ws.nb + cb] = mine;
-    if (rb == cb) ws.diagcol[base + pj] = col;
+    ws.col[(static_cast<int64_t>(seg) * ws.nb + rb) * ws.np + pj] = col;
 }
 
-// grid = S, block = 256. LDS: mask rows (when they fit) + keep flags.
-// NQ: 64-bit removed-set words per lane of the scanning wave (1: up to 64 chunks = 4096 boxes; 4: up to 16384)
-template <bool MASK_IN_LDS, int NQ = 1>
+// grid = S, block = 256. LDS: the segment's column words (when they fit) + keep flags + the chunks' survivor words.
+template <bool MASK_IN_LDS>
 __global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs ws, int64_t n_max,
                                                        const int32_t* __restrict__ seg_counts,
                                                        int64_t* __restrict__ keep_out,
@@ -382,72 +379,47 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(NmsWs ws, int64_t n_max,
     int n = seg_counts ? seg_counts[seg] : static_cast<int>(n_max);
     n = n < 0 ? 0 : (n > n_max ? static_cast<int>(n_max) : n);
     const int64_t base = static_cast<int64_t>(seg) * np;
-    const u64* gmask = ws.mask + base * nb;
-    u64* lmask = reinterpret_cast<u64*>(smem);                                  // [np][nb] if MASK_IN_LDS
+    const u64* gcol = ws.col + base * nb;                                       // [nb][np]
+    u64* lcol = reinterpret_cast<u64*>(smem);                                   // [nb][np] if MASK_IN_LDS
     unsigned char* keepf = smem + (MASK_IN_LDS ? sizeof(u64) * np * nb : 0);    // [np] by input index
-    u64* keptw = reinterpret_cast<u64*>(keepf + np);                            // [nb] survivors per chunk
-    u64* dcol = keptw + nb + 2;                                                 // [np] diagonal column masks
+    u64* keptw = reinterpret_cast<u64*>(keepf + np);                            // [nb] survivors per chunk (+ 2 spare words)
     const int nchunks = (n + 63) >> 6;
     if (MASK_IN_LDS) {
-        // only rows < n and only the upper triangle were written by K2; copy whole rows of live chunks
-        for (int e = tid; e < nchunks * 64 * nb; e += 256) lmask[e] = gmask[e];
+        // K2 wrote the words rb <= (column chunk) of columns < 64 * ceil(n / 64): copy exactly those (the upper triangle)
+        for (int rb = 0; rb < nchunks; ++rb)
+            for (int p = rb * 64 + tid; p < nchunks * 64; p += 256) lcol[rb * np + p] = gcol[static_cast<int64_t>(rb) * np + p];
     }
-    for (int i = tid; i < np; i += 256) {
-        keepf[i] = 0;
-        dcol[i] = ws.diagcol[base + i];
-    }
+    for (int i = tid; i < np; i += 256) keepf[i] = 0;
     __syncthreads();
-    const u64* mk = MASK_IN_LDS ? lmask : gmask;
+    const u64* ck = MASK_IN_LDS ? lcol : gcol;
     if (wave == 0) {
-        // lane w holds the removed bits of chunks w, w + 64, w + 128, w + 192 (up to 256 chunks = 16384 boxes)
-        u64 remv[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) remv[q] = 0;
         for (int c = 0; c < nchunks; ++c) {
             const int p = c * 64 + lane;
-            const u64 dc = dcol[p];  // earlier boxes of this chunk that would suppress box p
-            const int cq = c >> 6, cl = c & 63;  // uniform
-            u64 rsel = remv[0];
+            // removed by a survivor of an EARLIER chunk? (keptw[rb]: written by lane 0 below, read back by the same wave — LDS
+            // operations of one wave complete in order; one address for all lanes: a broadcast read)
+            const u64 dc = ck[static_cast<int64_t>(c) * np + p];  // earlier boxes of this chunk that would suppress box p
+            u64 rem = 0;
+            int rb = 0;
+            for (; rb + 8 <= c; rb += 8) {   // eight independent reads in flight (they come from L2 when the words are not in LDS)
+                u64 v[8];
 #pragma unroll
-            for (int q = 1; q < NQ; ++q) rsel = cq == q ? remv[q] : rsel;
-            const u32 r_lo = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(rsel)), cl));
-            const u32 r_hi = static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<u32>(rsel >> 32)), cl));
-            const u64 removed = (static_cast<u64>(r_hi) << 32) | r_lo;
-            const u64 validm = (n - c * 64 >= 64) ? ~0ull : ((1ull << (n - c * 64)) - 1ull);
-            const u64 alive = ~removed & validm;
+                for (int u = 0; u < 8; ++u) v[u] = ck[static_cast<int64_t>(rb + u) * np + p];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rem |= v[u] & keptw[rb + u];
+            }
+            for (; rb < c; ++rb) rem |= ck[static_cast<int64_t>(rb) * np + p] & keptw[rb];
+            const bool me_alive = p < n && rem == 0ull;
             // Greedy resolution of the chunk as a fixpoint: K[j] = alive[j] && no kept EARLIER box suppresses j.
             // Starting from K = alive, iteration t fixes (at least) the first t+1 positions, and a fixpoint
             // satisfies the greedy recurrence, whose solution is unique — typically 2-4 rounds of one AND +
             // one ballot instead of a 64-step serial walk.
-            const bool me_alive = (alive >> lane) & 1ull;
-            u64 kept = alive;
+            u64 kept = __ballot(me_alive);
             for (int round = 0; round < 65; ++round) {
                 const u64 next = __ballot(me_alive && (dc & kept) == 0ull);
                 if (next == kept) break;
                 kept = next;
             }
             if (lane == 0) keptw[c] = kept;
-            // survivors of this chunk remove later boxes: lane w ORs words w + 64 q of every surviving row
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int word = lane + 64 * q;
-                if (word > c && word < nb) {
-                    u64 acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-                    const u64* rowp = mk + (static_cast<int64_t>(c) * 64) * nb + word;
-#pragma unroll 4
-                    for (int i = 0; i < 64; i += 4) {
-                        const u64 v0 = rowp[static_cast<int64_t>(i) * nb];
-                        const u64 v1 = rowp[static_cast<int64_t>(i + 1) * nb];
-                        const u64 v2 = rowp[static_cast<int64_t>(i + 2) * nb];
-                        const u64 v3 = rowp[static_cast<int64_t>(i + 3) * nb];
-                        acc0 |= ((kept >> i) & 1ull) ? v0 : 0ull;
-                        acc1 |= ((kept >> (i + 1)) & 1ull) ? v1 : 0ull;
-                        acc2 |= ((kept >> (i + 2)) & 1ull) ? v2 : 0ull;
-                        acc3 |= ((kept >> (i + 3)) & 1ull) ? v3 : 0ull;
-                    }
-                    remv[q] |= acc0 | acc1 | acc2 | acc3;
-                }
-            }
         }
     }
     __syncthreads();
@@ -509,16 +481,14 @@ size_t ws_layout(int32_t S, int64_t n_max, void* base, NmsWs* ws) {
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_box = take(sizeof(float4) * S * np), o_area = take(sizeof(float) * S * np);
     const size_t o_cls = take(sizeof(int) * S * np), o_idx = take(sizeof(int) * S * np);
-    const size_t o_mask = take(sizeof(u64) * S * np * nb);
-    const size_t o_dcol = take(sizeof(u64) * S * np);
+    const size_t o_col = take(sizeof(u64) * S * np * nb);
     if (ws) {
         unsigned char* b = static_cast<unsigned char*>(base);
         ws->box = reinterpret_cast<float4*>(b + o_box);
         ws->area = reinterpret_cast<float*>(b + o_area);
         ws->cls = reinterpret_cast<int*>(b + o_cls);
         ws->idx = reinterpret_cast<int*>(b + o_idx);
-        ws->mask = reinterpret_cast<u64*>(b + o_mask);
-        ws->diagcol = reinterpret_cast<u64*>(b + o_dcol);
+        ws->col = reinterpret_cast<u64*>(b + o_col);
         ws->np = np;
         ws->nb = nb;
     }
@@ -527,8 +497,8 @@ size_t ws_layout(int32_t S, int64_t n_max, void* base, NmsWs* ws) {
 
 }  // namespace
 
-// With a workspace: 16384 boxes per segment (the scan keeps its removed-set as one 64-bit word per lane of a 256-thread
-// workgroup: 256 x 64; the sort holds 8-byte keys in LDS: 128 KB). Without: the single-launch path, 4096.
+// With a workspace: 16384 boxes per segment (256 chunks of 64: the column words live in the workspace; the sort holds
+// 8-byte keys in LDS: 128 KB). Without: the single-launch path, 4096.
 constexpr int64_t NMS_MAX_WS = 16384, NMS_MAX_LDS = 4096;
 extern "C" int64_t mrcnn_nms_max_boxes(void) { return NMS_MAX_WS; }
 
@@ -576,20 +546,16 @@ extern "C" int mrcnn_nms_batched_f32(const float* dets, int32_t num_segments, in
         hipLaunchKernelGGL(nms_mask_kernel, dim3(ws.nb * (ws.nb + 1) / 2, num_segments), dim3(64), 0, s, ws,
                            threshold);
         if ((rc = mrcnn::check_launch("nms_mask_kernel"))) return rc;
-        const size_t tail = ws.np + sizeof(u64) * (ws.nb + 2) + sizeof(u64) * ws.np;
+        const size_t tail = (ws.np + 7) / 8 * 8 + sizeof(u64) * (ws.nb + 2);
         const size_t lds_full = sizeof(u64) * ws.np * ws.nb + tail;
         if (lds_full <= 150 * 1024) {
             auto k = nms_scan_kernel<true>;
             if ((rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(k), lds_full, "nms"))) return rc;
             hipLaunchKernelGGL(k, dim3(num_segments), dim3(256), lds_full, s, ws, n_max, seg_counts, keep_out,
                                counts_out);
-        } else if (ws.nb <= 64) {
+        } else {
             hipLaunchKernelGGL(nms_scan_kernel<false>, dim3(num_segments), dim3(256), tail, s, ws, n_max,
                                seg_counts, keep_out, counts_out);
-        } else {
-            auto k4 = nms_scan_kernel<false, 4>;
-            if ((rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(k4), tail, "nms"))) return rc;
-            hipLaunchKernelGGL(k4, dim3(num_segments), dim3(256), tail, s, ws, n_max, seg_counts, keep_out, counts_out);
         }
         return mrcnn::check_launch("nms_scan_kernel");
     }

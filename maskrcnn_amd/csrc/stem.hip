@@ -572,22 +572,29 @@ __global__ __launch_bounds__(256, 1) void stem7x7_s2_pool_f32(const StemPool32Pa
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
             const float* wl = Wl + b_base + ct * 32 * 4;
+            // One wave per SIMD: nothing else covers an LDS round trip, so the operands of step s + 1 are read BEFORE the MFMAs of
+            // step s (two register sets; the sched_barriers pin the order the source states).
+            f32x2 a[2][NRW], bw[2];
+            auto fetch = [&](int step, int set) {
+                const int ky = step / S3_KQ, j = step - ky * S3_KQ;
+                bw[set] = *reinterpret_cast<const f32x2*>(wl + step * 64 * 4);
 #pragma unroll
-            for (int ky = 0; ky < 7; ++ky)
+                for (int i = 0; i < NRW; ++i) a[set][i] = *reinterpret_cast<const f32x2*>(Pl + a_base[i] + ky * S3_PITCH + 4 * j);
+            };
+            fetch(0, 0);
 #pragma unroll
-                for (int j = 0; j < S3_KQ; ++j) {
-                    f32x2 a[NRW];
-                    const f32x2 bw = *reinterpret_cast<const f32x2*>(wl + (ky * S3_KQ + j) * 64 * 4);
+            for (int step = 0; step < 7 * S3_KQ; ++step) {
+                const int cur = step & 1;
+                if (step + 1 < 7 * S3_KQ) fetch(step + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < NRW; ++i)
-                        a[i] = *reinterpret_cast<const f32x2*>(Pl + a_base[i] + ky * S3_PITCH + 4 * j);
+                for (int i = 0; i < NRW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].x, bw[cur].x, acc[i], 0, 0, 0);
+                if (step % S3_KQ < S3_KQ - 1) {
 #pragma unroll
-                    for (int i = 0; i < NRW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, bw.x, acc[i], 0, 0, 0);
-                    if (j < S3_KQ - 1) {
-#pragma unroll
-                        for (int i = 0; i < NRW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, bw.y, acc[i], 0, 0, 0);
-                    }
+                    for (int i = 0; i < NRW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i].y, bw[cur].y, acc[i], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // conv image of this channel half: affine + ReLU. Row r of a 32-pixel row tile is pixel q0 + d_r, d_r a compile-time
             // constant: one LDS base + immediates. (Conv pixels beyond the conv map hold whatever the zero-filled patch gives; the
             // pool below never lets them through.)
