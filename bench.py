@@ -492,6 +492,8 @@ def main():
     ap.add_argument("--traffic-timeout", type=int, default=120, help="seconds allowed per counter pass")
     ap.add_argument("--alt-injected", type=int, default=1,
                     help="also time the headline step with SURVEY 8(d)'s injected proposals (every RoI slot valid), N=1 only")
+    ap.add_argument("--alt-detect", type=int, default=1,
+                    help="also time MaskRCNNInference.detect() (uint8 images in, full-size masks out) on configs[0]-sized images, N=1 only")
     ap.add_argument("--alt-config5", type=int, default=1,
                     help="also time BASELINE configs[4]'s geometry (R101-FPN, 832x1344, fp16 MFMA path) on this GPU, N=1 only")
     args = ap.parse_args()
@@ -669,6 +671,12 @@ def main():
         except Exception as e:
             log(f"[bench] ERROR: injected-proposals entry failed: {e!r}")
             alt_configs = [{"config": "configs[2] with injected proposals", "error": repr(e)}]
+    if rank == 0 and world == 1 and args.alt_detect:
+        try:
+            alt_configs = (alt_configs or []) + [detect_entry(net, images, windows, args, cfg, dev)]
+        except Exception as e:
+            log(f"[bench] ERROR: detect entry failed: {e!r}")
+            alt_configs = (alt_configs or []) + [{"config": "detect() on uint8 images", "error": repr(e)}]
     if rank == 0 and world == 1 and args.alt_config5:
         del net
         torch.cuda.empty_cache()
@@ -790,6 +798,55 @@ def injected_entry(net, images, windows, args, cfg, dev, ops):
     return out
 
 
+def detect_entry(net, images, windows, args, cfg, dev):
+    """SURVEY 8f-4 under the clock: MaskRCNNInference.detect() — resize + pad + mean-subtract (utils.resize_image, mold_image),
+    the whole predict step, full-size mask pasting and the mapping back to the original frames (datalib.full_masks,
+    decode_boxes / decode_masks) — on `batch` uint8 RGB images of configs[0]'s size (1200 x 1920, seeded noise; already in HBM,
+    as the headline's inputs are). Beside it predict() alone on the molded batch of the SAME images: detect must stay within
+    10 % of it. Needs the square 1024 canvas of the reference; never `value`."""
+    if cfg.image_height != cfg.image_width or cfg.image_height != cfg.image_max_dim:
+        return {"config": "detect() on uint8 images", "skipped": "needs the square IMAGE_MAX_DIM canvas"}
+    from maskrcnn_amd import image as imagelib
+    b = images.size(0)
+    g = torch.Generator().manual_seed(58)
+    raw = [torch.randint(0, 256, (1200, 1920, 3), generator=g, dtype=torch.uint8).to(dev) for _ in range(b)]
+    molded, win, _ = imagelib.mold_inputs(raw, cfg, dev)
+    for _ in range(args.warmup):
+        net.predict(molded, win, with_masks=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.predict(molded, win, with_masks=True)
+    torch.cuda.synchronize()
+    el_p = time.perf_counter() - t0
+    for _ in range(args.warmup):
+        res = net.detect(raw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = net.detect(raw)
+    torch.cuda.synchronize()
+    el_d = time.perf_counter() - t0
+    split = {"mold_ms": 0.0, "predict_ms": 0.0, "paste_decode_ms": 0.0}
+    reps = 3
+    for _ in range(reps):
+        t = {}
+        net.detect(raw, timings=t)
+        for k in split:
+            split[k] += t[k] / reps
+    n_det = sum(0 if r[0] is None else int(r[0].numel()) for r in res)
+    mask_bytes = sum(0 if r[3] is None else r[3].numel() * r[3].element_size() for r in res)
+    return {"config": f"detect(): {b} uint8 RGB images of 1200 x 1920 (configs[0]'s size) -> class ids, scores, boxes and FULL-SIZE masks "
+                      "in each image's own frame (model.py:1095-1138, utils.py:42-90, data.py:264-314); same weights as the headline",
+            "value": round(b * args.steps / el_d, 2), "unit": "images/s", "ms_per_step": round(el_d / args.steps * 1e3, 3),
+            "predict_only_on_the_same_molded_batch": {"value": round(b * args.steps / el_p, 2), "ms_per_step": round(el_p / args.steps * 1e3, 3)},
+            "detect_over_predict": round(el_p / el_d, 4), "steps": args.steps,
+            "split_ms": {k: round(v, 3) for k, v in split.items()},
+            "split_note": "HIP events around the three stages of one detect() call (mean of 3); one host synchronisation per batch "
+                          "(the detection counts) sits between predict and paste",
+            "detections": n_det, "full_size_mask_bytes": mask_bytes}
+
+
 def config5_entry(dev, args, ops, modules, InferenceConfig, MaskRCNNInference):
     """BASELINE configs[4] on ONE GPU: ResNet-101-FPN, 832 x 1344, batch 8, precision "f16" (fp16 operands and fp16
     activations in HBM, fp32 accumulate; parity bar of this mode: 2e-2 of the activation range, tests/test_gpu_fullsize.py
@@ -826,7 +883,10 @@ def config5_entry(dev, args, ops, modules, InferenceConfig, MaskRCNNInference):
                       f"{args.proposals} proposals/img, fp16 MFMA path (fp16 operands + fp16 activations in HBM, fp32 accumulate)",
             "precision": "f16", "value": round(batch * args.steps / el, 2), "unit": "images/s",
             "ms_per_step": round(el / args.steps * 1e3, 3), "steps": args.steps,
-            "tolerance": "2e-2 of the activation range vs the fp32 oracle (tests/test_gpu_fullsize.py), not the 1e-4 bar",
+            "tolerance": "this mode's bars, not the 1e-4 one (tests/test_gpu_fullsize.py): trunk 2e-2 of the activation range vs the fp32 "
+                         "oracle; masks on the same boxes 3e-2 abs (sigmoid outputs in [0,1]) vs the fp32 masks; detections: >= 95 % of "
+                         "the fp32 path's confident detections have a same-class fp16 detection at IoU >= 0.9, none below 0.5 "
+                         "(three seeds x eight images)",
             "conv_ms_per_step": round(ms, 3), "conv_algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 1),
             "conv_frac_of_f16_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4),
             "conv_frac_of_per_launch_roofline": round(floor_ms / ms, 4),

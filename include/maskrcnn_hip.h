@@ -479,6 +479,12 @@ int mrcnn_resize_bilinear_u8(const uint8_t* src, int32_t n, int32_t in_h, int32_
 int mrcnn_mold_image_u8(const uint8_t* src, int32_t in_h, int32_t in_w, int32_t new_h, int32_t new_w, int32_t top,
                         int32_t left, int32_t out_h, int32_t out_w, const double mean_pixel[3], float* dst,
                         void* workspace, size_t workspace_bytes, mrcnn_stream_t stream);
+/* The same for n images of ONE size (a batch from one camera / dataset: detect() on a list, model.py:1097-1110): src image i
+ * at src + i * src_image_stride, dst n x [3][out_h][out_w]; one set of coefficient tables, one horizontal pass and one
+ * vertical + mold pass for the whole batch. workspace: mrcnn_resize_u8_workspace_bytes(n, in_h, in_w, 3, new_h, new_w). */
+int mrcnn_mold_images_u8(const uint8_t* src, int32_t n, int64_t src_image_stride, int32_t in_h, int32_t in_w, int32_t new_h,
+                         int32_t new_w, int32_t top, int32_t left, int32_t out_h, int32_t out_w, const double mean_pixel[3],
+                         float* dst, void* workspace, size_t workspace_bytes, mrcnn_stream_t stream);
 /* Replaces datalib.full_masks (data.py:287-314). For detection i: the class_ids[i] channel of its mask_h x mask_w
  * sigmoid mask (element (i,y,x,c) at masks[i*stride_n + y*stride_y + x*stride_x + c*stride_c], so both the
  * reference's [N,C,h,w] and this library's [N,h,w,C] layouts are accepted) is multiplied by 255, converted to 8 bits

@@ -127,6 +127,8 @@ _SIGS = {
                                                   c_vp, ctypes.c_size_t, c_vp]),
     "mrcnn_mold_image_u8": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                              ctypes.POINTER(ctypes.c_double), c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "mrcnn_mold_images_u8": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                              ctypes.POINTER(ctypes.c_double), c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "mrcnn_paste_masks_u8": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp,
                                               c_i32, c_i32, c_i32, c_vp, c_vp]),
 }

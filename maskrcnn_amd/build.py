@@ -34,7 +34,8 @@ SOURCES = {
     "conv_f16p.hip": [],
     "conv_wino.hip": ABL,
     "conv_wino4.hip": (["-DMRCNN_W4_ABLATIONS"] if (os.environ.get("MRCNN_W4_ABLATIONS") or os.environ.get("MRCNN_ABLATIONS")) else [])
-                      + ([f"-DMRCNN_W4_WALK_SHIFT={int(os.environ['MRCNN_W4_WALK_SHIFT'])}"] if os.environ.get("MRCNN_W4_WALK_SHIFT") else []),
+                      + ([f"-DMRCNN_W4_WALK_SHIFT={int(os.environ['MRCNN_W4_WALK_SHIFT'])}"] if os.environ.get("MRCNN_W4_WALK_SHIFT") else [])
+                      + (["-DMRCNN_W4_VMCNT0"] if os.environ.get("MRCNN_W4_VMCNT0") else []),
     "stem.hip": [],
     "bottleneck.hip": [],
     "bottleneck_op.hip": [],

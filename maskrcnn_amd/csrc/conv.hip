@@ -47,7 +47,16 @@ constexpr size_t conv_lds_bytes() {
 //   except the stem. No address arithmetic in the loop: a thread's byte offsets are fixed for the whole tile (out of
 //   range for rows beyond M), the k tile is the scalar soffset of the buffer loads. (VALU instructions do not
 //   co-execute with this MFMA — tools/mfma_valu_probe.hip — so each one removed is four cycles per wave and k tile.)
-template <int BM, int BN, int WM, int WN, int BK, int MODE, int RES>
+// SPLIT (round 5): the sum over K runs as TWO chains — the 32-wide k blocks alternate between two accumulator sets, added once
+// at the end — for the long-K layers (K >= 1024: the Bottleneck conv1 layers of C4 / C5, the C5 downsample, the P4 / P5 laterals,
+// the classifier's GEMMs). A float64 evaluation of every conv unit of the trunk on identical inputs (tools/fp64_truth.py
+// --attribute, profiles/r05_fp64_attribution.jsonl) put exactly those at the top of the HIP path's excess over torch-CPU's
+// blocked sums (rms 0.7 - 1.6 ulps of the output range against 0.2 - 0.4): the error of a sequential fp32 sum grows with its
+// length, and the second accumulator set is free — 151 + 64 registers stay inside the 256 of two workgroups per CU, the MFMAs
+// are the same, one packed add per accumulator register at the end. Which chain a k block belongs to depends on its position in K
+// only ((k0 >> 5) & 1), never on the tile (BK = 16 tiles give two consecutive k tiles to a chain), so every tile the launcher may
+// pick for a layer — by the batch — produces the same bits.
+template <int BM, int BN, int WM, int WN, int BK, int MODE, int RES, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
     constexpr bool GENERIC = MODE == 1, PW = MODE == 2;
     // LDS row pitch in floats. BK = 32: 36 — the +4 pad makes the fragment reads (16 consecutive rows, one 16-byte chunk each)
@@ -254,7 +263,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
             fb[slot][i] = *reinterpret_cast<const float4*>(Bw + buf * BN * LDS_STRIDE + i * 32 * LDS_STRIDE + jo);
     };
     read_frags(0, 0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    f32x16 acc2[SPLIT ? TM : 1][SPLIT ? TN : 1];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+    }
+    auto ktile = [&](auto chain_tag, int kt) {
+        constexpr int CH = decltype(chain_tag)::value;
         const int buf = kt & 1;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -277,7 +296,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
                     for (int jn = 0; jn < TN; ++jn) {
                         const float4 b = fb[cur][jn];
                         const float bv = s == 0 ? b.x : s == 1 ? b.y : s == 2 ? b.z : b.w;
-                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jn], 0, 0, 0);
+                        if constexpr (SPLIT && CH == 1)
+                            acc2[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2[i][jn], 0, 0, 0);
+                        else
+                            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jn], 0, 0, 0);
                         const int m = (s * TM + i) * TN + jn;  // MFMA index in the chunk, 0..NM-1
 #pragma unroll
                         for (int pc = m * NP / NM; pc < (m + 1) * NP / NM; ++pc) {
@@ -289,6 +311,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvParams p) {
                 }
             }
         }
+    };
+    if constexpr (!SPLIT) {
+        for (int kt = 0; kt < nk; ++kt) ktile(std::integral_constant<int, 0>{}, kt);
+    } else {
+        constexpr int TPB = 32 / BK;   // k tiles per 32-wide k block: 1 (BK = 32) or 2 (BK = 16)
+        static_assert(BK == 32 || BK == 16, "SPLIT: chains are 32-wide k blocks");
+        for (int kt = 0; kt < nk; kt += 2 * TPB) {
+#pragma unroll
+            for (int u = 0; u < TPB; ++u)
+                if (kt + u < nk) ktile(std::integral_constant<int, 0>{}, kt + u);
+#pragma unroll
+            for (int u = 0; u < TPB; ++u)
+                if (kt + TPB + u < nk) ktile(std::integral_constant<int, 1>{}, kt + TPB + u);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
     }
 
     if constexpr (RES == 5) {
@@ -468,6 +510,15 @@ int launch_pw_stream(ConvParams p, hipStream_t stream) {
     return mrcnn::check_launch("conv_pw_stream_f32");
 }
 
+// K >= this and one of the three tiles the long-K layers take (128x128 BK32, 128x64 BK16, 128x32 BK32), aligned-tap or
+// pointwise mode, epilogues 0-2: the two-chain sum (see SPLIT at the kernel)
+constexpr int SPLIT_MIN_K = 1024;
+template <int BM, int BN, int WM, int WN, int BK>
+constexpr bool split_tile() {
+    return (BM == 128 && BN == 128 && WM == 2 && WN == 2 && BK == 32) || (BM == 128 && BN == 64 && WM == 2 && WN == 2 && BK == 16) ||
+           (BM == 128 && BN == 32 && WM == 4 && WN == 1 && BK == 32);
+}
+
 template <int BM, int BN, int WM, int WN, int BK>
 int launch_conv(ConvParams p, int mode, hipStream_t stream) {  // mode: 0 aligned taps, 1 generic, 2 pointwise
     const bool generic = mode == 1;
@@ -495,6 +546,20 @@ int launch_conv(ConvParams p, int mode, hipStream_t stream) {  // mode: 0 aligne
     (void)generic;
 #endif
     if (res == 5) return mrcnn::fail(MRCNN_ERR_UNSUPPORTED, "conv: the fused-heads epilogue exists in MRCNN_ABLATIONS builds only");
+    if constexpr (split_tile<BM, BN, WM, WN, BK>()) {
+        static const bool no_split = getenv("MRCNN_CONV_NO_SPLIT") != nullptr;   // A/B switch (numerics), read once per process
+        if (p.K >= SPLIT_MIN_K && mode != 1 && res <= 2 && !no_split) {
+            auto by_res_split = [&](auto mode_tag) -> int {
+                constexpr int MD = decltype(mode_tag)::value;
+                return res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, MD, 0, true>)
+                     : res == 1 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, MD, 1, true>)
+                                : go(conv_igemm_f32<BM, BN, WM, WN, BK, MD, 2, true>);
+            };
+            rc = mode == 2 ? by_res_split(std::integral_constant<int, 2>{}) : by_res_split(std::integral_constant<int, 0>{});
+            if (rc) return rc;
+            return mrcnn::check_launch("conv_igemm_f32<split>");
+        }
+    }
     auto by_res = [&](auto mode_tag) -> int {
         constexpr int MD = decltype(mode_tag)::value;
         return res == 0 ? go(conv_igemm_f32<BM, BN, WM, WN, BK, MD, 0>)

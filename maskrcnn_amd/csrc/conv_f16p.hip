@@ -572,6 +572,13 @@ extern "C" int mrcnn_conv_f16_pipelined(const void* x_f16, int32_t batch, int32_
         }
     }
     int nwt = tile_cols ? tile_cols / 64 : (cout % 256 == 0 && !(p.K <= 256 && few_tiles)) ? 4 : (cout % 128 == 0 ? 2 : 1);
+    // Small maps (P5 / P6 of configs[4]: M = 8 736 / 2 184 rows): when even 128-row tiles of this width leave more than half the CUs
+    // without a workgroup, narrower tiles — two workgroups per CU — fill the chip (round 5, tools/f16_small_probe.py: P5 lateral
+    // 31.5 -> 23.0 us, P5 smoothing 33.5 -> 25.5, RPN P6 32.2 -> 23.0; layers with >= cus / 2 tiles are best where they are).
+    // The tile never changes a result (same operands, same k order per output element).
+    if (!tile_cols && !tile_rows) {
+        while (nwt > 1 && ((p.M + 127) / 128) * static_cast<long long>(cout / (64 * nwt)) < cus / 2) nwt >>= 1;
+    }
     int tmw = tile_rows ? tile_rows / 32 : 0;
     if (!tmw) tmw = nwt == 4 ? pick_rows(p.M, cout, cus) : 4;
     MRCNN_REQUIRE((tile_cols == 0 || tile_cols == 64 * nwt) && (tile_rows == 0 || tile_rows == 32 * tmw) && nwt >= 1 &&

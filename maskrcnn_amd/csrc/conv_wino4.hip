@@ -77,6 +77,13 @@ struct Wino4Params {
     int debug;  // MRCNN_W4_DEBUG: timing ablations (wrong results): 1 no DMA, 2 no transform, 4 no patch reads, 8 no B reads, 16 no raw staging
 };
 
+// The wait in front of the barrier that publishes a staged k tile: every LDS-DMA of this wave has landed; the three raw loads
+// issued last may stay in flight. -DMRCNN_W4_VMCNT0 (diagnostic build): wait for everything.
+#ifdef MRCNN_W4_VMCNT0
+#define W4_STAGE_WAIT_AND_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define W4_STAGE_WAIT_AND_BARRIER() asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 constexpr int W4_N = 64;                              // output channels per workgroup
 #ifndef MRCNN_W4_WALK_SHIFT
 #define MRCNN_W4_WALK_SHIFT 4
@@ -427,7 +434,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) load_raw1(2, i);
-        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        W4_STAGE_WAIT_AND_BARRIER();
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
             read_col(0, c);
@@ -473,7 +480,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            W4_STAGE_WAIT_AND_BARRIER();
             tie_b(NXT);
         };
         STAMP();  // 2: prologue done

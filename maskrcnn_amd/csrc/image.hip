@@ -58,6 +58,15 @@ __device__ __forceinline__ unsigned clip8(int v) {
     v >>= PRECISION_BITS;
     return static_cast<unsigned>(v < 0 ? 0 : v > 255 ? 255 : v);
 }
+// clip8 for values that are PACKED into a word (b0 | b1 << 8 | ...): the compiler fuses two shift + clamp + pack steps into
+// gfx950's v_ashr_pk_u8_i32, whose result it then ORs the next bytes onto as if bits 16-31 were zero — on the MI355X they are
+// not (they keep what the destination register held: measured, round 5: bytes 2 and 3 of every packed word came out OR-ed with
+// stale bits). Making each clamped value opaque before it is shifted into place keeps the plain shift / clamp / or sequence.
+__device__ __forceinline__ unsigned clip8_for_packing(int v) {
+    unsigned c = clip8(v);
+    asm volatile("" : "+v"(c));
+    return c;
+}
 
 __global__ __launch_bounds__(256) void coeffs_kernel(const Axis a, int* __restrict__ bounds, int* __restrict__ kk) {
     const int xx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -111,6 +120,77 @@ __global__ __launch_bounds__(256) void resample_v_u8(const uint8_t* __restrict__
     }
 }
 
+// ---- the same two passes, shaped for bandwidth (round 5: detect() decodes hundreds of full-size masks per batch) -------------
+// Horizontal, single-channel images: a thread owns FOUR consecutive output columns — their taps and coefficients live in
+// registers for all the rows it walks — and writes them as one 32-bit store (a wave: 256 contiguous bytes per row). Taps beyond
+// a column's count carry coefficient 0 and a clamped index, so the loads of a row are independent of the counts.
+// grid (column groups of 1024, row chunks of ROWS), block 256. Needs out_w % 4 == 0 and ksize <= 3 (not shrinking by > 1... the
+// BILINEAR support is 1 when enlarging: at most three taps); the generic kernel above takes every other case.
+constexpr int RH_ROWS = 16;
+__global__ __launch_bounds__(256) void resample_h1_u8_fast(const uint8_t* __restrict__ src, int total_rows, int in_h, int in_w,
+                                                           int64_t image_stride, int64_t row_stride, int out_w,
+                                                           const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                           uint8_t* __restrict__ tmp) {
+    const int x4 = (blockIdx.y * 256 + threadIdx.x) * 4;   // (rows on grid.x: hundreds of thousands of them; columns on grid.y)
+    if (x4 >= out_w) return;
+    int i0[4], i1[4], i2[4], k0[4], k1[4], k2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xx = x4 + j;
+        const int xmin = bounds[2 * xx];
+        i0[j] = xmin;
+        i1[j] = min(xmin + 1, in_w - 1);
+        i2[j] = min(xmin + 2, in_w - 1);
+        k0[j] = kk[xx * 3];
+        k1[j] = kk[xx * 3 + 1];
+        k2[j] = kk[xx * 3 + 2];
+    }
+    const int y_lo = blockIdx.x * RH_ROWS, y_hi = min(y_lo + RH_ROWS, total_rows);
+    for (int yg = y_lo; yg < y_hi; ++yg) {
+        const int img = yg / in_h, y = yg - img * in_h;
+        const uint8_t* s = src + img * image_stride + y * row_stride;
+        unsigned packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ss = (1 << (PRECISION_BITS - 1)) + s[i0[j]] * k0[j] + s[i1[j]] * k1[j] + s[i2[j]] * k2[j];
+            packed |= clip8_for_packing(ss) << (8 * j);
+        }
+        *reinterpret_cast<unsigned*>(tmp + static_cast<int64_t>(yg) * out_w + x4) = packed;
+    }
+}
+
+// Vertical, any channel count (a row is just `row` bytes): a thread owns SIXTEEN consecutive bytes of an output row — one 16-byte
+// load per tap row, one 16-byte store; the row's taps and coefficients are wave-uniform. grid (16-byte groups / 256, output
+// rows of all images), block 256. Needs row % 16 == 0 and 16-byte aligned buffers.
+__global__ __launch_bounds__(256) void resample_v_u8_fast(const uint8_t* __restrict__ tmp, int64_t row, int total_rows, int in_h, int out_h,
+                                                          const int* __restrict__ bounds, const int* __restrict__ kk,
+                                                          int ksize, uint8_t* __restrict__ dst) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    // short rows: several output rows per block (rpb of them, G = groups per row each), long rows: column blocks on grid.y
+    const int G = static_cast<int>((row / 16 < 256 ? row / 16 : 256)), rpb = 256 / G;
+    const int r = threadIdx.x / G, gi = threadIdx.x - r * G;
+    const int64_t xe = (static_cast<int64_t>(blockIdx.y) * 256 + gi) * 16;
+    const int yg = blockIdx.x * rpb + r;
+    if (r >= rpb || xe >= row || yg >= total_rows) return;
+    const int img = yg / out_h, yy = yg - img * out_h;
+    const int ymin = bounds[2 * yy], cnt = bounds[2 * yy + 1];
+    const int* k = kk + static_cast<int64_t>(yy) * ksize;
+    const uint8_t* s = tmp + (static_cast<int64_t>(img) * in_h + ymin) * row + xe;
+    int acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 1 << (PRECISION_BITS - 1);
+    for (int t = 0; t < cnt; ++t) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(s + t * row);
+        const int kt = k[t];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] += static_cast<int>((v[j >> 2] >> (8 * (j & 3))) & 255u) * kt;
+    }
+    u32x4 o = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j >> 2] |= clip8_for_packing(acc[j]) << (8 * (j & 3));
+    *reinterpret_cast<u32x4*>(dst + static_cast<int64_t>(yg) * row + xe) = o;
+}
+
 // Vertical pass (or a plain read when RESIZE is false) fused with centre padding, mean subtraction and HWC -> CHW:
 // dst[ch][oy][ox] = float(double(pixel) - mean[ch]); pad pixels are 0 before the subtraction (utils.py:86,
 // model.py:1754: MEAN_PIXEL is a float64 array, so the reference subtracts in double and narrows afterwards).
@@ -118,9 +198,11 @@ template <bool RESIZE>
 __global__ __launch_bounds__(256) void mold_kernel(const uint8_t* __restrict__ img, int new_h, int new_w, int top,
                                                    int left, int out_h, int out_w, const int* __restrict__ bounds,
                                                    const int* __restrict__ kk, int ksize, double m0, double m1,
-                                                   double m2, float* __restrict__ dst) {
+                                                   double m2, float* __restrict__ dst, int64_t img_stride) {
     const int64_t plane = static_cast<int64_t>(out_h) * out_w;
     const int64_t row = static_cast<int64_t>(new_w) * 3;
+    img += blockIdx.y * img_stride;            // image blockIdx.y of a batch of equally sized images
+    dst += blockIdx.y * 3 * plane;
     for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < plane;
          e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const int oy = static_cast<int>(e / out_w), ox = static_cast<int>(e - static_cast<int64_t>(oy) * out_w);
@@ -172,12 +254,20 @@ unsigned blocks_for(int64_t n) {
 // coefficient tables + horizontal pass; leaves the intermediate at workspace[0..)
 int run_horizontal(const uint8_t* src, int n, int in_h, int in_w, int c, int64_t image_stride, int64_t row_stride,
                    int out_h, int out_w, const ResizePlan& p, unsigned char* ws, hipStream_t s) {
+    (void)out_h;
     int* bh = reinterpret_cast<int*>(ws + p.off_bh);
     int* kh = reinterpret_cast<int*>(ws + p.off_kh);
     int* bv = reinterpret_cast<int*>(ws + p.off_bv);
     int* kv = reinterpret_cast<int*>(ws + p.off_kv);
     hipLaunchKernelGGL(coeffs_kernel, dim3((out_w + 255) / 256), dim3(256), 0, s, p.ah, bh, kh);
     hipLaunchKernelGGL(coeffs_kernel, dim3((out_h + 255) / 256), dim3(256), 0, s, p.av, bv, kv);
+    if (c == 1 && p.ah.ksize == 3 && out_w % 4 == 0) {
+        const dim3 grid(static_cast<unsigned>((static_cast<int64_t>(n) * in_h + RH_ROWS - 1) / RH_ROWS),
+                        static_cast<unsigned>((out_w / 4 + 255) / 256));
+        hipLaunchKernelGGL(resample_h1_u8_fast, grid, dim3(256), 0, s, src, n * in_h, in_h, in_w, image_stride, row_stride, out_w,
+                           bh, kh, ws);
+        return mrcnn::check_launch("resample_h1_u8_fast");
+    }
     hipLaunchKernelGGL(resample_h_u8, dim3(blocks_for(static_cast<int64_t>(n) * in_h * out_w * c)), dim3(256), 0, s,
                        src, n, in_h, c, image_stride, row_stride, out_w, bh, kh, p.ah.ksize, ws);
     return mrcnn::check_launch("resample_h_u8");
@@ -355,38 +445,57 @@ extern "C" int mrcnn_resize_bilinear_u8(const uint8_t* src, int32_t n, int32_t i
     if (int rc = run_horizontal(src, n, in_h, in_w, channels, src_image_stride, src_row_stride, out_h, out_w, p, ws, s))
         return rc;
     const int64_t row = static_cast<int64_t>(out_w) * channels;
+    if (row % 16 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+        const int G = static_cast<int>(row / 16 < 256 ? row / 16 : 256), rpb = 256 / G;
+        const int64_t total_rows = static_cast<int64_t>(n) * out_h;
+        const dim3 grid(static_cast<unsigned>((total_rows + rpb - 1) / rpb), static_cast<unsigned>((row / 16 + 255) / 256));
+        hipLaunchKernelGGL(resample_v_u8_fast, grid, dim3(256), 0, s, ws, row, static_cast<int>(total_rows), in_h, out_h,
+                           reinterpret_cast<const int*>(ws + p.off_bv), reinterpret_cast<const int*>(ws + p.off_kv), p.av.ksize, dst);
+        return mrcnn::check_launch("resample_v_u8_fast");
+    }
     hipLaunchKernelGGL(resample_v_u8, dim3(blocks_for(row * out_h * n)), dim3(256), 0, s, ws, row, n, in_h, out_h,
                        reinterpret_cast<const int*>(ws + p.off_bv), reinterpret_cast<const int*>(ws + p.off_kv),
                        p.av.ksize, dst);
     return mrcnn::check_launch("resample_v_u8");
 }
 
-extern "C" int mrcnn_mold_image_u8(const uint8_t* src, int32_t in_h, int32_t in_w, int32_t new_h, int32_t new_w,
-                                   int32_t top, int32_t left, int32_t out_h, int32_t out_w, const double mean_pixel[3],
-                                   float* dst, void* workspace, size_t workspace_bytes, mrcnn_stream_t stream) {
+extern "C" int mrcnn_mold_images_u8(const uint8_t* src, int32_t n, int64_t src_image_stride, int32_t in_h, int32_t in_w,
+                                    int32_t new_h, int32_t new_w, int32_t top, int32_t left, int32_t out_h, int32_t out_w,
+                                    const double mean_pixel[3], float* dst, void* workspace, size_t workspace_bytes,
+                                    mrcnn_stream_t stream) {
     MRCNN_REQUIRE(src && dst && mean_pixel, "mold_image: null pointer");
+    MRCNN_REQUIRE(n >= 1 && n <= 65535 && src_image_stride >= static_cast<int64_t>(in_h) * in_w * 3, "mold_image: n=%d / image stride", n);
     MRCNN_REQUIRE(resize_args_ok(in_h, in_w, 3, new_h, new_w) && out_h >= 1 && out_w >= 1 && out_h <= 16384 &&
                       out_w <= 16384, "mold_image: bad shape");
     MRCNN_REQUIRE(top >= 0 && left >= 0 && top + new_h <= out_h && left + new_w <= out_w,
                   "mold_image: the resized image (%dx%d at %d,%d) does not fit the %dx%d output", new_h, new_w, top,
                   left, out_h, out_w);
     hipStream_t s = mrcnn::as_stream(stream);
-    const unsigned grid = blocks_for(static_cast<int64_t>(out_h) * out_w);
+    const dim3 grid(blocks_for(static_cast<int64_t>(out_h) * out_w), static_cast<unsigned>(n));
     if (new_h == in_h && new_w == in_w) {  // scale == 1 (utils.py:72): no resample at all
-        hipLaunchKernelGGL(mold_kernel<false>, dim3(grid), dim3(256), 0, s, src, new_h, new_w, top, left, out_h, out_w,
-                           nullptr, nullptr, 0, mean_pixel[0], mean_pixel[1], mean_pixel[2], dst);
+        hipLaunchKernelGGL(mold_kernel<false>, grid, dim3(256), 0, s, src, new_h, new_w, top, left, out_h, out_w,
+                           nullptr, nullptr, 0, mean_pixel[0], mean_pixel[1], mean_pixel[2], dst, src_image_stride);
         return mrcnn::check_launch("mold_kernel");
     }
-    const ResizePlan p = plan_resize(1, in_h, in_w, 3, new_h, new_w);
+    const ResizePlan p = plan_resize(n, in_h, in_w, 3, new_h, new_w);
     MRCNN_REQUIRE(workspace && workspace_bytes >= p.total, "mold_image: workspace too small (%zu < %zu)",
                   workspace_bytes, p.total);
     unsigned char* ws = static_cast<unsigned char*>(workspace);
-    if (int rc = run_horizontal(src, 1, in_h, in_w, 3, 0, static_cast<int64_t>(in_w) * 3, new_h, new_w, p, ws, s))
+    if (int rc = run_horizontal(src, n, in_h, in_w, 3, src_image_stride, static_cast<int64_t>(in_w) * 3, new_h, new_w, p, ws, s))
         return rc;
-    hipLaunchKernelGGL(mold_kernel<true>, dim3(grid), dim3(256), 0, s, ws, new_h, new_w, top, left, out_h, out_w,
+    // the horizontal pass left image i's rows at ws + i * in_h * new_w * 3
+    hipLaunchKernelGGL(mold_kernel<true>, grid, dim3(256), 0, s, ws, new_h, new_w, top, left, out_h, out_w,
                        reinterpret_cast<const int*>(ws + p.off_bv), reinterpret_cast<const int*>(ws + p.off_kv),
-                       p.av.ksize, mean_pixel[0], mean_pixel[1], mean_pixel[2], dst);
+                       p.av.ksize, mean_pixel[0], mean_pixel[1], mean_pixel[2], dst,
+                       static_cast<int64_t>(in_h) * new_w * 3);
     return mrcnn::check_launch("mold_kernel");
+}
+
+extern "C" int mrcnn_mold_image_u8(const uint8_t* src, int32_t in_h, int32_t in_w, int32_t new_h, int32_t new_w,
+                                   int32_t top, int32_t left, int32_t out_h, int32_t out_w, const double mean_pixel[3],
+                                   float* dst, void* workspace, size_t workspace_bytes, mrcnn_stream_t stream) {
+    return mrcnn_mold_images_u8(src, 1, static_cast<int64_t>(in_h) * in_w * 3, in_h, in_w, new_h, new_w, top, left, out_h, out_w,
+                                mean_pixel, dst, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mrcnn_paste_masks_u8(const float* masks, int64_t stride_n, int64_t stride_y, int64_t stride_x,

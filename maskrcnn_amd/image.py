@@ -51,19 +51,35 @@ def _to_device_u8(image, device) -> torch.Tensor:
 def mold_inputs(images, cfg: InferenceConfig, device="cuda:0"):
     """A list of RGB uint8 [h,w,3] images (numpy or torch, any sizes) → molded fp32 [B,3,H,W] on the device, int
     windows [B,4], and per-image (scale, padding, original (h,w)) — detect()'s pre-processing (model.py:1097-1110)
-    for a batch. Needs a square canvas, like the reference (IMAGE_MAX_DIM x IMAGE_MAX_DIM)."""
+    for a batch. Needs a square canvas, like the reference (IMAGE_MAX_DIM x IMAGE_MAX_DIM). Images of one size are molded
+    TOGETHER (one host-to-device copy, one set of launches per size: ops.mold_images_u8), in whatever order they come."""
     if cfg.image_height != cfg.image_width or cfg.image_height != cfg.image_max_dim:
         raise RuntimeError("mold_inputs: resize_image pads to IMAGE_MAX_DIM x IMAGE_MAX_DIM; configure a square canvas "
                            "of image_max_dim, or mold images yourself")
     device = torch.device(device)
     out = torch.empty(len(images), 3, cfg.image_height, cfg.image_width, dtype=torch.float32, device=device)
-    windows, metas = [], []
+    windows, metas, groups = [], [], {}
     for i, image in enumerate(images):
+        if tuple(image.shape[2:]) != (3,) or len(image.shape) != 3 or image.dtype not in (torch.uint8, np.uint8):
+            raise RuntimeError(f"expected an RGB uint8 [h,w,3] image, got {image.dtype} {tuple(image.shape)}")
         h, w = int(image.shape[0]), int(image.shape[1])
         new_h, new_w, window, scale, padding = resize_plan(h, w, cfg.image_min_dim, cfg.image_max_dim, True)
-        ops.mold_image_u8(_to_device_u8(image, device), new_h, new_w, window[0], window[1], out[i], cfg.mean_pixel)
         windows.append(window)
         metas.append((scale, padding, (h, w)))
+        groups.setdefault((h, w), []).append(i)
+    for (h, w), idx in groups.items():
+        new_h, new_w, window, _, _ = resize_plan(h, w, cfg.image_min_dim, cfg.image_max_dim, True)
+        members = [images[i] for i in idx]
+        if all(isinstance(m, np.ndarray) for m in members):
+            stack = torch.from_numpy(np.stack(members)).to(device, non_blocking=True)          # one copy for the group
+        else:
+            stack = torch.stack([_to_device_u8(m, device) for m in members])
+        whole = idx == list(range(idx[0], idx[0] + len(idx)))                                   # a contiguous run of the batch
+        dst = out[idx[0]:idx[0] + len(idx)] if whole else torch.empty(len(idx), 3, cfg.image_height, cfg.image_width,
+                                                                      dtype=torch.float32, device=device)
+        ops.mold_images_u8(stack.contiguous(), new_h, new_w, window[0], window[1], dst, cfg.mean_pixel)
+        if not whole:
+            out[torch.tensor(idx, device=device)] = dst
     return out, torch.tensor(windows, dtype=torch.int64), metas
 
 

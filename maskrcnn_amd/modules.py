@@ -534,6 +534,11 @@ class FusedBackbone:
         if (self.kblocked[3] is not None and self.kblocked[3].dim() == 5 and p6.size(1) % 2 == 0 and p6.size(2) % 2 == 0
                 and p6.size(3) % 8 == 0):
             p6k = ops.maxpool(outs[3], 1, 2, out_kblocked=True)
+        elif (self.kblocked[3] is not None and self.kblocked[3].dim() == 4 and self.kblocked[3].dtype == torch.float16):
+            # "f16" mode (round 5): the RPN's shared conv reads an fp16 copy of every level; P6's is the same subsample of the
+            # fp16 copy of P5 (the values the conv would round the fp32 map to), so the level runs the pipelined kernel like the
+            # others instead of the round-1 kernel on the fp32 map (62 us for 2 184 pixels)
+            p6k = ops.maxpool(self.kblocked[3], 1, 2)
         self.kblocked.append(p6k)
         return outs
 

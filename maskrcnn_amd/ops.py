@@ -1121,6 +1121,24 @@ def mold_image_u8(image: torch.Tensor, new_h: int, new_w: int, top: int, left: i
 
 
 @_on_device
+def mold_images_u8(images: torch.Tensor, new_h: int, new_w: int, top: int, left: int, out: torch.Tensor, mean_pixel) -> None:
+    """n RGB images of ONE size, uint8 [n,h,w,3] contiguous → out fp32 [n,3,H,W]: mold_image_u8 for a whole batch in one set of
+    launches (coefficient tables, horizontal pass, vertical + mold pass)."""
+    _need_gpu(images, out)
+    if images.dtype != torch.uint8 or images.dim() != 4 or images.size(3) != 3 or not images.is_contiguous():
+        raise RuntimeError(f"mold_images_u8: expected contiguous uint8 [n,h,w,3], got {images.dtype} {tuple(images.shape)}")
+    n, h, w = images.shape[:3]
+    assert out.dtype == torch.float32 and out.dim() == 4 and out.size(0) == n and out.size(1) == 3 and out.is_contiguous()
+    nbytes, ws = 0, None
+    if (new_h, new_w) != (h, w):
+        nbytes = int(lib.mrcnn_resize_u8_workspace_bytes(n, h, w, 3, new_h, new_w))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=images.device)
+    mean = (ctypes.c_double * 3)(*[float(m) for m in mean_pixel])
+    check(lib.mrcnn_mold_images_u8(images.data_ptr(), n, h * w * 3, h, w, new_h, new_w, top, left, out.size(2), out.size(3), mean,
+                                   out.data_ptr(), _ptr(ws), nbytes, _stream()))
+
+
+@_on_device
 def paste_masks(masks: torch.Tensor, class_ids: torch.Tensor, boxes: torch.Tensor, height: int, width: int,
                 channels_last: bool, as_l8: bool = False) -> torch.Tensor:
     """datalib.full_masks (data.py:287-314) for N detections in one launch → bool [N,height,width] (as_l8: the same

@@ -122,12 +122,14 @@ class MaskRCNNInference:
     # ---------------------------------------------------------------- whole step
     @torch.no_grad()
     def predict(self, images: torch.Tensor, windows: torch.Tensor, with_masks: bool = True,
-                return_intermediates: bool = False, rois_override=None):
+                return_intermediates: bool = False, rois_override=None, host_counts=None):
         """images [B,3,H,W] fp32 NCHW, already molded (resized/padded, mean-subtracted: model.py:1102-1110);
         windows [B,4] pixel (y1,x1,y2,x2) of the un-padded image area.
         rois_override = (rois [B,P,4] normalised, counts int32 [B]): measurement aid (SURVEY.md §8d "synthetic input —
         proposals"): the proposal stage still runs — its launches stay in the step — but the heads see these RoIs instead of
-        its output, e.g. proposal_count VALID proposals per image whatever random weights make of the RPN."""
+        its output, e.g. proposal_count VALID proposals per image whatever random weights make of the RPN.
+        host_counts = (pinned int32 tensor [>= B], torch.cuda.Event): the detection counts are copied there (asynchronously)
+        and the event recorded as soon as they exist, ahead of the mask head (detect() uses it)."""
         c = self.cfg
         assert images.is_cuda and images.dtype == torch.float32
         b = images.size(0)
@@ -137,6 +139,7 @@ class MaskRCNNInference:
             # equals image i alone bit for bit — but the kernels address tensors with 32-bit element offsets (< 2^30 elements),
             # so past max_batch a layer would fall to another kernel. Oversized batches therefore run as equal sub-batches.
             assert not return_intermediates, f"return_intermediates needs batch <= {self.max_batch} at this image size"
+            assert host_counts is None, "host_counts: one launch group per call (batch <= max_batch)"
             n = -(-b // self.max_batch)
             step = -(-b // n)
             ro = rois_override
@@ -165,6 +168,12 @@ class MaskRCNNInference:
         logits, bbox = self.classifier(pooled, skip, p)
         ids, det_scores, boxes, mrois, counts = self.detections(rois, roi_counts, logits, bbox,
                                                                 windows.to(self.device))
+        if host_counts is not None:
+            # detect(): the detection counts start their way to the host HERE, before the mask head is enqueued — by the time the
+            # host has them (one event wait) the GPU still has the mask head to run, so building the per-image index lists and
+            # enqueueing the paste / decode launches costs the GPU no idle time
+            host_counts[0][:b].copy_(counts, non_blocking=True)
+            host_counts[1].record()
         masks = None
         if with_masks:
             d = boxes.size(1)
@@ -187,31 +196,69 @@ class MaskRCNNInference:
 
     # ---------------------------------------------------------------- images in, full-size masks out
     @torch.no_grad()
-    def detect(self, images):
+    def detect(self, images, timings: dict | None = None):
         """MaskRCNN.detect (model.py:1095-1138) for a list of RGB uint8 [h,w,3] images of any sizes: resize + pad +
         mean-subtract on the GPU (utils.resize_image, mold_image), predict, paste the masks at full size
         (datalib.full_masks, which the reference calls inside predict, model.py:1190) and map boxes and masks back
-        to each original image (decode_boxes / decode_masks). One host synchronisation, at the end, to size the
-        per-image results. → per image (class_ids [n], scores [n], boxes [n,4], masks [n,h',w']) device tensors, or
-        (None, None, None, None) when nothing was detected (model.py:1119-1120). The reference returns Python
-        lists (:1132-1135); masks are bool when scale == 1 and uint8 grey levels otherwise, as in the reference."""
+        to each original image (decode_boxes / decode_masks). ONE host synchronisation per batch (the detection counts, to
+        size the per-image results); pasting and decoding run once per group of images that share a size — one launch per
+        stage for a batch from one source — over the VALID detections of the group only. → per image (class_ids [n],
+        scores [n], boxes [n,4], masks [n,h',w']) device tensors (views of the batch's tensors), or (None, None, None, None)
+        when nothing was detected (model.py:1119-1120). The reference returns Python lists (:1132-1135); masks are bool when
+        scale == 1 and uint8 grey levels otherwise, as in the reference.
+        timings: filled with HIP-event milliseconds of the three stages (mold / predict / paste + decode) when given."""
         c = self.cfg
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timings is not None else None
+        if ev:
+            ev[0].record()
         molded, windows, metas = imagelib.mold_inputs(images, c, self.device)
-        det = self.predict(molded, windows)
-        counts = det.counts.tolist()
-        results = []
-        for b, n in enumerate(counts):
-            if n == 0:
-                results.append((None, None, None, None))
-                continue
-            scale, _, _ = metas[b]
-            window = tuple(int(v) for v in windows[b])
-            ids, scores, boxes = det.class_ids[b, :n], det.scores[b, :n], det.boxes[b, :n]
-            m28 = det.masks[b, :n]                                             # [n,28,28,C] NHWC
+        if ev:
+            ev[1].record()
+        nb = molded.size(0)
+        if nb <= self.max_batch:
+            if getattr(self, "_host_counts", None) is None or self._host_counts[0].numel() < nb:
+                self._host_counts = (torch.empty(max(nb, 64), dtype=torch.int32).pin_memory(), torch.cuda.Event())
+            det = self.predict(molded, windows, host_counts=self._host_counts)
+            if ev:
+                ev[2].record()
+            self._host_counts[1].synchronize()                                  # the one host synchronisation (counts only)
+            counts = self._host_counts[0][:nb].tolist()
+        else:
+            det = self.predict(molded, windows)
+            if ev:
+                ev[2].record()
+            counts = det.counts.tolist()
+        b, d = det.class_ids.shape
+        windows_l = windows.tolist()
+        results = [(None, None, None, None)] * b
+        # the class channel of every detection's mask, [B*D, mh, mw]: what the paste reads (one gather for the batch)
+        m = det.masks.view(b * d, det.masks.size(2), det.masks.size(3), det.masks.size(4))
+        ids_flat = det.class_ids.reshape(-1)
+        m_cls = torch.gather(m, 3, ids_flat.clamp(min=0).view(-1, 1, 1, 1).expand(-1, m.size(1), m.size(2), 1)).squeeze(3)
+        groups = {}
+        for i, n in enumerate(counts):
+            if n > 0:
+                groups.setdefault((metas[i][0], tuple(windows_l[i])), []).append(i)
+        for (scale, window), idx in groups.items():
+            rows = torch.tensor([i * d + j for i in idx for j in range(counts[i])], dtype=torch.int64).to(self.device, non_blocking=True)
+            g_masks = m_cls.index_select(0, rows).unsqueeze(3)                  # [N,mh,mw,1]: class 0 of a one-class tensor
+            g_boxes = det.boxes.reshape(-1, 4).index_select(0, rows)
+            zeros = torch.zeros(rows.numel(), dtype=torch.int64, device=self.device)
             if scale == 1:
-                masks = ops.paste_masks(m28, ids, boxes, c.image_height, c.image_width, channels_last=True)
+                pasted = ops.paste_masks(g_masks, zeros, g_boxes, c.image_height, c.image_width, channels_last=True)
+                out_boxes = g_boxes
             else:
-                l8 = ops.paste_masks(m28, ids, boxes, c.image_height, c.image_width, channels_last=True, as_l8=True)
-                masks = imagelib.decode_masks(l8, scale, window)
-            results.append((ids, scores, imagelib.decode_boxes(boxes, scale, window), masks))
+                l8 = ops.paste_masks(g_masks, zeros, g_boxes, c.image_height, c.image_width, channels_last=True, as_l8=True)
+                pasted = imagelib.decode_masks(l8, scale, window)
+                out_boxes = imagelib.decode_boxes(g_boxes, scale, window)
+            off = 0
+            for i in idx:
+                n = counts[i]
+                results[i] = (det.class_ids[i, :n], det.scores[i, :n], out_boxes[off:off + n], pasted[off:off + n])
+                off += n
+        if ev:
+            ev[3].record()
+            torch.cuda.synchronize()
+            timings.update(mold_ms=ev[0].elapsed_time(ev[1]), predict_ms=ev[1].elapsed_time(ev[2]),
+                           paste_decode_ms=ev[2].elapsed_time(ev[3]))
         return results

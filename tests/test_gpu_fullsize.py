@@ -261,42 +261,51 @@ def _fp64_truth(oracle, image, sd, arch):
         return oracle.fpn_forward(image.double(), sd64, arch)
 
 
-def _fp64_rows(key, truth, got, want32, factor=3.0):
-    """Per level: max / rms of |HIP - fp64| and |oracle_fp32 - fp64| → REPORT. Asserted: max|HIP - fp64| <= factor x max|oracle_fp32
-    - fp64| and the same for the rms (or 1e-4 abs, whichever is larger); factor 3 in exact fp32 (measured 1.8 - 2.2 x; the
-    oracle's own distance depends on the host's oneDNN blocking, so the bar leaves room for another CPU), 3.5 for the f32+f16x3
-    alt mode (22-bit-significand products on the long-K layers: measured 2.2 - 2.6 x). Measured on the MI355X (profiles/r04_fp64_truth.jsonl): the
-    reference's own arithmetic (torch-CPU fp32) is 6 - 9 ulps of the activation range from the truth (1.6e-4 abs at |act| 210,
-    7.2e-4 at 650: ABOVE 1e-4 abs on its own), the HIP trunk 13 - 17 ulps = 1.8 - 2.2 x that (rms 1.8 - 2.0 x) — and the exact
-    direct kernel everywhere (MRCNN_WINOGRAD=0, bitwise one fmaf chain over K per output) 25 - 35 ulps: the distance is the
-    length of the sequential fp32 accumulation, not the Winograd transforms, which shorten it."""
+FP64_MAX_BAR = 2.5e-6   # max|HIP - fp64| <= 2.5e-6 * max|fp64| per pyramid level = 21 ulps (2^-23) of the level's range
+FP64_RMS_BAR = 5.0e-7   # rms(HIP - fp64) <= 5e-7 * max|fp64|
+
+
+def _fp64_rows(key, truth, got, want32):
+    """Per level: max / rms of |HIP - fp64| and |oracle_fp32 - fp64| → REPORT. Asserted — a bar that does not depend on the host
+    the oracle runs on (round 4's was a ratio to torch-CPU's own error, i.e. fitted to one box's oneDNN blocking): the HIP trunk's
+    distance from the float64 truth is at most FP64_MAX_BAR (2.5e-6) of the level's activation range, its rms at most
+    FP64_RMS_BAR (5e-7) of it. Measured on the MI355X (profiles/r04_fp64_truth.jsonl, r05_parity_fullsize.json): 1.5 - 2.1e-6
+    (13 - 17 ulps) max and 2.3 - 3.5e-7 rms in exact fp32 over both configs, 1.6 - 1.9e-6 / 2.9 - 4.0e-7 for the f32+f16x3 alt
+    mode. The reference's own arithmetic (torch-CPU fp32) is recorded beside it: 6 - 9 ulps of the range (1.6e-4 abs at |act| 210,
+    7.2e-4 at 650: ABOVE north_star's 1e-4 absolute on its own), so the HIP trunk is 1.8 - 2.2 x as far from the truth as the
+    oracle on this host — the length of the sequential fp32 accumulation over K in the MFMA loops (the exact direct kernel
+    everywhere is 25 - 35 ulps; Winograd shortens the sums), attributed per layer by tools/fp64_truth.py --attribute."""
     for lvl, (t, g_, w_) in enumerate(zip(truth, got, want32)):
         eh, eo = (g_.double() - t[0]).abs(), (w_[0].double() - t[0]).abs()
         hip_err, ora_err = eh.max().item(), eo.max().item()
         hip_rms, ora_rms = eh.pow(2).mean().sqrt().item(), eo.pow(2).mean().sqrt().item()
+        rng = t.abs().max().item()
         REPORT[f"{key}/P{lvl + 2}"] = {"max_abs_hip_minus_fp64": hip_err, "max_abs_oracle_fp32_minus_fp64": ora_err,
                                        "rms_hip_minus_fp64": hip_rms, "rms_oracle_fp32_minus_fp64": ora_rms,
-                                       "max_abs_fp64": t.abs().max().item(), "hip_over_oracle_max": hip_err / max(ora_err, 1e-30),
+                                       "max_abs_fp64": rng, "hip_over_oracle_max": hip_err / max(ora_err, 1e-30),
                                        "hip_over_oracle_rms": hip_rms / max(ora_rms, 1e-30),
+                                       "hip_max_over_range": hip_err / rng, "hip_rms_over_range": hip_rms / rng,
+                                       "hip_max_in_ulps_of_range": hip_err / (rng * 2.0 ** -23),
+                                       "bar_max_over_range": FP64_MAX_BAR, "bar_rms_over_range": FP64_RMS_BAR,
                                        "oracle_fp32_meets_1e-4_abs": bool(ora_err <= 1e-4), "hip_meets_1e-4_abs": bool(hip_err <= 1e-4)}
-        assert hip_err <= max(factor * ora_err, 1e-4), (f"{key}/P{lvl + 2}: max|HIP - fp64| {hip_err:.3e} > max({factor} x max|oracle_fp32 "
-                                                        f"- fp64| {ora_err:.3e}, 1e-4)")
-        assert hip_rms <= max(factor * ora_rms, 1e-4), (f"{key}/P{lvl + 2}: rms(HIP - fp64) {hip_rms:.3e} > {factor} x rms(oracle_fp32 - "
-                                                        f"fp64) {ora_rms:.3e}")
+        assert hip_err <= max(FP64_MAX_BAR * rng, 1e-4), (f"{key}/P{lvl + 2}: max|HIP - fp64| {hip_err:.3e} > {FP64_MAX_BAR} x "
+                                                         f"max|fp64| {rng:.1f} (oracle fp32: {ora_err:.3e})")
+        assert hip_rms <= max(FP64_RMS_BAR * rng, 2e-5), (f"{key}/P{lvl + 2}: rms(HIP - fp64) {hip_rms:.3e} > {FP64_RMS_BAR} x "
+                                                         f"max|fp64| {rng:.1f} (oracle fp32: {ora_rms:.3e})")
 
 
 def test_full_size_trunk_against_fp64_truth(full, oracle):
     """What the relative pipeline bar rests on (north_star says 1e-4 ABSOLUTE; at |act| ~ 200 the HIP trunk is 3.5e-4 from the
     fp32 oracle): the same image through the trunk in FLOAT64 on the host. If torch-CPU fp32 — the reference's own arithmetic —
     is itself further than 1e-4 from the true result on this data (it is: 1.6e-4), a 1e-4 ABSOLUTE bar against it measures
-    agreement of rounding sequences, not accuracy, and the honest bar is "as close to the truth as the reference is, within a small
-    factor": see _fp64_rows. Both distances are recorded per level."""
+    agreement of rounding sequences, not accuracy; the bar asserted here is the HIP trunk's own distance from the truth in units
+    of the activation range (_fp64_rows: host-independent). Both distances are recorded per level."""
     s = full
     img = s["images"][:1]
     truth = _fp64_truth(oracle, img, s["sd"], "resnet50")
     want32 = oracle.fpn_forward(img, s["sd"], "resnet50")
     got = [m[0].permute(2, 0, 1).cpu() for m in s["mid"]["feature_maps"]]
-    _fp64_rows(f"{s['tag']}/fp64_truth/img0", truth, got, want32, 3.0 if s["precision"] == "f32" else 3.5)
+    _fp64_rows(f"{s['tag']}/fp64_truth/img0", truth, got, want32)
 
 
 def test_full_size_proposals(full, oracle):
@@ -587,11 +596,103 @@ def test_config5_end_to_end_fp32_exact_and_fp16_detections(dev, oracle):
     REPORT["config5/f16/masks_on_f32_boxes_max_abs_diff"] = merr
     # measured on the MI355X (profiles/r04_parity_fullsize.json): 2.3e-2 — the fp16 trunk's 2e-3-of-range feature error through
     # an fp16 mask head, on sigmoid outputs in [0, 1]
-    assert merr <= 3e-2, merr
-    # measured: 10 of 11 (score differences of the matched <= 2.7e-3); with RANDOM weights a near-tie between two overlapping
-    # proposals of one class can flip which one survives the per-class NMS (model.py:1454-1475), so one miss is tolerated
+    assert merr <= FP16_MASK_BAR, merr
+    # (two images are an anecdote — 10 of 11 in round 4; the RATE over three seeds x eight images is asserted by
+    # test_config5_fp16_detection_agreement_rate below)
     assert matched >= strong - max(1, strong // 8), (f"fp16 path: {matched} of {strong} confident fp32 detections have a same-class "
                                                       f"fp16 detection with IoU >= 0.9 (worst {worst_iou:.3f})")
+
+
+FP16_MASK_BAR = 3e-2   # fp16 mask head on the fp32 path's boxes vs the fp32 masks, sigmoid outputs in [0, 1] (measured 2.3e-2)
+
+
+def test_config5_fp16_detection_agreement_rate(dev):
+    """BASELINE configs[4]'s "fp16 MFMA path" END TO END as a RATE (round 4 rested on 11 detections of two images, one seed):
+    R101-FPN, 832 x 1344, batch 8, three image seeds, calibrated heads. Every fp32 detection with score > 0.5 (the fp32 path's
+    detections equal the oracle's: test above and configs[2]) is looked up among the fp16 path's detections of the same image
+    and class. Asserted over all of them (>= 100): at least 95 % have a same-class fp16 detection with IoU >= 0.9 (measured:
+    127 of 130, score differences of the matched <= 2e-3) and at most 3 % are without one at IoU >= 0.5. Measured: 2 of 130 —
+    both BARELY confident in fp32 (scores 0.507 and 0.501 against the 0.5 cut) and both a different PROPOSAL, not a wrong box: the
+    fp16 path's nearest same-class candidate before its per-class NMS overlaps them by IoU 0.55 / 0.61 with a score of 0.39 / 0.41,
+    i.e. the RoI they came from did not survive the fp16 path's proposal stage (a near-tie in the RPN's top-k / NMS,
+    model.py:1345-1366), and with RANDOM head weights a neighbouring RoI scores differently. Every unmatched case is recorded
+    with these figures.
+    Recorded: the IoU histogram of the best matches, the score-difference histogram of the matched pairs, the unmatched cases."""
+    from maskrcnn_amd import modules
+    from maskrcnn_amd.config import InferenceConfig
+    from maskrcnn_amd.pipeline import MaskRCNNInference
+    h, w, nb = 832, 1344, 8
+    cfg = InferenceConfig(image_height=h, image_width=w, backbone="resnet101", pre_nms_limit=1000, proposal_count=1000,
+                          detection_max_instances=50)
+    sd = modules.synthetic_state_dict("resnet101", seed=0, bn_seed=1)
+    g = torch.Generator().manual_seed(5)
+    sd["classifier.linear_class.weight"] = torch.randn(81, 1024, generator=g) * 0.05
+    sd["classifier.linear_class.bias"] = torch.randn(81, generator=g) * 0.5
+    sd["classifier.linear_bbox.weight"] = torch.randn(324, 1024, generator=g) * 0.02
+    sd["rpn.conv_bbox.bias"] = torch.randn(12, generator=g) * 0.3
+    windows = torch.tensor([[16., 5., 816., 1338.]] * (nb // 2) + [[0., 0., 832., 1344.]] * (nb - nb // 2))
+    best_all, ds_all, per_seed, unmatched = [], [], {}, []
+    net = net16 = None
+    for seed in (55, 56, 57):
+        g0 = torch.Generator().manual_seed(seed)
+        images = (torch.randint(0, 256, (nb, h, w, 3), generator=g0).float() - torch.tensor(cfg.mean_pixel))
+        images = images.permute(0, 3, 1, 2).contiguous()
+        if net is None:   # the heads are calibrated ONCE (first seed); both modes and all seeds then share the weights
+            net, det, _ = _calibrated(cfg, sd, images, windows, dev, "f32")
+            net16 = MaskRCNNInference(sd, cfg, dev, precision="f16")
+        else:
+            det = net.predict(images.to(dev), windows.to(dev))
+        det16, mid16 = net16.predict(images.to(dev), windows.to(dev), return_intermediates=True)
+        torch.cuda.synchronize()
+        # the fp16 path's candidates BEFORE its per-class NMS: decoded boxes, argmax class and score of every proposal
+        from maskrcnn_amd import ops as _ops
+        cand, _, cand_cls = _ops.detection_decode(mid16["logits"], mid16["bbox"], mid16["rois"].contiguous(), mid16["roi_counts"],
+                                                  windows.to(dev).float().contiguous(), cfg.rpn_bbox_std_dev, h, w, 0.0)
+        cand, cand_cls = cand.cpu(), cand_cls.cpu()
+        n_seed = 0
+        for b in range(nb):
+            k, k16 = int(det.counts[b]), int(det16.counts[b])
+            sel = (det.scores[b, :k] > 0.5).nonzero().flatten().cpu()
+            if sel.numel() == 0:
+                continue
+            n_seed += sel.numel()
+            if k16 == 0:
+                best_all += [0.0] * sel.numel()
+                continue
+            iou = _iou_matrix(det.boxes[b, :k].cpu()[sel], det16.boxes[b, :k16].cpu())
+            same = det.class_ids[b, :k].cpu()[sel][:, None] == det16.class_ids[b, :k16].cpu()[None, :]
+            best, arg = (iou * same).max(1)
+            best_all += best.tolist()
+            for j in (best < 0.5).nonzero().flatten().tolist():   # a vanished detection: is its candidate still there?
+                dj = sel[j]
+                box, cls_, sc_ = det.boxes[b, dj].cpu(), int(det.class_ids[b, dj]), float(det.scores[b, dj])
+                nv = int(mid16["roi_counts"][b])
+                ci = _iou_matrix(box[None], cand[b, :nv, :4])[0] * (cand_cls[b, :nv] == cls_)
+                cb, ca = ci.max(0)
+                unmatched.append({"seed": seed, "image": b, "class": cls_, "f32_score": sc_, "best_same_class_f16_detection_iou": float(best[j]),
+                                  "f16_candidate_iou": float(cb), "f16_candidate_score": float(cand[b, ca, 4]),
+                                  "any_class_f16_detection_iou": float(_iou_matrix(box[None], det16.boxes[b, :k16].cpu()).max())})
+            ds = (det.scores[b, :k].cpu()[sel] - det16.scores[b, :k16].cpu()[arg]).abs()
+            ds_all += ds[best >= 0.9].tolist()
+        per_seed[str(seed)] = n_seed
+    best_t = torch.tensor(best_all, dtype=torch.float64)
+    ds_t = torch.tensor(ds_all, dtype=torch.float64)
+    n, n90, n50 = best_t.numel(), int((best_t >= 0.9).sum()), int((best_t >= 0.5).sum())
+    iou_edges = [0.0, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95, 0.99, 1.0 + 1e-9]
+    ds_edges = [0.0, 1e-4, 3e-4, 1e-3, 3e-3, 1e-2, 3e-2, 1.0]
+    hist = lambda t, edges: [int(((t >= lo) & (t < hi)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
+    REPORT["config5/f16/detection_agreement_rate"] = {
+        "f32_detections_score_gt_0.5": n, "per_seed": per_seed, "matched_same_class_iou_ge_0.9": n90, "rate_iou_ge_0.9": n90 / max(n, 1),
+        "with_a_match_iou_ge_0.5": n50, "worst_best_iou": float(best_t.min()) if n else None,
+        "best_iou_histogram": {"edges": iou_edges[:-1] + [1.0], "counts": hist(best_t, iou_edges)},
+        "abs_score_diff_of_matched_histogram": {"edges": ds_edges, "counts": hist(ds_t, ds_edges)},
+        "max_abs_score_diff_of_matched": float(ds_t.max()) if ds_t.numel() else None,
+        "without_a_match_iou_ge_0.5": unmatched}
+    assert n >= 100, f"only {n} confident fp32 detections over three seeds x eight images"
+    assert n90 >= 0.95 * n, f"fp16 path: {n90} of {n} confident fp32 detections matched at IoU >= 0.9 ({n90 / n:.3f} < 0.95)"
+    assert n - n50 <= 0.03 * n, f"fp16 path: {n - n50} of {n} confident fp32 detections have NO same-class fp16 detection with IoU >= 0.5"
+    for u in unmatched:   # never a confident detection that vanished: the unmatched ones sit at the confidence cut
+        assert u["f32_score"] <= 0.6, u
 
 
 # ------------------------------------------------------------------------------------------------------------

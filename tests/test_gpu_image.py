@@ -229,6 +229,46 @@ def test_detect_end_to_end(ops, oracle):
             assert abs(masks.shape[1] - h0) <= 1 and abs(masks.shape[2] - w0) <= 1
 
 
+def test_detect_batches_images_of_one_size(ops):
+    """Round 5: detect() molds, pastes and decodes the images that share a size TOGETHER (one launch per stage and group, over
+    the group's valid detections) with one host synchronisation per batch. A batch with two sizes in mixed order (A B A A B)
+    must give, image by image, exactly what each image alone gives — and the per-image results are views into the group's
+    tensors, never copies per image."""
+    from maskrcnn_amd import modules
+    from maskrcnn_amd.config import InferenceConfig
+    from maskrcnn_amd.pipeline import MaskRCNNInference
+    cfg = InferenceConfig(image_height=256, image_width=256, image_min_dim=200, image_max_dim=256, backbone="resnet50",
+                          pre_nms_limit=300, proposal_count=100, detection_max_instances=10)
+    sd = modules.synthetic_state_dict("resnet50", seed=0, bn_seed=1)
+    g = torch.Generator().manual_seed(5)
+    sd["classifier.linear_class.weight"] = torch.randn(81, 1024, generator=g) * 0.05
+    sd["classifier.linear_class.bias"] = torch.randn(81, generator=g) * 0.5
+    net = MaskRCNNInference(sd, cfg, DEV)
+    rng = np.random.default_rng(19)
+    shapes = ((300, 480, 3), (256, 256, 3), (300, 480, 3), (300, 480, 3), (256, 256, 3))
+    images = [rng.integers(0, 256, s, dtype=np.uint8) for s in shapes]
+    timings = {}
+    results = net.detect(images, timings=timings)
+    assert set(timings) == {"mold_ms", "predict_ms", "paste_decode_ms"} and all(v >= 0 for v in timings.values())
+    some = 0
+    for i, img in enumerate(images):
+        alone = net.detect([img])[0]
+        if alone[0] is None:
+            assert results[i][0] is None
+            continue
+        some += 1
+        for a, c in zip(results[i], alone):
+            assert a.dtype == c.dtype and torch.equal(a, c), i
+        h0, w0 = img.shape[:2]
+        assert abs(results[i][3].shape[1] - h0) <= 1 and abs(results[i][3].shape[2] - w0) <= 1
+    assert some >= 3
+    # torch tensors (already on the device) are accepted beside numpy arrays
+    mixed = [torch.from_numpy(images[0]).to(DEV), images[2]]
+    r2 = net.detect(mixed)
+    for a, c in zip(r2[1], results[2]):
+        assert (a is None and c is None) or torch.equal(a, c)
+
+
 def test_config1_car_image_mold_and_detect(ops, oracle):
     """BASELINE configs[0] — `predict.py images/car58a54312d.jpg`: the reference's sample image (decoded pixels in the
     fixture) through detect(): 1200 x 1920 → 640 x 1024 → 1024^2 canvas, window (192, 0, 832, 1024) (utils.py:42-90,

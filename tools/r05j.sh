@@ -1,0 +1,6 @@
+set -u
+OUT=gpurun_out/r05j; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 500 python tools/w4_race_probe.py 20000 2 > $OUT/race_default.jsonl 2>&1; cat $OUT/race_default.jsonl | cut -c1-1500
+MRCNN_W4_VMCNT0=1 timeout -k 10 400 python maskrcnn_amd/build.py > $OUT/build.log 2>&1; echo "rebuild rc=$?"
+W4_BUILD=vmcnt0 timeout -k 10 500 python tools/w4_race_probe.py 20000 2 > $OUT/race_vmcnt0.jsonl 2>&1; cat $OUT/race_vmcnt0.jsonl | cut -c1-1500
