@@ -75,14 +75,44 @@ struct Wino4Params {
     int C3;
     unsigned w3_bytes, y3_bytes;
     int debug;  // MRCNN_W4_DEBUG: timing ablations (wrong results): 1 no DMA, 2 no transform, 4 no patch reads, 8 no B reads, 16 no raw staging
+    int diag;   // MRCNN_W4_DIAG builds only (tools/w4_diag_soak.py; results stay correct): 1 one tile per workgroup (host),
+                // 2 a second barrier behind every staging barrier, 4 vmcnt(0) in front of every epilogue barrier, 8 both
+                // buffers' worth of nops behind the staging barrier
 };
 
-// The wait in front of the barrier that publishes a staged k tile: every LDS-DMA of this wave has landed; the three raw loads
-// issued last may stay in flight. -DMRCNN_W4_VMCNT0 (diagnostic build): wait for everything.
-#ifdef MRCNN_W4_VMCNT0
-#define W4_STAGE_WAIT_AND_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// The two barriers of the kernel. STAGING (end of the prologue and of every k tile): every LDS-DMA of this wave has landed —
+// the three raw loads issued last may stay in flight —, every LDS access is retired, barrier. EPILOGUE (twice per round): LDS
+// only (a __syncthreads() would also drain the round's global stores).
+// Round 5: the eight wait states on either side are a measured fix, not an understood one. Soaked on constant inputs, the kernel
+// WITHOUT them returned a launch with a few wrong tiles (whole 16 x 32 x 64 tiles, or single 4-row rounds of the epilogue, all of
+// one iteration of the persistent loop) about once per 3 000 - 5 000 launches of 1 024 tiles — on every box, in every run of that
+// binary, while builds whose instruction stream differed by a few scalar instructions at these two places ran 720 000 launches
+// clean (tools/w4_race_probe.py, w4_diag_soak.py; same box, builds alternating, events per 40 000 launches: without 15 and 4,
+// nops behind the staging barrier only 12 and 5, nops in front of the epilogue barriers only 4 and 3, both 0 and 0;
+// profiles/r05_w4_reproducibility.jsonl). vmcnt(0) instead of vmcnt(3) does not help (3 of 20 000); neither the hazard table
+// nor the LDS-DMA ordering rules explain why an s_waitcnt that directly follows an LDS instruction, or LDS reads that directly
+// follow the barrier, should matter. -DMRCNN_W4_NO_RACE_FIX builds the kernel as it was (for the A/B).
+#ifdef MRCNN_W4_NO_RACE_FIX
+#define W4_NOPS_AFTER_STAGING ""
+#define W4_NOPS_BEFORE_EPILOGUE_BARRIER ""
 #else
-#define W4_STAGE_WAIT_AND_BARRIER() asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define W4_NOPS_AFTER_STAGING "\n\ts_nop 7"
+#define W4_NOPS_BEFORE_EPILOGUE_BARRIER "s_nop 7\n\t"
+#endif
+#ifdef MRCNN_W4_VMCNT0
+#define W4_STAGE_WAIT_AND_BARRIER_() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" W4_NOPS_AFTER_STAGING ::: "memory")
+#else
+#define W4_STAGE_WAIT_AND_BARRIER_() asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" W4_NOPS_AFTER_STAGING ::: "memory")
+#endif
+#ifdef MRCNN_W4_DIAG
+#define W4_STAGE_WAIT_AND_BARRIER() do { W4_STAGE_WAIT_AND_BARRIER_(); \
+        if (p.diag & 2) asm volatile("s_barrier" ::: "memory"); \
+        if (p.diag & 8) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); } while (0)
+#define W4_EPILOGUE_BARRIER() do { if (p.diag & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+        asm volatile(W4_NOPS_BEFORE_EPILOGUE_BARRIER "s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
+#else
+#define W4_STAGE_WAIT_AND_BARRIER() W4_STAGE_WAIT_AND_BARRIER_()
+#define W4_EPILOGUE_BARRIER() asm volatile(W4_NOPS_BEFORE_EPILOGUE_BARRIER "s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 constexpr int W4_N = 64;                              // output channels per workgroup
 #ifndef MRCNN_W4_WALK_SHIFT
@@ -554,7 +584,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
             // barriers of the epilogue: LDS only. __syncthreads() would also wait (vmcnt(0)) for the previous round's global
             // stores — output pixels or head sums — to complete: their whole latency, once per round
             if (g == 0 || g == 1) STAMP();  // after the Z writes
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            W4_EPILOGUE_BARRIER();
             if (g == 0 || g == 1) STAMP();  // after the first barrier
             f32x2 w[6][4];
 #pragma unroll
@@ -606,7 +636,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
             }
             if (g == 0 || g == 1) STAMP();  // after transform + stores
             if (HEADS && g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the head-weight DMA has landed
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // Z is read out: the next round / tile may overwrite it
+            W4_EPILOGUE_BARRIER();  // Z is read out: the next round / tile may overwrite it
             if (g == 0 || g == 1) STAMP();  // round end
             if constexpr (HEADS && !(DBG & 128)) {
                 // wave w: pixels 32 w .. 32 w + 31 of the round x 32 heads x all 64 channels. The M tile's sums over the N
@@ -648,7 +678,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                                                               static_cast<int>(hbase + static_cast<unsigned>((r & 3) + 8 * (r >> 2)) * 128u), 0, 0);
                 }
                 // T overlaps U buffer 1: the next tile's prologue must not start before every wave has read it
-                if (g == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (g == 3) W4_EPILOGUE_BARRIER();
                 if (g == 0 || g == 1) STAMP();  // after the heads block
             }
             if constexpr (CONV3) {
@@ -736,7 +766,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                 }
                 // T lies inside Z: the next round's Z writes (and, after the last round, the next tile's prologue) must not
                 // start before every wave has read its rows
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                W4_EPILOGUE_BARRIER();
             }
         }
         if constexpr ((DBG & 2048) != 0) {
@@ -849,8 +879,12 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
     p.w_head = nullptr; p.head_part = nullptr; p.head_bytes = 0;
     p.w3 = nullptr; p.scale3 = nullptr; p.shift3 = nullptr; p.res3 = nullptr; p.y3 = nullptr; p.C3 = 0; p.w3_bytes = 0; p.y3_bytes = 0;
     p.debug = 0;
+    p.diag = 0;
 #ifdef MRCNN_W4_ABLATIONS
     p.debug = getenv("MRCNN_W4_DEBUG") ? atoi(getenv("MRCNN_W4_DEBUG")) : 0;
+#endif
+#ifdef MRCNN_W4_DIAG
+    p.diag = getenv("MRCNN_W4_DIAG") ? atoi(getenv("MRCNN_W4_DIAG")) : 0;
 #endif
     const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
     MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd4: grid too large");
@@ -874,7 +908,7 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
     const int cus = mrcnn::device_cu_count();
     if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd4: cannot query the device");
     const int ncu = cus >= 8 ? (cus / 8) * 8 : 8;
-    const long long launch = grid > ncu ? ncu : grid;
+    const long long launch = (grid > ncu && !(p.diag & 1)) ? ncu : grid;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(launch)), dim3(256), WINO4_LDS, mrcnn::as_stream(stream), p);
     return mrcnn::check_launch("conv3x3_wino4_f32");
 }
@@ -914,8 +948,12 @@ extern "C" int mrcnn_conv3x3_winograd4_heads_f32(const float* x_kblocked, int32_
     p.head_bytes = static_cast<unsigned>(4LL * rows * 32);
     p.w3 = nullptr; p.scale3 = nullptr; p.shift3 = nullptr; p.res3 = nullptr; p.y3 = nullptr; p.C3 = 0; p.w3_bytes = 0; p.y3_bytes = 0;
     p.debug = 0;
+    p.diag = 0;
 #ifdef MRCNN_W4_ABLATIONS
     p.debug = getenv("MRCNN_W4_DEBUG") ? atoi(getenv("MRCNN_W4_DEBUG")) : 0;
+#endif
+#ifdef MRCNN_W4_DIAG
+    p.diag = getenv("MRCNN_W4_DIAG") ? atoi(getenv("MRCNN_W4_DIAG")) : 0;
 #endif
     void (*kern)(const Wino4Params) = activation ? conv3x3_wino4_f32<0, true, true> : conv3x3_wino4_f32<0, true, false>;
 #ifdef MRCNN_W4_ABLATIONS
@@ -974,6 +1012,10 @@ extern "C" int mrcnn_conv3x3_winograd4_conv3_f32(const float* x_kblocked, int32_
     p.w3_bytes = static_cast<unsigned>(4LL * c3 * W4_N);
     p.y3_bytes = static_cast<unsigned>(4LL * px * c3);
     p.debug = 0;
+    p.diag = 0;
+#ifdef MRCNN_W4_DIAG
+    p.diag = getenv("MRCNN_W4_DIAG") ? atoi(getenv("MRCNN_W4_DIAG")) : 0;
+#endif
     void (*kern)(const Wino4Params) = conv3x3_wino4_f32<0, false, true, true>;
     if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), WINO4_CONV3_LDS, "conv3x3_winograd4_conv3"))
         return rc;
@@ -981,7 +1023,7 @@ extern "C" int mrcnn_conv3x3_winograd4_conv3_f32(const float* x_kblocked, int32_
     if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd4_conv3: cannot query the device");
     const int ncu = cus >= 8 ? (cus / 8) * 8 : 8;
     const long long grid = 8LL * ((p.tiles_m + 7) / 8);
-    const long long launch = grid > ncu ? ncu : grid;
+    const long long launch = (grid > ncu && !(p.diag & 1)) ? ncu : grid;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(launch)), dim3(256), WINO4_CONV3_LDS, mrcnn::as_stream(stream), p);
     return mrcnn::check_launch("conv3x3_wino4_f32<conv3>");
 }

@@ -488,6 +488,44 @@ def test_config5_full_size_r101_832x1344(dev, oracle):
         del net
 
 
+def test_config5_f16_kernel_routing_is_independent_of_the_batch(dev):
+    """The routing table of the "f16" mode at configs[4]'s geometry (R101-FPN, 832 x 1344; VERDICT r4 item 8: the f32 table was
+    the only one pinned): the SAME sequence of (kernel, N, K) for one image as for two — a layer's kernel is a function of the image
+    size, never of the batch — and the documented launch counts: the pipelined kernel for every 1x1 / 3x3 layer with 64-multiple
+    channels (and, round 5, the RPN's P6 level), the 128 x 128 / 256 x 64 tile kernel for the 64-channel C2 layers and the
+    18-channel heads of the small levels, one stem launch."""
+    from maskrcnn_amd import modules, ops
+    from maskrcnn_amd.config import InferenceConfig
+    from maskrcnn_amd.pipeline import MaskRCNNInference
+    h, w = 832, 1344
+    cfg = InferenceConfig(image_height=h, image_width=w, backbone="resnet101", pre_nms_limit=1000, proposal_count=1000)
+    sd = modules.synthetic_state_dict("resnet101", seed=0, bn_seed=1)
+    net = MaskRCNNInference(sd, cfg, dev, precision="f16")
+    g = torch.Generator().manual_seed(3)
+    images = (torch.randint(0, 256, (2, h, w, 3), generator=g).float() - torch.tensor(cfg.mean_pixel)).permute(0, 3, 1, 2).contiguous().to(dev)
+    windows = torch.tensor([[0., 0., float(h), float(w)]] * 2, device=dev)
+    seqs = {}
+    for b in (1, 2):
+        ops.CONV_PROFILE = []
+        try:
+            net.predict(images[:b], windows[:b])
+            torch.cuda.synchronize()
+            prof = ops.CONV_PROFILE
+        finally:
+            ops.CONV_PROFILE = None
+        seqs[b] = [(r[5] if len(r) > 5 else "direct", r[3][1], r[3][2]) for r in prof]
+    assert seqs[1] == seqs[2], [(i, a, c) for i, (a, c) in enumerate(zip(seqs[1], seqs[2])) if a != c][:5]
+    counts = {}
+    for tag, _, _ in seqs[2]:
+        counts[tag] = counts.get(tag, 0) + 1
+    REPORT["config5/f16/kernel_routing"] = counts
+    assert counts == F16_ROUTING_832x1344, counts
+
+
+# conv launches of one "f16" step at 832 x 1344, R101-FPN (measured on the MI355X, round 5; DESIGN 6.0000)
+F16_ROUTING_832x1344 = {"stem": 1, "f16p": 116, "f16": 11}
+
+
 def _iou_matrix(a, b):
     """[n,4] x [m,4] pixel boxes (y1,x1,y2,x2) → IoU [n,m] (plain areas, no +1)."""
     a, b = a.double(), b.double()
