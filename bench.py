@@ -19,8 +19,15 @@ Prints ONE JSON line on rank 0 with the driver's contract fields plus
                   F(2x2,3x3), / 4 for F(4x4,3x3)) / its summed launch durations — HIP events on the launch stream around every conv
                   launch, in an instrumented pass right after the timed region — against the fp32-MFMA peak, so
                   `frac` <= 1; the convolution-equivalent (algorithmic) rate and the whole conv path sit beside it;
+                  FLOPs / bytes are those of the work that RAN: the classifier's row-group GEMMs skip 128-row tiles of empty RoI slots
+                  and are booked on the rows of the tiles that executed (`heads_rows`); every `by_kernel` row carries
+                  `executed_gflop_per_step`, so frac of any set of families = sum(GFLOP) / sum(ms) / peak from the line itself;
   `roofline_ops`  RoIAlign (BASELINE config 2 shape + the pipeline's pyramid call; HBM-bound) and NMS 8 x 1000
                   (latency-bound), measured in the same run after the timed region;
+  `alt_configs`   never `value`: the headline step with SURVEY 8(d)'s 1000 VALID proposals per image injected behind the proposal
+                  stage; MaskRCNNInference.detect() (uint8 images in, full-size masks out) beside predict() on the same batch;
+                  BASELINE configs[4]'s geometry (R101-FPN, 832x1344, fp16 MFMA path) on this GPU;
+  `per_rank_ms_per_step`  slowest / fastest rank's own K steps per repetition (a straggler shows the first time N > 1 runs);
   `cpu_baseline`  the CPU oracle's predict() on a bounded sample of the same workload, timed on this host's cores.
 """
 import argparse
@@ -40,7 +47,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measure
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 
 
-TRAFFIC_PROFILE = "r04_hbm_traffic.json"
+TRAFFIC_PROFILE = "r05_hbm_traffic.json"
 
 
 def log(*a):

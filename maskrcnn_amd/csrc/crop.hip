@@ -564,90 +564,10 @@ __global__ __launch_bounds__(256) void roi_align_pyramid_nhwc(
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// NCHW forward, MAP-stationary (round 5; the staged kernel above and the gather kernel are BOX-stationary: a workgroup owns a box
-// and gathers the ~70-byte row segments of its footprint). Here a workgroup owns a BAND of `br` map rows x CB_CS channels of one
-// image: the band (br + 1 rows: a sample's bottom tap may be the next band's first row) streams into LDS as whole rows — the
-// map is read once, in 1 KB runs, at the copy rate —, every thread bins one box (which of its crop rows have their top tap in
-// this band: a list of (box, crop row) in LDS), and each wave then takes list entries: lane = (channel, crop column), four LDS
-// taps, the reference's lerp order (bilerp above), one cw-float run per channel out. Rows of a crop whose sample lies outside
-// the map (and boxes with a bad box_index) belong to band 0 (of image 0) and are filled with extrapolation_value.
-// Every output element is written exactly once, by the band its row sample falls in; arithmetic per element is the shared
-// make_sample / bilerp: bit-identical to the other two kernels.
-// ------------------------------------------------------------------------------------------------
-constexpr int CB_CS = 4;        // channels per workgroup
-constexpr int CB_LIST = 2048;   // (box, crop row) entries per binning chunk
-
-__global__ __launch_bounds__(256) void crop_forward_nchw_band(
-    const float* __restrict__ image, int batch, int depth, int H, int W, const float* __restrict__ boxes,
-    const int* __restrict__ box_index, int num_boxes, float extrap, int ch, int cw, int br, int bands,
-    float* __restrict__ crops) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int rows_lds = br + 1;
-    float* band = reinterpret_cast<float*>(smem);                                    // [CB_CS][rows_lds][W]
-    unsigned* list = reinterpret_cast<unsigned*>(band + CB_CS * rows_lds * W);       // [CB_LIST]
-    int* count = reinterpret_cast<int*>(list + CB_LIST);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int img = blockIdx.x / bands, bd = blockIdx.x - img * bands;
-    const int r0 = bd * br, r1 = min(r0 + br, H);          // crop rows whose TOP tap lies in [r0, r1)
-    const int rl = min(r0 + rows_lds, H) - r0;             // map rows staged
-    const int c0 = blockIdx.y * CB_CS, nc = min(CB_CS, depth - c0);
-    const int64_t HW = static_cast<int64_t>(H) * W;
-    // ---- the band: whole rows, contiguous per channel (W % 4 == 0, 16-byte aligned: checked by the launcher)
-    {
-        const float* src = image + (static_cast<int64_t>(img) * depth + c0) * HW + static_cast<int64_t>(r0) * W;
-        const int per_c = rl * W;
-        for (int c = 0; c < nc; ++c)
-            for (int i = tid * 4; i < per_c; i += 1024)
-                *reinterpret_cast<float4*>(band + c * rows_lds * W + i) = *reinterpret_cast<const float4*>(src + c * HW + i);
-    }
-    // the lane's (channel, crop column) of an entry; entries wider than a wave (nc * cw > 64) loop
-    const int per_entry = nc * cw;
-    const int chunk = min(256, CB_LIST / ch);
-    for (int chunk0 = 0; chunk0 < num_boxes; chunk0 += chunk) {
-        if (tid == 0) *count = 0;
-        __syncthreads();                                   // (first trip: also the band's stores)
-        const int n = chunk0 + tid;
-        if (tid < chunk && n < num_boxes) {
-            const int b_in = box_index[n];
-            const bool bad = b_in < 0 || b_in >= batch;
-            if (bad ? img == 0 : b_in == img) {
-                const float y1 = boxes[n * 4 + 0], y2 = boxes[n * 4 + 2];
-                for (int y = 0; y < ch; ++y) {
-                    const Sample Y = make_sample(y1, y2, H, ch, y);
-                    const bool out = bad || !Y.inside;
-                    if (out ? bd == 0 : (Y.lo >= r0 && Y.lo < r1))
-                        list[atomicAdd(count, 1)] = static_cast<unsigned>(n) | (static_cast<unsigned>(y) << 16);
-                }
-            }
-        }
-        __syncthreads();
-        const int cnt = *count;
-        for (int e = wave; e < cnt; e += 4) {
-            const unsigned ent = __builtin_amdgcn_readfirstlane(list[e]);
-            const int nb = static_cast<int>(ent & 0xFFFFu), y = static_cast<int>(ent >> 16);
-            const float y1 = boxes[nb * 4 + 0], x1 = boxes[nb * 4 + 1], y2 = boxes[nb * 4 + 2], x2 = boxes[nb * 4 + 3];
-            const int b_in = box_index[nb];
-            const bool bad = b_in < 0 || b_in >= batch;
-            const Sample Y = make_sample(y1, y2, H, ch, y);
-            float* out = crops + ((static_cast<int64_t>(nb) * depth + c0) * ch + y) * cw;
-            const int64_t cstride = static_cast<int64_t>(ch) * cw;
-            for (int i = lane; i < per_entry; i += 64) {
-                const int c = i / cw, x = i - c * cw;
-                const Sample X = make_sample(x1, x2, W, cw, x);
-                float v = extrap;
-                if (!bad && Y.inside && X.inside) {
-                    const float* p = band + c * rows_lds * W;
-                    const int top = (Y.lo - r0) * W, bot = (Y.hi - r0) * W;
-                    v = bilerp(p[top + X.lo], p[top + X.hi], p[bot + X.lo], p[bot + X.hi], X.lerp, Y.lerp);
-                }
-                out[c * cstride + x] = v;
-            }
-        }
-        __syncthreads();                                   // the list is rebuilt by the next chunk
-    }
-}
-
+// (Round 5: a MAP-stationary kernel — a workgroup owns a band of 16 map rows x 4 channels streamed into LDS as whole rows, bins
+// the boxes' crop rows into the band and writes 14-float runs — was built behind MRCNN_CROP_BAND, bit-identical to the kernels
+// here, and lost the hipGraph-timed A/B on BASELINE configs[1] by 4x: 118 us against 30.3 on P2, 98 / 145 / 242 against 21.7 /
+// 17.1 / 16.3 on P3 - P5 (profiles/r05_crop_band_probe.jsonl). Removed; the box-stationary kernels stay.)
 // MRCNN_CROP_STAGED=0 keeps every call on the gather kernel (tuning / A-B measurements; results are identical)
 // The tuning switches of the launch path, read ONCE per process (a getenv walks the whole environment: not per launch).
 struct CropTuning {
@@ -655,10 +575,7 @@ struct CropTuning {
     int cpw;          // MRCNN_CROP_CPW=n: channels per wave (0 = automatic)
     bool linear_map;  // MRCNN_CROP_MAP=0: plain (box, slab) grid
     int ring_slots;   // MRCNN_CROP_RING=n: DMA ring size (0 = default)
-    int band;         // MRCNN_CROP_BAND=0 / 1: the map-stationary kernel never / whenever it can run (-1: the launcher's rule)
     CropTuning() {
-        const char* eb = getenv("MRCNN_CROP_BAND");
-        band = eb ? (atoi(eb) != 0 ? 1 : 0) : -1;
         const char* e = getenv("MRCNN_CROP_STAGED");
         staged = !(e && e[0] == '0');
         e = getenv("MRCNN_CROP_CPW");
@@ -695,29 +612,6 @@ extern "C" int mrcnn_crop_forward_f32(const float* image, int32_t batch, int32_t
     const bool staged = plane % 4 == 0 && plane <= 256 && crop_height + crop_width <= 64 && width % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(image) & 15) == 0 && (reinterpret_cast<uintptr_t>(crops) & 15) == 0 &&
                         static_cast<uint64_t>(depth) * height * width * 4 < (1ull << 32) && crop_staged_enabled();
-    // map-stationary kernel: whole-row streaming of the map pays when the boxes together cover the map several times over
-    // (many boxes on a large level: BASELINE configs[1]); rule set from the hipGraph-timed A/B in bench.py's roofline_ops
-    {
-        const int rows_fit = static_cast<int>((72 * 1024) / (static_cast<size_t>(CB_CS) * width * 4));
-        const int br = std::min(16, rows_fit - 1);
-        const bool can = width % 4 == 0 && br >= 2 && crop_height <= 64 && crop_width <= 64 && num_boxes <= 65535 &&
-                         (reinterpret_cast<uintptr_t>(image) & 15) == 0 && CB_LIST / crop_height >= 1 &&
-                         (static_cast<int64_t>(height) * width) % 4 == 0;
-        const int want = crop_tuning().band;
-        const bool rule = false;   // (set below once measured)
-        if (can && (want == 1 || (want < 0 && rule))) {
-            const int bands = (height + br - 1) / br;
-            const size_t lds = sizeof(float) * CB_CS * (br + 1) * width + sizeof(unsigned) * CB_LIST + 16;
-            if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(crop_forward_nchw_band), lds, "crop_band")) return rc;
-            const long long gx = 1LL * bands * batch, gy = (depth + CB_CS - 1) / CB_CS;
-            if (gx <= 0x7FFFFFFF && gy <= 65535) {
-                hipLaunchKernelGGL(crop_forward_nchw_band, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), dim3(256), lds, s,
-                                   image, batch, depth, height, width, boxes, box_index, num_boxes, extrapolation_value, crop_height,
-                                   crop_width, br, bands, crops);
-                return mrcnn::check_launch("crop_forward_nchw_band");
-            }
-        }
-    }
     if (staged) {
         // channels per wave (= per workgroup): 16 — 8 on large maps, where the footprints are big, a channel is its own DMA
         // group and the waves of the largest boxes would otherwise run long after the others (measured on 256 boxes x 256
