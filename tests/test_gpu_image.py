@@ -62,6 +62,27 @@ def test_resize_batched_cropped_view(ops, oracle):
         assert np.array_equal(got[i], oracle.pil_resize_u8(a[i, 10:90, 4:100], 50, 60))
 
 
+def test_resize_fast_paths_vs_oracle(ops, oracle):
+    """Round 5: the bandwidth-shaped resample kernels behind decode_masks — four output columns per thread (horizontal), sixteen
+    bytes per thread (vertical), and both passes in ONE launch with the 8-bit intermediate in LDS for single-channel enlargements
+    with 16-byte rows — against Pillow's arithmetic (the oracle), bit for bit: batches, cropped views, ragged row tiles, sizes
+    that take each of the paths (fused: out_w % 16 == 0 and enlarging; horizontal-fast only: out_w % 4 == 0; generic: the rest)."""
+    rng = np.random.default_rng(15)
+    for (n, h, w, oh, ow) in ((3, 40, 64, 75, 128), (2, 17, 33, 40, 48), (5, 7, 9, 28, 32), (2, 31, 20, 31, 64), (1, 64, 64, 64, 64),
+                              (2, 40, 64, 75, 120), (2, 40, 64, 75, 122), (2, 40, 64, 30, 128), (1, 300, 400, 1000, 1024)):
+        a = rng.integers(0, 256, (n, h + 6, w + 10), dtype=np.uint8)
+        t = torch.from_numpy(a).to(DEV)
+        view = t[:, 3:3 + h, 5:5 + w]                                   # a cropped view: strides, no copy
+        got = ops.resize_bilinear_u8(view, oh, ow).cpu().numpy()
+        for i in range(n):
+            assert np.array_equal(got[i], oracle.pil_resize_u8(a[i, 3:3 + h, 5:5 + w], oh, ow)), (n, h, w, oh, ow, i)
+    # binary 0 / 255 masks (what decode_masks resizes) at the bench's size, a few of them
+    a = (rng.random((3, 1024, 1024)) > 0.5).astype(np.uint8) * 255
+    got = ops.resize_bilinear_u8(torch.from_numpy(a).to(DEV)[:, 192:832, :], 1200, 1920).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], oracle.pil_resize_u8(a[i, 192:832, :], 1200, 1920)), i
+
+
 def test_mold_golden(ops, gold):
     from maskrcnn_amd import image as imagelib
     from maskrcnn_amd.config import InferenceConfig
