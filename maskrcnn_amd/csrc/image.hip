@@ -192,49 +192,74 @@ __global__ __launch_bounds__(256) void resample_v_u8_fast(const uint8_t* __restr
 }
 
 // Both passes in ONE launch for the decode of full-size masks (single channel, enlarging: <= 3 taps each way, out_w % 16 == 0): a
-// workgroup owns FV_ROWS output rows of one image, runs the horizontal pass for the <= FV_IN input rows those need into LDS
-// ([rows][out_w] bytes — the 8-bit intermediate of Pillow's two-pass resample, never written to memory: for 400 masks of
-// 640 x 1024 -> 1200 x 1920 that is 491 MB written and read back) and the vertical pass from there. Same integer arithmetic,
-// same intermediate rounding: bit-identical to the two launches.
-constexpr int FV_ROWS = 16;    // output rows per workgroup
-constexpr int FV_IN = 20;      // input rows a workgroup may need (enlarging: <= FV_ROWS + 2)
+// workgroup owns a tile of FV_ROWS x FV_COLS output pixels of one image. It stages the input footprint of the tile (<= FV_IN rows
+// of <= FV_COLS + 4 bytes) in LDS with coalesced byte loads; if every byte of it is zero, so is the tile — the resample of zeros is
+// exactly zero — and the workgroup stores zeros and is done (a pasted mask is zero outside its box: most tiles of most masks). Otherwise
+// the horizontal pass runs from LDS into LDS ([rows][FV_COLS] bytes — the 8-bit intermediate of Pillow's two-pass resample, never written
+// to memory: for 400 masks of 640 x 1024 -> 1200 x 1920 that is 491 MB written and read back) and the vertical pass from there. Same
+// integer arithmetic, same intermediate rounding: bit-identical to the two launches.
+constexpr int FV_ROWS = 16;     // output rows per workgroup
+constexpr int FV_COLS = 256;    // output columns per workgroup
+constexpr int FV_IN = 20;       // input rows a workgroup may need (enlarging: <= FV_ROWS + 2)
+constexpr int FV_IN_W = FV_COLS + 8;   // input columns a workgroup may need (enlarging: <= FV_COLS + 3)
 __global__ __launch_bounds__(256) void resample_hv1_u8_fused(const uint8_t* __restrict__ src, int in_h, int in_w,
                                                              int64_t image_stride, int64_t row_stride, int out_h, int out_w,
                                                              const int* __restrict__ bh, const int* __restrict__ kh,
                                                              const int* __restrict__ bv, const int* __restrict__ kv,
                                                              uint8_t* __restrict__ dst) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    extern __shared__ __attribute__((aligned(16))) unsigned char fv_lds[];   // [rows_in][out_w]
-    const int tiles_y = (out_h + FV_ROWS - 1) / FV_ROWS;
-    const int img = blockIdx.x / tiles_y, ty = blockIdx.x - img * tiles_y;
+    __shared__ __attribute__((aligned(16))) unsigned char in_lds[FV_IN * FV_IN_W];    // [rows_in][FV_IN_W]
+    __shared__ __attribute__((aligned(16))) unsigned char mid_lds[FV_IN * FV_COLS];   // [rows_in][FV_COLS]
+    const int tiles_x = (out_w + FV_COLS - 1) / FV_COLS, tiles_y = (out_h + FV_ROWS - 1) / FV_ROWS;
+    const int tx = blockIdx.x % tiles_x, rest = blockIdx.x / tiles_x;
+    const int ty = rest % tiles_y, img = rest / tiles_y;
     const int y0 = ty * FV_ROWS, y1 = min(y0 + FV_ROWS, out_h);
-    // input rows the tile's output rows read: bounds are monotone in the output row
-    const int in0 = bv[2 * y0], in1 = min(bv[2 * (y1 - 1)] + 3, in_h);   // [in0, in1): ymin .. ymin + 2 (clamped)
-    const int rows_in = in1 - in0;
-    const uint8_t* simg = src + img * image_stride;
-    // ---- horizontal pass: a thread owns four output columns for all the tile's input rows
-    for (int x4 = threadIdx.x * 4; x4 < out_w; x4 += 1024) {
-        int i0[4], i1[4], i2[4], k0[4], k1[4], k2[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int xx = x4 + j, xmin = bh[2 * xx];
-            i0[j] = xmin; i1[j] = min(xmin + 1, in_w - 1); i2[j] = min(xmin + 2, in_w - 1);
-            k0[j] = kh[xx * 3]; k1[j] = kh[xx * 3 + 1]; k2[j] = kh[xx * 3 + 2];
+    const int x0 = tx * FV_COLS, x1 = min(x0 + FV_COLS, out_w);
+    // the input rows and columns the tile reads: the bounds are monotone in the output coordinate
+    const int in0 = bv[2 * y0], rows_in = min(min(bv[2 * (y1 - 1)] + 3, in_h) - in0, FV_IN);
+    const int c0 = bh[2 * x0], cols_in = min(min(bh[2 * (x1 - 1)] + 3, in_w) - c0, FV_IN_W);
+    const uint8_t* simg = src + img * image_stride + in0 * row_stride + c0;
+    unsigned any = 0;
+    for (int i = threadIdx.x; i < rows_in * cols_in; i += 256) {
+        const int r = i / cols_in, c = i - r * cols_in;
+        const unsigned v = simg[r * row_stride + c];
+        in_lds[r * FV_IN_W + c] = static_cast<unsigned char>(v);
+        any |= v;
+    }
+    const int groups = (x1 - x0) / 16;   // 16-byte store groups per tile row
+    uint8_t* dtile = dst + (static_cast<int64_t>(img) * out_h + y0) * out_w + x0;
+    if (!__syncthreads_or(static_cast<int>(any))) {
+        for (int it = threadIdx.x; it < (y1 - y0) * groups; it += 256) {
+            const int ry = it / groups, gx = it - ry * groups;
+            *reinterpret_cast<u32x4*>(dtile + static_cast<int64_t>(ry) * out_w + gx * 16) = u32x4{0, 0, 0, 0};
         }
-        for (int r = 0; r < rows_in; ++r) {
-            const uint8_t* sr = simg + (in0 + r) * row_stride;
-            unsigned packed = 0;
+        return;
+    }
+    // ---- horizontal pass, LDS -> LDS: a thread owns four output columns; the four waves take the input rows in turn
+    {
+        const int q = threadIdx.x & 63, rg = threadIdx.x >> 6, x4 = x0 + q * 4;
+        if (x4 < x1) {
+            int i0[4], i1[4], i2[4], k0[4], k1[4], k2[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int ss = (1 << (PRECISION_BITS - 1)) + sr[i0[j]] * k0[j] + sr[i1[j]] * k1[j] + sr[i2[j]] * k2[j];
-                packed |= clip8_for_packing(ss) << (8 * j);
+                const int xx = x4 + j, xmin = bh[2 * xx];
+                i0[j] = xmin - c0; i1[j] = min(xmin + 1, in_w - 1) - c0; i2[j] = min(xmin + 2, in_w - 1) - c0;
+                k0[j] = kh[xx * 3]; k1[j] = kh[xx * 3 + 1]; k2[j] = kh[xx * 3 + 2];
             }
-            *reinterpret_cast<unsigned*>(fv_lds + r * out_w + x4) = packed;
+            for (int r = rg; r < rows_in; r += 4) {
+                const unsigned char* sr = in_lds + r * FV_IN_W;
+                unsigned packed = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ss = (1 << (PRECISION_BITS - 1)) + sr[i0[j]] * k0[j] + sr[i1[j]] * k1[j] + sr[i2[j]] * k2[j];
+                    packed |= clip8_for_packing(ss) << (8 * j);
+                }
+                *reinterpret_cast<unsigned*>(mid_lds + r * FV_COLS + q * 4) = packed;
+            }
         }
     }
     __syncthreads();
     // ---- vertical pass from LDS: a thread owns sixteen bytes of an output row
-    const int groups = out_w / 16;
     for (int it = threadIdx.x; it < (y1 - y0) * groups; it += 256) {
         const int ry = it / groups, gx = it - ry * groups, yy = y0 + ry;
         const int ymin = bv[2 * yy], cnt = bv[2 * yy + 1];
@@ -243,7 +268,7 @@ __global__ __launch_bounds__(256) void resample_hv1_u8_fused(const uint8_t* __re
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = 1 << (PRECISION_BITS - 1);
         for (int t = 0; t < cnt; ++t) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(fv_lds + (ymin - in0 + t) * out_w + gx * 16);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(mid_lds + (ymin - in0 + t) * FV_COLS + gx * 16);
             const int kt = k[t];
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] += static_cast<int>((v[j >> 2] >> (8 * (j & 3))) & 255u) * kt;
@@ -251,7 +276,7 @@ __global__ __launch_bounds__(256) void resample_hv1_u8_fused(const uint8_t* __re
         u32x4 o = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 16; ++j) o[j >> 2] |= clip8_for_packing(acc[j]) << (8 * (j & 3));
-        *reinterpret_cast<u32x4*>(dst + (static_cast<int64_t>(img) * out_h + yy) * out_w + gx * 16) = o;
+        *reinterpret_cast<u32x4*>(dtile + static_cast<int64_t>(ry) * out_w + gx * 16) = o;
     }
 }
 
@@ -507,17 +532,16 @@ extern "C" int mrcnn_resize_bilinear_u8(const uint8_t* src, int32_t n, int32_t i
     hipStream_t s = mrcnn::as_stream(stream);
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     // single-channel enlargement with aligned rows (decode_masks): both passes in one launch, the intermediate stays in LDS
-    if (channels == 1 && p.ah.ksize == 3 && p.av.ksize == 3 && out_w % 16 == 0 && out_h >= in_h &&
-        (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && static_cast<size_t>(FV_IN) * out_w <= 64 * 1024 &&
-        static_cast<int64_t>(n) * ((out_h + FV_ROWS - 1) / FV_ROWS) <= 0x7FFFFFFF) {
+    const int64_t fv_tiles = static_cast<int64_t>(n) * ((out_h + FV_ROWS - 1) / FV_ROWS) * ((out_w + FV_COLS - 1) / FV_COLS);
+    if (channels == 1 && p.ah.ksize == 3 && p.av.ksize == 3 && out_w % 16 == 0 && out_h >= in_h && out_w >= in_w &&
+        (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && fv_tiles <= 0x7FFFFFFF) {
         int* bh = reinterpret_cast<int*>(ws + p.off_bh);
         int* kh = reinterpret_cast<int*>(ws + p.off_kh);
         int* bv = reinterpret_cast<int*>(ws + p.off_bv);
         int* kv = reinterpret_cast<int*>(ws + p.off_kv);
         hipLaunchKernelGGL(coeffs_kernel, dim3((out_w + 255) / 256), dim3(256), 0, s, p.ah, bh, kh);
         hipLaunchKernelGGL(coeffs_kernel, dim3((out_h + 255) / 256), dim3(256), 0, s, p.av, bv, kv);
-        const unsigned grid = static_cast<unsigned>(static_cast<int64_t>(n) * ((out_h + FV_ROWS - 1) / FV_ROWS));
-        hipLaunchKernelGGL(resample_hv1_u8_fused, dim3(grid), dim3(256), static_cast<size_t>(FV_IN) * out_w, s, src, in_h, in_w,
+        hipLaunchKernelGGL(resample_hv1_u8_fused, dim3(static_cast<unsigned>(fv_tiles)), dim3(256), 0, s, src, in_h, in_w,
                            src_image_stride, src_row_stride, out_h, out_w, bh, kh, bv, kv, dst);
         return mrcnn::check_launch("resample_hv1_u8_fused");
     }

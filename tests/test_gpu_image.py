@@ -64,9 +64,9 @@ def test_resize_batched_cropped_view(ops, oracle):
 
 def test_resize_fast_paths_vs_oracle(ops, oracle):
     """Round 5: the bandwidth-shaped resample kernels behind decode_masks — four output columns per thread (horizontal), sixteen
-    bytes per thread (vertical), and both passes in ONE launch with the 8-bit intermediate in LDS for single-channel enlargements
-    with 16-byte rows — against Pillow's arithmetic (the oracle), bit for bit: batches, cropped views, ragged row tiles, sizes
-    that take each of the paths (fused: out_w % 16 == 0 and enlarging; horizontal-fast only: out_w % 4 == 0; generic: the rest)."""
+    bytes per thread (vertical), and both passes in ONE launch per 16 x 256 output tile (input footprint and 8-bit intermediate
+    in LDS; all-zero footprints stored as zeros) for single-channel enlargements with 16-byte rows — against Pillow's arithmetic
+    (the oracle), bit for bit: batches, cropped views, ragged row tiles, sizes that take each of the paths (fused: out_w % 16 == 0 and enlarging; horizontal-fast only: out_w % 4 == 0; generic: the rest)."""
     rng = np.random.default_rng(15)
     for (n, h, w, oh, ow) in ((3, 40, 64, 75, 128), (2, 17, 33, 40, 48), (5, 7, 9, 28, 32), (2, 31, 20, 31, 64), (1, 64, 64, 64, 64),
                               (2, 40, 64, 75, 120), (2, 40, 64, 75, 122), (2, 40, 64, 30, 128), (1, 300, 400, 1000, 1024)):
@@ -81,6 +81,17 @@ def test_resize_fast_paths_vs_oracle(ops, oracle):
     got = ops.resize_bilinear_u8(torch.from_numpy(a).to(DEV)[:, 192:832, :], 1200, 1920).cpu().numpy()
     for i in range(3):
         assert np.array_equal(got[i], oracle.pil_resize_u8(a[i, 192:832, :], 1200, 1920)), i
+    # pasted masks as detect() sees them: zero but for a box (tiles whose input footprint is all zero are stored as zeros without
+    # being computed), with box edges and single pixels ON the tile borders of the fused kernel (16 output rows x 256 columns)
+    a = np.zeros((4, 1024, 1024), dtype=np.uint8)
+    a[0, 300:420, 100:333] = 255
+    a[1, 192 + 8:192 + 9, 136:137] = 255                                # one pixel; 136 * 1.875 = 255: the border of column tile 0 / 1
+    a[1, 831, 1023] = 200                                              # the last pixel of the window
+    a[2, 192:832, :][rng.random((640, 1024)) > 0.999] = 255            # sparse dots: most tiles empty, neighbours of a dot are not
+    a[3, 500:501, :] = 1                                               # one faint row
+    got = ops.resize_bilinear_u8(torch.from_numpy(a).to(DEV)[:, 192:832, :], 1200, 1920).cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(got[i], oracle.pil_resize_u8(a[i, 192:832, :], 1200, 1920)), ("sparse", i)
 
 
 def test_mold_golden(ops, gold):

@@ -1,7 +1,7 @@
 set -u
 OUT=gpurun_out/r05s; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/prof -o det -- python3 bench.py --cpu-images 0 --alt-precision none --alt-injected 0 --alt-config5 0 --measure-traffic 0 --roofline-steps 0 --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o det -- python3 bench.py --cpu-images 0 --alt-precision none --alt-injected 0 --alt-config5 0 --measure-traffic 0 --roofline-steps 0 --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 find $OUT/prof -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 rm -rf $OUT/prof
 python - <<'PY'
