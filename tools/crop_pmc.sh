@@ -8,10 +8,12 @@ mkdir -p $OUT
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TD_TC_STALL_sum GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_64B_sum"; do
     i=$((i+1))
-    d=$OUT/crop_pmc_${LVL}_$i
+    for mode in 1 0; do
+    d=$OUT/crop_pmc_${LVL}_${i}m$mode
     mkdir -p $d
-    timeout -k 10 200 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $d -o p -- python3 tools/crop_pmc.py $LVL > $d.log 2>&1 || { tail -5 $d.log; }
+    timeout -k 10 200 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $d -o p -- python3 tools/crop_pmc.py $LVL $mode > $d.log 2>&1 || { tail -5 $d.log; }
     find $d -name "*_kernel_trace.csv" -delete
+    done
 done
 python3 - <<PY
 import csv, glob, collections
