@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 15
+#define MRCNN_ABI_VERSION 16
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -265,6 +265,24 @@ int mrcnn_maxpool_nhwc_f32(const float* x, int32_t batch, int32_t height, int32_
 int mrcnn_maxpool_f32(const float* x, int32_t batch, int32_t height, int32_t width, int32_t channels, int32_t kernel,
                       int32_t stride, int32_t pad_top, int32_t pad_left, int32_t pad_bottom, int32_t pad_right, float* y,
                       int32_t y_layout, mrcnn_stream_t stream);
+
+/* Bottleneck.forward (/root/reference/model.py:190-211, residual branch :254-262) for the ResNet C2 blocks of the plain-fp16
+ * path in ONE launch (csrc/bottleneck_f16.hip): planes = 64, stride 1, fp16 NHWC in and out,
+ *   y = relu(conv3(relu(conv2(relu(conv1(x)*s1+t1))*s2+t2))*s3+t3 + residual),   conv2 = SamePad2d(3,1) + 3x3,
+ * residual = x (cin = 256, wd_frags null) or fp16(conv_d(x)*sd+td) (cin = 64: the stage's first block, 1x1 downsample conv + BN).
+ * Both 64-channel intermediates are rounded to fp16 where the per-layer path (mrcnn_conv_bn_act_nhwc_f16io /
+ * mrcnn_conv_f16_pipelined, one launch per conv) rounds them; the two paths differ by the summation order inside an MFMA only.
+ * Weights arrive as A fragments made by mrcnn_pack_afrags_f16 from the fp16 OHWI tensors flattened to [cout][k]
+ * (k = kh*kw*cin): w1 [64][cin], w2 [64][576], w3 [256][64], wd [256][64]; s / t: the folded BN scale and shift (fp32, per output
+ * channel). Image i of a batch == image i alone (a tile never spans images, one kernel for every batch size).
+ * _supported: 1 when the shape is in range (planes 64, cin 256 / 64 as above, 32-bit byte offsets), else 0. */
+int mrcnn_pack_afrags_f16(const void* w_f16, int32_t cout, int32_t k, void* frags_f16, mrcnn_stream_t stream);
+int mrcnn_bottleneck_c2_f16_supported(int32_t batch, int32_t height, int32_t width, int32_t cin, int32_t planes,
+                                      int32_t has_downsample);
+int mrcnn_bottleneck_c2_f16(const void* x_f16, int32_t batch, int32_t height, int32_t width, int32_t cin, const void* w1_frags,
+                            const float* s1, const float* t1, const void* w2_frags, const float* s2, const float* t2,
+                            const void* w3_frags, const float* s3, const float* t3, const void* wd_frags, const float* sd,
+                            const float* td, void* y_f16, mrcnn_stream_t stream);
 
 /* RPN glue, two launches.
  * mrcnn_rpn_scores_deltas_f32 — replaces the per-level permute/view/softmax/cat of RPN.forward + rpn_detect

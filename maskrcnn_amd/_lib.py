@@ -61,6 +61,10 @@ _SIGS = {
                                                   c_i32, c_vp]),
     "mrcnn_conv_f16_pipelined_heads": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
                                                         c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
+    "mrcnn_pack_afrags_f16": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "mrcnn_bottleneck_c2_f16_supported": (ctypes.c_int, [c_i32] * 6),
+    "mrcnn_bottleneck_c2_f16": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                 c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mrcnn_maxpool_nhwc_f16": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                                 c_vp, c_vp]),
     "mrcnn_deconv2x2_bias_act_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32,

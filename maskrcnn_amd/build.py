@@ -41,6 +41,7 @@ SOURCES = {
     "stem.hip": [],
     "bottleneck.hip": [],
     "bottleneck_op.hip": [],
+    "bottleneck_f16.hip": [],
     "misc.hip": ["-ffp-contract=off"],
     "select.hip": ["-ffp-contract=off"],
     "image.hip": ["-ffp-contract=off"],   # Pillow's coefficient arithmetic, operation by operation in fp64

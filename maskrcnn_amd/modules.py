@@ -223,6 +223,9 @@ F16_PIPELINED = os.environ.get("MRCNN_F16_PIPELINED", "1") != "0"
 # "f16" mode: the stem's conv + BN + ReLU + max-pool as one fp16-MFMA launch (csrc/stem.hip: stem7x7_s2_pool_f16). 0 = the
 # exact-fp32 stem with an fp16 store + the separate fp16 max-pool (rounds 2-3).
 F16_STEM_POOL = os.environ.get("MRCNN_F16_STEM_POOL", "1") != "0"
+# "f16" mode: a ResNet C2 block (planes 64, stride 1) as ONE launch (csrc/bottleneck_f16.hip: both 64-channel maps stay on chip,
+# x is read once). MRCNN_F16_FUSED_C2=0 keeps the three / four per-layer launches.
+F16_FUSED_C2 = os.environ.get("MRCNN_F16_FUSED_C2", "1") != "0"
 # the RPN heads run inside that kernel on levels of at least this many pixels PER IMAGE (never a function of the batch: the two
 # forms round differently, and image i of a batch must equal image i alone); below it the 18-channel conv is a launch of its own
 F16_HEADS_MIN_PIXELS = int(os.environ.get("MRCNN_F16_HEADS_MIN_PIXELS", "4096"))
@@ -351,6 +354,13 @@ class FusedBottleneck:
 
     def __init__(self, p, precision="f32", convs=None):
         self.p, self.precision, self.convs = p, precision, convs
+        self.f16_block = None
+        if convs is not None and precision == "f16" and F16_ACT:
+            c1, c2, c3, cd = convs
+            if (c1.stride == 1 and c1.w.shape[0] == 64 and c3.w.shape[0] == 256 and c1.w.w_hi.is_cuda
+                    and c1.w.shape[3] == (64 if cd is not None else 256) and all(c is None or c.w.precision == "f16" for c in convs)):
+                # the block's weights as the A fragments of the one-launch kernel (ops.bottleneck_c2_f16)
+                self.f16_block = tuple(ops.pack_afrags_f16(c.w.w_hi) if c is not None else None for c in convs)
 
     @classmethod
     def from_state_dict(cls, sd, prefix, stride, device, precision="f32"):
@@ -383,6 +393,11 @@ class FusedBottleneck:
         if self.convs is None:
             return torch.ops.maskrcnn.bottleneck_forward(x, *self.p)
         c1, c2, c3, cd = self.convs
+        if (self.f16_block is not None and F16_FUSED_C2 and x.dim() == 4 and x.dtype == torch.float16
+                and ops.bottleneck_c2_f16_supported(x.size(0), x.size(1), x.size(2), x.size(3), 64, cd is not None)):
+            f1, f2, f3, fd = self.f16_block
+            return ops.bottleneck_c2_f16(x, f1, c1.scale, c1.shift, f2, c2.scale, c2.shift, f3, c3.scale, c3.shift, fd,
+                                         None if cd is None else cd.scale, None if cd is None else cd.shift)
         if (FUSED_BOTTLENECK and WINOGRAD and self.precision == "f32" and cd is None and c1.stride == 1
                 and c2.w.u is not None and x.dim() == 4
                 and ops.bottleneck_fused_supported(x.size(1), x.size(2), x.size(3), c1.w.shape[0])):

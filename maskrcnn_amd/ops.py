@@ -532,6 +532,53 @@ def conv_f16_pipelined(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor | N
     return y16 if out_f16 else y32
 
 
+def pack_afrags_f16(w: torch.Tensor) -> torch.Tensor:
+    """fp16 weights [Cout, ...] (OHWI, flattened to [Cout][K], Cout % 32 == 0, K % 32 == 0) -> the A fragments
+    csrc/bottleneck_f16.hip reads: [K/32][Cout/16][64 lanes][8]."""
+    _need_gpu(w)
+    assert w.dtype == torch.float16 and w.is_contiguous()
+    cout, k = w.size(0), w.numel() // w.size(0)
+    out = torch.empty(k // 32, cout // 16, 64, 8, dtype=torch.float16, device=w.device)
+    with torch.cuda.device(w.device):
+        check(lib.mrcnn_pack_afrags_f16(w.data_ptr(), cout, k, out.data_ptr(), _stream()))
+    return out
+
+
+def bottleneck_c2_f16_supported(b: int, h: int, w: int, cin: int, planes: int, has_downsample: bool) -> bool:
+    """Shape gate of bottleneck_c2_f16 (planes 64, stride 1, Cin 256 identity / 64 with the downsample branch)."""
+    return bool(lib.mrcnn_bottleneck_c2_f16_supported(int(b), int(h), int(w), int(cin), int(planes), int(bool(has_downsample))))
+
+
+@_on_device
+def bottleneck_c2_f16(x: torch.Tensor, w1f, s1, t1, w2f, s2, t2, w3f, s3, t3, wdf=None, sd=None, td=None) -> torch.Tensor:
+    """Bottleneck.forward (model.py:190-211) of a ResNet C2 block in ONE launch, plain-fp16 path (csrc/bottleneck_f16.hip):
+    x fp16 NHWC [B,H,W,256] (identity block) or [B,H,W,64] (the stage's first block: wdf / sd / td = its downsample branch);
+    w*f: pack_afrags_f16 of the fp16 OHWI weights; s* / t*: folded BN (fp32). → fp16 NHWC [B,H,W,256]."""
+    _need_gpu(x, w1f, w2f, w3f, wdf, s1, t1, s2, t2, s3, t3, sd, td)
+    assert x.dtype == torch.float16 and x.is_contiguous() and x.dim() == 4
+    b, h, w, cin = x.shape
+    if w1f.numel() != 64 * cin or w2f.numel() != 64 * 576 or w3f.numel() != 256 * 64 or (wdf is not None and wdf.numel() != 256 * 64):
+        raise RuntimeError("bottleneck_c2_f16: weight fragments do not belong to a planes-64 block of this Cin")
+    for v, n in ((s1, 64), (t1, 64), (s2, 64), (t2, 64), (s3, 256), (t3, 256), (sd, 256), (td, 256)):
+        if v is not None and not (v.dtype == torch.float32 and v.numel() == n and v.is_contiguous()):
+            raise RuntimeError("bottleneck_c2_f16: scale / shift vectors must be contiguous fp32 of the layer's Cout")
+    y = torch.empty(b, h, w, 256, dtype=torch.float16, device=x.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mrcnn_bottleneck_c2_f16(x.data_ptr(), b, h, w, cin, w1f.data_ptr(), _ptr(s1), _ptr(t1), w2f.data_ptr(), _ptr(s2),
+                                      _ptr(t2), w3f.data_ptr(), _ptr(s3), _ptr(t3), _ptr(wdf), _ptr(sd), _ptr(td),
+                                      y.data_ptr(), _stream()))
+    if prof is not None:
+        e1.record()
+        m = b * h * w
+        kk = cin * 64 + 576 * 64 + 64 * 256 + (cin * 256 if wdf is not None else 0)       # multiply-adds per pixel
+        nbytes = x.numel() * 2 + y.numel() * 2 + 2 * kk
+        prof.append((e0, e1, 2.0 * m * kk, (m, 256, kk // 256), nbytes, "f16blk"))
+    return y
+
+
 @_on_device
 def conv_f16_pipelined_heads(x: torch.Tensor, w: torch.Tensor, scale, shift, w_head32: torch.Tensor, pad=(1, 1, 1, 1),
                              relu: bool = True, tile_rows: int = 0, algo_cin: int | None = None) -> "HeadSums":

@@ -609,6 +609,69 @@ def test_bottleneck_native_call_equals_launch_by_launch(dev, blk):
                                                native.data_ptr(), torch.cuda.current_stream().cuda_stream))
 
 
+# (batch, H, W, first block?): the C2 stage in the plain-fp16 mode — one launch per block (csrc/bottleneck_f16.hip)
+F16_C2_BLOCKS = [(2, 64, 64, False), (2, 64, 64, True), (1, 8, 16, False), (1, 8, 16, True), (3, 21, 37, False), (3, 21, 37, True),
+                 (1, 5, 3, False), (2, 208, 336, False), (2, 208, 336, True)]
+
+
+@pytest.mark.parametrize("blk", F16_C2_BLOCKS, ids=lambda c: "x".join(str(int(v)) for v in c))
+def test_bottleneck_c2_f16_one_launch(dev, blk):
+    """The ResNet C2 block of the "f16" mode as ONE launch (mrcnn_bottleneck_c2_f16; model.py:190-211, residual :254-262)
+    against (a) the per-layer fp16 launches it replaces — same fp16 operands, both intermediates rounded to fp16 at the same
+    places: the two may differ where an fp32 sum lands within an fp16 rounding boundary (another MFMA shape sums in another order),
+    i.e. by one fp16 ulp on a few elements: asserted <= 2 fp16 ulps of the output range and <= 0.5 % of the elements differing —,
+    (b) the reference module's arithmetic in torch-CPU fp32 at the fp16 mode's bar (2e-2 of the range), and (c) itself: image i of
+    a batch == image i alone, a repeat == bit for bit. Ragged tiles (8 x 16 pixels), one-tile and sub-tile maps, configs[4]'s size."""
+    from maskrcnn_amd import modules, ops
+    b, h, w, first = blk
+    cin = 64 if first else 256
+    g = torch.Generator().manual_seed(2000 + h * 7 + w + cin)
+    sd = _block_sd(g, cin, 64, first)
+    x = torch.randn(b, cin, h, w, generator=g).half()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    m = modules.FusedBottleneck.from_state_dict(sd, "", 1, dev, "f16")
+    assert m.f16_block is not None and ops.bottleneck_c2_f16_supported(b, h, w, cin, 64, first)
+    got = m(xd)
+    assert got.dtype == torch.float16 and tuple(got.shape) == (b, h, w, 256)
+    assert torch.equal(got, m(xd))
+    for i in range(b):
+        assert torch.equal(m(xd[i:i + 1].contiguous())[0], got[i]), i
+    per_layer = m.launch_by_launch(xd)
+    rng = per_layer.float().abs().max().item()
+    ulp = 2.0 ** (math.floor(math.log2(rng)) - 10)                     # fp16 spacing at the top of the range
+    diff = (got.float() - per_layer.float()).abs()
+    assert diff.max().item() <= 2 * ulp, (diff.max().item(), ulp)
+    assert (diff > 0).float().mean().item() <= 5e-3
+    # the reference arithmetic (fp32, on the fp16-rounded input)
+    xf = x.float()
+    def bn(y, n):
+        return F.batch_norm(y, sd[f"{n}.running_mean"], sd[f"{n}.running_var"], sd[f"{n}.weight"], sd[f"{n}.bias"], False, 0.0, 1e-3)
+    r = F.relu(bn(F.conv2d(xf, sd["conv1.weight"], sd["conv1.bias"]), "bn1"))
+    r = F.relu(bn(F.conv2d(F.pad(r, (1, 1, 1, 1)), sd["conv2.weight"], sd["conv2.bias"]), "bn2"))
+    r = bn(F.conv2d(r, sd["conv3.weight"], sd["conv3.bias"]), "bn3")
+    res = bn(F.conv2d(xf, sd["downsample.0.weight"], sd["downsample.0.bias"]), "downsample.1") if first else xf
+    want = F.relu(r + res)
+    err = (got.float().permute(0, 3, 1, 2).cpu() - want).abs().max().item()
+    assert err <= 2e-2 * want.abs().max().item(), (err, want.abs().max().item())
+
+
+def test_bottleneck_c2_f16_rejects_other_blocks(dev):
+    from maskrcnn_amd import modules, ops
+    assert not ops.bottleneck_c2_f16_supported(1, 64, 64, 512, 128, False)      # C3: planes 128
+    assert not ops.bottleneck_c2_f16_supported(1, 64, 64, 64, 64, False)        # Cin 64 without the downsample branch
+    assert not ops.bottleneck_c2_f16_supported(1, 64, 64, 256, 64, True)
+    assert not ops.bottleneck_c2_f16_supported(64, 1024, 1024, 256, 64, False)  # past the 32-bit offsets
+    g = torch.Generator().manual_seed(7)
+    assert modules.FusedBottleneck.from_state_dict(_block_sd(g, 512, 128, False), "", 1, dev, "f16").f16_block is None
+    assert modules.FusedBottleneck.from_state_dict(_block_sd(g, 256, 64, False), "", 1, dev, "f32").f16_block is None
+    m = modules.FusedBottleneck.from_state_dict(_block_sd(g, 256, 64, False), "", 1, dev, "f16")
+    f1, f2, f3, _ = m.f16_block
+    c1, c2, c3, _ = m.convs
+    with pytest.raises(RuntimeError, match="fragments"):
+        ops.bottleneck_c2_f16(torch.zeros(1, 8, 8, 64, dtype=torch.float16, device=dev), f1, c1.scale, c1.shift, f2, c2.scale,
+                              c2.shift, f3, c3.scale, c3.shift)
+
+
 def test_bottleneck_fused_rejects_other_shapes(dev):
     from maskrcnn_amd import ops
     from maskrcnn_amd._lib import MaskrcnnHipError
