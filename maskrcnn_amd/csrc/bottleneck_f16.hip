@@ -55,6 +55,7 @@ constexpr int TAB_S1 = 0, TAB_T1 = 256, TAB_S2 = 512, TAB_T2 = 768, TAB_S3 = 102
 constexpr int LDS_BYTES = L_TAB + 5120;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 constexpr unsigned OOB = 0xFFFFFFF0u;
+constexpr int BAND = 4;   // tile rows per band of the tile order
 
 struct BParams {
     const _Float16* x;      // [B][H][W][Cin]
@@ -75,24 +76,40 @@ __device__ __forceinline__ void lds_barrier() {   // LDS-only: outstanding globa
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-// eight consecutive floats of an affine table (the lane's channels g*32 + q*8 .. +7)
-__device__ __forceinline__ void tab8(const unsigned char* tab, int ch, float (&v)[8]) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(tab + ch * 4), b = *reinterpret_cast<const f32x4*>(tab + ch * 4 + 16);
-    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// relu(acc * s + t) of the accumulator pair (lo, hi) = the lane's 8 channels, rounded to fp16 (fp32 value materialised first:
-// two roundings, as the per-layer kernels' epilogues)
-__device__ __forceinline__ f16x8 affine_relu_f16(const f32x4& lo, const f32x4& hi, const float (&s)[8], const float (&t)[8]) {
-    f16x8 o;
+// Epilogue arithmetic on PAIRS (v_pk_fma_f32, v_pk_add_f32, v_cvt_pk_f16_f32, v_pk_max_f16: three VALU instructions per element
+// instead of six — at two waves per SIMD the element-wise epilogues were as long as the MFMAs). Same values as the per-layer kernels'
+// epilogues: the fp32 result is materialised, then rounded to fp16 (two roundings); ReLU after the rounding (rounding is monotonic
+// and keeps zero: max(fp16(v), 0) == fp16(max(v, 0))).
+__device__ __forceinline__ f32x2 pair_of(const f32x4& lo, const f32x4& hi, int j) {   // elements 2j, 2j+1 of the lane's 8 channels
+    const f32x4& a = j < 2 ? lo : hi;
+    return (j & 1) ? f32x2{a[2], a[3]} : f32x2{a[0], a[1]};
+}
+// the lane's 8 consecutive table entries (channels ch .. ch + 7) as four pairs
+__device__ __forceinline__ void tab8(const unsigned char* tab, int ch, f32x2 (&v)[4]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(tab + ch * 4), b = *reinterpret_cast<const f32x4*>(tab + ch * 4 + 16);
+    v[0] = f32x2{a[0], a[1]}; v[1] = f32x2{a[2], a[3]}; v[2] = f32x2{b[0], b[1]}; v[3] = f32x2{b[2], b[3]};
+}
+__device__ __forceinline__ f16x8 pack8(const f16x2 (&h)[4]) {
+    return __builtin_bit_cast(f16x8, u32x4{__builtin_bit_cast(unsigned, h[0]), __builtin_bit_cast(unsigned, h[1]),
+                                           __builtin_bit_cast(unsigned, h[2]), __builtin_bit_cast(unsigned, h[3])});
+}
+__device__ __forceinline__ f16x2 round_relu(f32x2 v) {
+    asm volatile("" : "+v"(v));   // the fp32 value exists before it is rounded (no fused multiply-add-convert)
+    return __builtin_elementwise_max(__builtin_convertvector(v, f16x2), f16x2{0, 0});
+}
+// relu(acc * s + t) of the accumulator pair (lo, hi) = the lane's 8 channels, as fp16
+__device__ __forceinline__ f16x8 affine_relu_f16(const f32x4& lo, const f32x4& hi, const unsigned char* tab_s, const unsigned char* tab_t,
+                                                 int ch) {
+    f32x2 s[4], t[4];
+    tab8(tab_s, ch, s);
+    tab8(tab_t, ch, t);
+    f16x2 h[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float v = (e < 4 ? lo[e & 3] : hi[e & 3]) * s[e] + t[e];
-        v = v > 0.f ? v : 0.f;
-        asm volatile("" : "+v"(v));
-        o[e] = static_cast<_Float16>(v);
-    }
-    return o;
+    for (int j = 0; j < 4; ++j) h[j] = round_relu(__builtin_elementwise_fma(pair_of(lo, hi, j), s[j], t[j]));
+    return pack8(h);
 }
 
 template <bool FIRST>
@@ -164,9 +181,14 @@ __global__ __launch_bounds__(512, 1) void bottleneck_c2_f16(const BParams p) {
     auto geometry = [&](int tile) {
         Geo g;
         g.b = tile / tiles_img;
-        const int r = tile - g.b * tiles_img, ty = r / p.tiles_x;
+        // tiles of an image in bands of BAND tile rows, column by column inside a band: the 32 tiles an XCD works on at one time
+        // are a BAND x 8 block (32 x 128 pixels), so most of a tile's halo is a neighbour's interior in the same L2 at the same time
+        const int r = tile - g.b * tiles_img, band_tiles = BAND * p.tiles_x;
+        const int band = r / band_tiles, rem = r - band * band_tiles;
+        const int rows = min(BAND, p.tiles_y - band * BAND);
+        const int tx = rem / rows, ty = band * BAND + (rem - tx * rows);
         g.ty0 = ty * TH;
-        g.tx0 = (r - ty * p.tiles_x) * TW;
+        g.tx0 = tx * TW;
         const int iyA = g.ty0 - 1 + hyA, ixA = g.tx0 - 1 + hxA, iyB = g.ty0 - 1 + hyB, ixB = g.tx0 - 1 + hxB;
         g.inA = iyA >= 0 && iyA < p.H && ixA >= 0 && ixA < p.W;
         g.inB = lane_b && iyB >= 0 && iyB < p.H && ixB >= 0 && ixB < p.W;
@@ -179,19 +201,16 @@ __global__ __launch_bounds__(512, 1) void bottleneck_c2_f16(const BParams p) {
 #pragma unroll
         for (int kc = 0; kc < KC1; ++kc)
             xa[kc] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(g.offA), kc * 64, 0));
-        if (has_b) {
+        // (waves 4-7 have no second tile: their offsets are out of range, the loads move nothing — but EVERY wave issues the same
+        // memory instructions in the same order, so the compiler's vmcnt bookkeeping is exact; see the dummy stores below)
 #pragma unroll
-            for (int kc = 0; kc < KC1; ++kc)
-                xb[kc] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(g.offB), kc * 64, 0));
-        }
+        for (int kc = 0; kc < KC1; ++kc)
+            xb[kc] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(g.offB), kc * 64, 0));
     };
     auto write_t1 = [&](const f32x4 (&acc)[4], int P, bool inside) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            float s[8], sh[8];
-            tab8(smem + L_TAB + TAB_S1, h * 32 + q * 8, s);
-            tab8(smem + L_TAB + TAB_T1, h * 32 + q * 8, sh);
-            f16x8 o = affine_relu_f16(acc[2 * h], acc[2 * h + 1], s, sh);
+            f16x8 o = affine_relu_f16(acc[2 * h], acc[2 * h + 1], smem + L_TAB + TAB_S1, smem + L_TAB + TAB_T1, h * 32 + q * 8);
             if (!inside) o = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             const int chunk = h * 4 + q;
             *reinterpret_cast<f16x8*>(smem + L_T1 + P * 128 + ((chunk ^ ((P >> 1) & 7)) << 4)) = o;
@@ -200,22 +219,41 @@ __global__ __launch_bounds__(512, 1) void bottleneck_c2_f16(const BParams p) {
 
     Geo g = geometry(t);
     load_x(g);
+    // Eight stores that store nothing (out of range), so that the loop is ENTERED with the memory instructions in flight it is
+    // re-entered with: x loads of the tile, then the previous tile's 8 stores. The compiler merges the wait counts of both entries
+    // to the stricter one; without these the first use of an x fragment waited for "all but 7 - kc" operations — i.e., on the
+    // back edge, for the previous tile's STORES to complete (their latency exposed once per tile: ISA, first version).
+#pragma unroll
+    for (int hp = 0; hp < 8; ++hp)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, y_rsrc, static_cast<int>(OOB), hp * 64, 0);
     for (;;) {
         // ---- phase 1: conv1 on the wave's pixel tiles ---------------------------------------------------------------
+        // (every MFMA group of the three phases reads its A / B fragments one group AHEAD, into a second register set, with a
+        // scheduling barrier between the reads and the MFMAs: left to itself the compiler sinks each ds_read to one MFMA in front of
+        // its use, and the wave waits out the LDS latency once per MFMA — SQ_WAIT_INST 36 % of the wave cycles, first version)
         f32x4 a1[4] = {zero4(), zero4(), zero4(), zero4()}, b1[4] = {zero4(), zero4(), zero4(), zero4()};
+        auto w1_frag = [&](int kc, int cb) -> f16x8 {
+            if (FIRST || kc * 4 + cb < WX_REG_ID) return w1r[(FIRST || kc * 4 + cb < WX_REG_ID) ? kc * 4 + cb : 0];
+            return *reinterpret_cast<const f16x8*>(smem + L_WX + (kc * 4 + cb - WX_REG_ID) * 1024 + lane * 16);
+        };
+        {
+            f16x8 wf[2][4];
 #pragma unroll
-        for (int kc = 0; kc < KC1; ++kc) {
-            f16x8 wf[4];
+            for (int cb = 0; cb < 4; ++cb) wf[0][cb] = w1_frag(0, cb);
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                if (FIRST || kc * 4 + cb < WX_REG_ID) wf[cb] = w1r[kc * 4 + cb];
-                else wf[cb] = *reinterpret_cast<const f16x8*>(smem + L_WX + (kc * 4 + cb - WX_REG_ID) * 1024 + lane * 16);
-            }
+            for (int kc = 0; kc < KC1; ++kc) {
+                if (kc + 1 < KC1) {
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) a1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cb], xa[kc], a1[cb], 0, 0, 0);
-            if (has_b) {
+                    for (int cb = 0; cb < 4; ++cb) wf[(kc + 1) & 1][cb] = w1_frag(kc + 1, cb);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) b1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cb], xb[kc], b1[cb], 0, 0, 0);
+                for (int cb = 0; cb < 4; ++cb) a1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kc & 1][cb], xa[kc], a1[cb], 0, 0, 0);
+                if (has_b) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) b1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kc & 1][cb], xb[kc], b1[cb], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         f16x8 xres[KC1];   // the wave's own row of x: the identity residual / the downsample conv's operand
@@ -234,30 +272,38 @@ __global__ __launch_bounds__(512, 1) void bottleneck_c2_f16(const BParams p) {
 
         // ---- phase 2: conv2 out of T1 ------------------------------------------------------------------------------
         f32x4 a2[4] = {zero4(), zero4(), zero4(), zero4()};
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
+        {
+            f16x8 wf[2][8], xf[2][2];
+            auto read_tap = [&](int tap, int set) {
+                const int dy = tap / 3, dx = tap - dy * 3;
                 const int P = (wave + dy) * HWD + l16 + dx;
                 const unsigned char* px = smem + L_T1 + P * 128;
                 const int sw = (P >> 1) & 7;
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
-                    const f16x8 xf = *reinterpret_cast<const f16x8*>(px + (((kc * 4 + q) ^ sw) << 4));
-                    const unsigned char* wf = smem + L_W2 + (((dy * 3 + dx) * 2 + kc) * 4) * 1024 + lane * 16;
+                    xf[set][kc] = *reinterpret_cast<const f16x8*>(px + (((kc * 4 + q) ^ sw) << 4));
 #pragma unroll
                     for (int cb = 0; cb < 4; ++cb)
-                        a2[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(wf + cb * 1024), xf, a2[cb], 0, 0, 0);
+                        wf[set][kc * 4 + cb] = *reinterpret_cast<const f16x8*>(smem + L_W2 + ((tap * 2 + kc) * 4 + cb) * 1024 + lane * 16);
                 }
+            };
+            read_tap(0, 0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) read_tap(tap + 1, (tap + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        a2[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tap & 1][kc * 4 + cb], xf[tap & 1][kc], a2[cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
         f16x8 t2f[2];      // relu(bn2(conv2)) in fp16: the lane's B fragments of conv3
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float s[8], sh[8];
-            tab8(smem + L_TAB + TAB_S2, h * 32 + q * 8, s);
-            tab8(smem + L_TAB + TAB_T2, h * 32 + q * 8, sh);
-            t2f[h] = affine_relu_f16(a2[2 * h], a2[2 * h + 1], s, sh);
-        }
+        for (int h = 0; h < 2; ++h)
+            t2f[h] = affine_relu_f16(a2[2 * h], a2[2 * h + 1], smem + L_TAB + TAB_S2, smem + L_TAB + TAB_T2, h * 32 + q * 8);
 
         // ---- phase 3: conv3 (+ the downsample conv of the first block), residual, ReLU, store --------------------------
         const int oy = gc.ty0 + wave, ox = gc.tx0 + l16;
@@ -271,54 +317,59 @@ __global__ __launch_bounds__(512, 1) void bottleneck_c2_f16(const BParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) ad[j] = zero4();
             }
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int cb = half * 8 + j;
-                    const f16x8 wf = *reinterpret_cast<const f16x8*>(smem + L_W3 + (kc * 16 + cb) * 1024 + lane * 16);
-                    a3[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, t2f[kc], a3[j], 0, 0, 0);
-                }
-                if constexpr (FIRST) {
+            {
+                // groups of 8 MFMAs: (conv3, kc 0), (conv3, kc 1) and, in the first block, (downsample, kc 0), (downsample, kc 1)
+                constexpr int NG = FIRST ? 4 : 2;
+                f16x8 wf[2][8];
+                auto read_group = [&](int grp, int set) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int cb = half * 8 + j;
-                        const int f = kc * 16 + cb;
-                        const f16x8 wf = f < WX_REG_FIRST ? wdr[f < WX_REG_FIRST ? f : 0]
-                                                          : *reinterpret_cast<const f16x8*>(smem + L_WX + (f - WX_REG_FIRST) * 1024 + lane * 16);
-                        ad[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xres[kc], ad[j], 0, 0, 0);
+                        const int kc = grp & 1, cb = half * 8 + j, f = kc * 16 + cb;
+                        if (grp < 2) wf[set][j] = *reinterpret_cast<const f16x8*>(smem + L_W3 + f * 1024 + lane * 16);
+                        else if (f < WX_REG_FIRST) wf[set][j] = wdr[f < WX_REG_FIRST ? f : 0];
+                        else wf[set][j] = *reinterpret_cast<const f16x8*>(smem + L_WX + (f - WX_REG_FIRST) * 1024 + lane * 16);
                     }
+                };
+                read_group(0, 0);
+#pragma unroll
+                for (int grp = 0; grp < NG; ++grp) {
+                    if (grp + 1 < NG) read_group(grp + 1, (grp + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (grp < 2) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a3[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[grp & 1][j], t2f[grp & 1], a3[j], 0, 0, 0);
+                    } else if constexpr (FIRST) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ad[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[grp & 1][j], xres[grp & 1], ad[j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #pragma unroll
             for (int hh = 0; hh < 4; ++hh) {
                 const int hp = half * 4 + hh;   // 32-channel group: the lane's channels hp*32 + q*8 .. +7
-                float s[8], sh[8], res[8];
+                f32x2 s[4], sh[4], res[4];
                 tab8(smem + L_TAB + TAB_S3, hp * 32 + q * 8, s);
                 tab8(smem + L_TAB + TAB_T3, hp * 32 + q * 8, sh);
                 if constexpr (FIRST) {
-                    float sdv[8], tdv[8];
+                    f32x2 sdv[4], tdv[4];
                     tab8(smem + L_TAB + TAB_SD, hp * 32 + q * 8, sdv);
                     tab8(smem + L_TAB + TAB_TD, hp * 32 + q * 8, tdv);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {   // the downsample branch as the per-layer path leaves it in HBM: fp16
-                        float r = (e < 4 ? ad[2 * hh][e & 3] : ad[2 * hh + 1][e & 3]) * sdv[e] + tdv[e];
+                    for (int j = 0; j < 4; ++j) {   // the downsample branch as the per-layer path leaves it in HBM: fp16
+                        f32x2 r = __builtin_elementwise_fma(pair_of(ad[2 * hh], ad[2 * hh + 1], j), sdv[j], tdv[j]);
                         asm volatile("" : "+v"(r));
-                        res[e] = static_cast<float>(static_cast<_Float16>(r));
+                        res[j] = __builtin_convertvector(__builtin_convertvector(r, f16x2), f32x2);
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) res[e] = static_cast<float>(xres[hp][e]);
+                    for (int j = 0; j < 4; ++j) res[j] = f32x2{static_cast<float>(xres[hp][2 * j]), static_cast<float>(xres[hp][2 * j + 1])};
                 }
-                f16x8 o;
+                f16x2 h[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float v = (e < 4 ? a3[2 * hh][e & 3] : a3[2 * hh + 1][e & 3]) * s[e] + sh[e];
-                    v += res[e];
-                    v = v > 0.f ? v : 0.f;
-                    asm volatile("" : "+v"(v));
-                    o[e] = static_cast<_Float16>(v);
-                }
+                for (int j = 0; j < 4; ++j)
+                    h[j] = round_relu(__builtin_elementwise_fma(pair_of(a3[2 * hh], a3[2 * hh + 1], j), s[j], sh[j]) + res[j]);
+                const f16x8 o = pack8(h);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), y_rsrc, static_cast<int>(yoff), hp * 64, 0);
             }
         }
