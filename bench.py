@@ -197,7 +197,8 @@ def conv_roofline(prof, args, H, W, modules, measured=None, measured_reason=None
     kernel_of = {"winograd": "conv3x3_wino8_f32", "winograd_spatial": "conv3x3_wino8s_f32", "winograd4": "conv3x3_wino4_f32",
                  "direct": "conv_igemm_f32",
                  "stem": "stem7x7_s2_f32",
-                 "f16": "conv_igemm_f16", "rpn_fused": "conv_igemm_f32<heads>", "bottleneck": "bottleneck_fused_f32"}
+                 "f16": "conv_igemm_f16", "f16p": "conv_f16p", "f16blk": "bottleneck_c2_f16",
+                 "rpn_fused": "conv_igemm_f32<heads>", "bottleneck": "bottleneck_fused_f32"}
     if args.dump_conv:
         per = len(prof) // steps
         rows = []
@@ -886,6 +887,13 @@ def config5_entry(dev, args, ops, modules, InferenceConfig, MaskRCNNInference):
     # algorithmic bytes (the stem's fp32 MFMAs are priced at the fp16 peak too, i.e. against it)
     floor_ms = sum(max(r[2] / (F16_MFMA_PEAK_TFLOPS * 1e12), r[4] / (HBM_PEAK_GBS * 1e9)) * 1e3 for r in prof) / max(1, args.roofline_steps)
     hbm_bound = sum(1 for r in prof if r[4] / (HBM_PEAK_GBS * 1e9) > r[2] / (F16_MFMA_PEAK_TFLOPS * 1e12)) // max(1, args.roofline_steps)
+    # the same sum with every REFERENCE LAYER on its own floor, whatever launch computes it (a launch that fuses a Bottleneck is then
+    # priced on its layers' floors — the yardstick of rounds 3-4, when every layer was a launch: fusing layers lowers the
+    # per-launch floor sum with the time, so the per-launch fraction cannot show what a fusion bought)
+    def layer_floor(r):
+        layers = r[7]["layers"] if len(r) > 7 and isinstance(r[7], dict) and "layers" in r[7] else [(r[2], r[4])]
+        return sum(max(f / (F16_MFMA_PEAK_TFLOPS * 1e12), b / (HBM_PEAK_GBS * 1e9)) for f, b in layers) * 1e3
+    layer_floor_ms = sum(layer_floor(r) for r in prof) / max(1, args.roofline_steps)
     return {"config": "BASELINE configs[4] geometry on 1 GPU: ResNet-101-FPN, 832x1344 (1333x800 padded to /64), batch 8, "
                       f"{args.proposals} proposals/img, fp16 MFMA path (fp16 operands + fp16 activations in HBM, fp32 accumulate)",
             "precision": "f16", "value": round(batch * args.steps / el, 2), "unit": "images/s",
@@ -897,7 +905,11 @@ def config5_entry(dev, args, ops, modules, InferenceConfig, MaskRCNNInference):
             "conv_ms_per_step": round(ms, 3), "conv_algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 1),
             "conv_frac_of_f16_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4),
             "conv_frac_of_per_launch_roofline": round(floor_ms / ms, 4),
+            "conv_frac_of_per_layer_roofline": round(layer_floor_ms / ms, 4),
             "conv_launches": len(prof) // max(1, args.roofline_steps), "conv_launches_hbm_bound_at_peak": hbm_bound,
+            "per_layer_roofline_note": "as conv_frac_of_per_launch_roofline, but a launch that computes several of the reference's "
+                                       "layers (a whole C2 Bottleneck, csrc/bottleneck_f16.hip) is priced at the SUM of those layers' own "
+                                       "floors: comparable with rounds 3-4, when every layer was a launch",
             "per_launch_roofline_note": "sum over launches of max(algorithmic FLOPs / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s) / summed "
                                         "launch durations: most 1x1 layers of this path have their HBM floor above their fp16-MFMA floor; "
                                         "the fp16-MFMA launches are power-bound on random data (the same kernel on all-zero operands "

@@ -575,7 +575,13 @@ def bottleneck_c2_f16(x: torch.Tensor, w1f, s1, t1, w2f, s2, t2, w3f, s3, t3, wd
         m = b * h * w
         kk = cin * 64 + 576 * 64 + 64 * 256 + (cin * 256 if wdf is not None else 0)       # multiply-adds per pixel
         nbytes = x.numel() * 2 + y.numel() * 2 + 2 * kk
-        prof.append((e0, e1, 2.0 * m * kk, (m, 256, kk // 256), nbytes, "f16blk"))
+        # the reference's layers inside this launch, each as the per-layer path books it (FLOPs, bytes: input + output (+ residual)
+        # + weights) — bench.py prices a fused launch against ITS bytes and, beside that, against the layers' own floors
+        layers = [(2.0 * m * cin * 64, 2 * (m * cin + m * 64 + cin * 64)), (2.0 * m * 576 * 64, 2 * (2 * m * 64 + 576 * 64)),
+                  (2.0 * m * 64 * 256, 2 * (m * 64 + 2 * m * 256 + 64 * 256))]
+        if wdf is not None:
+            layers.append((2.0 * m * cin * 256, 2 * (m * cin + m * 256 + cin * 256)))
+        prof.append((e0, e1, 2.0 * m * kk, (m, 256, kk // 256), nbytes, "f16blk", 2.0 * m * kk, {"layers": layers}))
     return y
 
 

@@ -42,7 +42,16 @@ wh16 = wh16.to(dev)
 img16 = torch.randn(2, 3, 832, 1344, generator=g).to(dev)
 wst = torch.zeros(64, 7, 7, 4); wst[..., :3] = torch.randn(64, 7, 7, 3, generator=g) * 0.05
 wst = wst.to(dev)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from maskrcnn_amd import modules
+from test_gpu_conv import _block_sd
+blk_id = modules.FusedBottleneck.from_state_dict(_block_sd(g, 256, 64, False), "", 1, dev, "f16")
+blk_first = modules.FusedBottleneck.from_state_dict(_block_sd(g, 64, 64, True), "", 1, dev, "f16")
+x16c = torch.randn(4, 208, 336, 256, generator=g).half().to(dev)
+x16d = torch.randn(4, 208, 336, 64, generator=g).half().to(dev)
 cases = {
+    "c2_f16_block_identity": lambda: blk_id(x16c),
+    "c2_f16_block_first": lambda: blk_first(x16d),
     "wino2_linear_mask_head": lambda: ops.conv3x3_winograd(xmk, u2, None, shift, True, None, "kblocked"),
     "f16p_c4_conv2": lambda: ops.conv_f16_pipelined(x16, w16, None, shift, (1, 1, 1, 1), True, None, out_f16=True),
     "f16p_rpn_heads_p2": lambda: ops.conv_f16_pipelined_heads(x16b, w16b, None, shift512, wh16, (1, 1, 1, 1), True).part,
