@@ -56,6 +56,11 @@ constexpr int LDS_BYTES = L_TAB + 5120;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr int BAND = 4;   // tile rows per band of the tile order
+// timing-only ablations (MRCNN_BF16_ABL=<mask> python maskrcnn_amd/build.py; tools/c2_f16_ablate.sh): 1 no x loads after the first
+// tile, 2 no stores, 4 no conv2 MFMAs / fragment reads, 8 no conv3 (+ downsample) MFMAs, 16 no conv1 MFMAs. Results are wrong.
+#ifndef MRCNN_BF16_ABL
+#define MRCNN_BF16_ABL 0
+#endif
 
 struct BParams {
     const _Float16* x;      // [B][H][W][Cin]
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(512, 1) void bottleneck_c2_f16(const BParams p) {
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) wf[0][cb] = w1_frag(0, cb);
 #pragma unroll
-            for (int kc = 0; kc < KC1; ++kc) {
+            for (int kc = 0; kc < ((MRCNN_BF16_ABL & 16) ? 1 : KC1); ++kc) {
                 if (kc + 1 < KC1) {
 #pragma unroll
                     for (int cb = 0; cb < 4; ++cb) wf[(kc + 1) & 1][cb] = w1_frag(kc + 1, cb);
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void bottleneck_c2_f16(const BParams p) {
         const int tn = t + per;
         if (tn < hi) {     // the next tile's x, in flight through phases 2 and 3
             g = geometry(tn);
-            load_x(g);
+            if (!(MRCNN_BF16_ABL & 1)) load_x(g);
         }
         lds_barrier();     // every wave has finished reading the previous tile's T1
         write_t1(a1, PA, gc.inA);
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void bottleneck_c2_f16(const BParams p) {
             };
             read_tap(0, 0);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
+            for (int tap = 0; tap < ((MRCNN_BF16_ABL & 4) ? 1 : 9); ++tap) {
                 if (tap + 1 < 9) read_tap(tap + 1, (tap + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(512, 1) void bottleneck_c2_f16(const BParams p) {
                 };
                 read_group(0, 0);
 #pragma unroll
-                for (int grp = 0; grp < NG; ++grp) {
+                for (int grp = 0; grp < ((MRCNN_BF16_ABL & 8) ? 1 : NG); ++grp) {
                     if (grp + 1 < NG) read_group(grp + 1, (grp + 1) & 1);
                     __builtin_amdgcn_sched_barrier(0);
                     if (grp < 2) {
@@ -370,7 +375,8 @@ __global__ __launch_bounds__(512, 1) void bottleneck_c2_f16(const BParams p) {
                 for (int j = 0; j < 4; ++j)
                     h[j] = round_relu(__builtin_elementwise_fma(pair_of(a3[2 * hh], a3[2 * hh + 1], j), s[j], sh[j]) + res[j]);
                 const f16x8 o = pack8(h);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), y_rsrc, static_cast<int>(yoff), hp * 64, 0);
+                if (!(MRCNN_BF16_ABL & 2) || o[0] == static_cast<_Float16>(12345.0f))
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), y_rsrc, static_cast<int>(yoff), hp * 64, 0);
             }
         }
         if (tn >= hi) break;
