@@ -197,7 +197,7 @@ def conv_roofline(prof, args, H, W, modules, measured=None, measured_reason=None
     kernel_of = {"winograd": "conv3x3_wino8_f32", "winograd_spatial": "conv3x3_wino8s_f32", "winograd4": "conv3x3_wino4_f32",
                  "direct": "conv_igemm_f32",
                  "stem": "stem7x7_s2_f32",
-                 "f16": "conv_igemm_f16", "f16p": "conv_f16p", "f16blk": "bottleneck_c2_f16",
+                 "f16": "conv_igemm_f16", "f16p": "conv_f16p", "f16blk": "bottleneck_c2_f16", "f16tail": "mask_tail_f16",
                  "rpn_fused": "conv_igemm_f32<heads>", "bottleneck": "bottleneck_fused_f32"}
     if args.dump_conv:
         per = len(prof) // steps

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MRCNN_ABI_VERSION 16
+#define MRCNN_ABI_VERSION 17
 
 #define MRCNN_OK 0
 #define MRCNN_ERR_INVALID_ARGUMENT (-1) /* bad shape / null pointer / unsupported size          */
@@ -283,6 +283,19 @@ int mrcnn_bottleneck_c2_f16(const void* x_f16, int32_t batch, int32_t height, in
                             const float* s1, const float* t1, const void* w2_frags, const float* s2, const float* t2,
                             const void* w3_frags, const float* s3, const float* t3, const void* wd_frags, const float* sd,
                             const float* td, void* y_f16, mrcnn_stream_t stream);
+
+/* The tail of Mask.forward (/root/reference/model.py:906-914) of the plain-fp16 path in ONE launch (csrc/mask_tail_f16.hip):
+ *   y = sigmoid(conv5(relu(deconv(x) + bias_de)) + bias5)
+ * x fp16 NHWC [rois][height][width][256]; deconv = ConvTranspose2d(256, 256, kernel 2, stride 2) given as the A fragments
+ * (mrcnn_pack_afrags_f16) of its GEMM form [4*256][256], output row (dy*2 + dx)*256 + co (the weight mrcnn_deconv2x2_bias_act_nhwc_f16io
+ * takes), bias_de4 [4*256] (the bias repeated per sub-pixel); conv5 1x1 256 -> classes (<= 96) given as the A fragments of its
+ * weight zero-padded to [96][256], bias5 [classes]; y fp32 NHWC [rois][2*height][2*width][classes], fully overwritten.
+ * The deconv's output is rounded to fp16 where the two-launch path rounds it (its HBM tensor) but never stored.
+ * _supported: 1 when the shape is in range (cin 256, cout_deconv 256, classes <= 96, 32-bit byte offsets), else 0. */
+int mrcnn_mask_tail_f16_supported(int32_t rois, int32_t height, int32_t width, int32_t cin, int32_t cout_deconv, int32_t classes);
+int mrcnn_mask_tail_f16(const void* x_f16, int32_t rois, int32_t height, int32_t width, int32_t cin, const void* wde_frags,
+                        const float* bias_de4, int32_t cout_deconv, const void* w5_frags, const float* bias5, int32_t classes,
+                        float* y_f32, mrcnn_stream_t stream);
 
 /* RPN glue, two launches.
  * mrcnn_rpn_scores_deltas_f32 — replaces the per-level permute/view/softmax/cat of RPN.forward + rpn_detect

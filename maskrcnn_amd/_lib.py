@@ -65,6 +65,8 @@ _SIGS = {
     "mrcnn_bottleneck_c2_f16_supported": (ctypes.c_int, [c_i32] * 6),
     "mrcnn_bottleneck_c2_f16": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mrcnn_mask_tail_f16_supported": (ctypes.c_int, [c_i32] * 6),
+    "mrcnn_mask_tail_f16": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "mrcnn_maxpool_nhwc_f16": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                                 c_vp, c_vp]),
     "mrcnn_deconv2x2_bias_act_nhwc_f32": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_i32,

@@ -41,6 +41,7 @@ SOURCES = {
     "stem.hip": [],
     "bottleneck.hip": [],
     "bottleneck_op.hip": [],
+    "mask_tail_f16.hip": [],
     "bottleneck_f16.hip": ([f"-DMRCNN_BF16_ABL={int(os.environ['MRCNN_BF16_ABL'])}"] if os.environ.get("MRCNN_BF16_ABL") else []),
     "misc.hip": ["-ffp-contract=off"],
     "select.hip": ["-ffp-contract=off"],

@@ -226,6 +226,9 @@ F16_STEM_POOL = os.environ.get("MRCNN_F16_STEM_POOL", "1") != "0"
 # "f16" mode: a ResNet C2 block (planes 64, stride 1) as ONE launch (csrc/bottleneck_f16.hip: both 64-channel maps stay on chip,
 # x is read once). MRCNN_F16_FUSED_C2=0 keeps the three / four per-layer launches.
 F16_FUSED_C2 = os.environ.get("MRCNN_F16_FUSED_C2", "1") != "0"
+# "f16" mode: the mask head's deconv + ReLU + conv5 + sigmoid as ONE launch (csrc/mask_tail_f16.hip: the deconv's fp16 map stays in
+# registers). MRCNN_F16_FUSED_MASK_TAIL=0 keeps the two launches.
+F16_FUSED_MASK_TAIL = os.environ.get("MRCNN_F16_FUSED_MASK_TAIL", "1") != "0"
 # the RPN heads run inside that kernel on levels of at least this many pixels PER IMAGE (never a function of the batch: the two
 # forms round differently, and image i of a batch must equal image i alone); below it the 18-channel conv is a launch of its own
 F16_HEADS_MIN_PIXELS = int(os.environ.get("MRCNN_F16_HEADS_MIN_PIXELS", "4096"))
@@ -680,6 +683,12 @@ class FusedMask:
         self.b_de = sd[prefix + "deconv.bias"].float().repeat(4).contiguous().to(device)
         self.cout = cout
         self.conv5 = FusedConv(sd, prefix + "conv5", None, device, relu=2, precision=precision, out_f16=False)  # 2 = sigmoid
+        self.tail16 = None
+        if (precision == "f16" and F16_ACT and cin == 256 and cout == 256 and self.conv5.w.shape[0] <= 96 and self.conv5.w.shape[3] == 256
+                and self.w_de.w_hi.is_cuda):
+            w5 = self.conv5.w.w_hi.reshape(self.conv5.w.shape[0], 256)
+            w5p = torch.cat([w5, w5.new_zeros(96 - w5.size(0), 256)], 0).contiguous()
+            self.tail16 = (ops.pack_afrags_f16(self.w_de.w_hi), ops.pack_afrags_f16(w5p))
 
     def wants_f16(self) -> bool:
         """"f16" mode: RoIAlign may hand over fp16 crops (what conv1 would round fp32 ones to)."""
@@ -698,6 +707,9 @@ class FusedMask:
         for i, c in enumerate(self.convs):
             # Winograd -> Winograd: intermediate maps stay in the k-blocked layout, no transposition passes
             x = c(x, out="kblocked" if (chain and i + 1 < len(self.convs)) else "nhwc")
+        if (self.tail16 is not None and F16_FUSED_MASK_TAIL and x.dim() == 4 and x.dtype == torch.float16
+                and ops.mask_tail_f16_supported(x.size(0), x.size(1), x.size(2), x.size(3), 256, self.conv5.w.shape[0])):
+            return ops.mask_tail_f16(x, self.tail16[0], self.b_de, self.tail16[1], self.conv5.shift)
         y = self.w_de.deconv2x2(x, self.b_de, activation=1)   # [R,2h,2w,C]: deconv + bias + ReLU, scattered in place
         return self.conv5(y)                                  # 1x1 conv + bias + sigmoid (model.py:913-914)
 

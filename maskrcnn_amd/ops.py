@@ -585,6 +585,41 @@ def bottleneck_c2_f16(x: torch.Tensor, w1f, s1, t1, w2f, s2, t2, w3f, s3, t3, wd
     return y
 
 
+def mask_tail_f16_supported(rois: int, h: int, w: int, cin: int, cout_deconv: int, classes: int) -> bool:
+    """Shape gate of mask_tail_f16 (Cin 256, deconv Cout 256, classes <= 96, 32-bit byte offsets)."""
+    return bool(lib.mrcnn_mask_tail_f16_supported(int(rois), int(h), int(w), int(cin), int(cout_deconv), int(classes)))
+
+
+@_on_device
+def mask_tail_f16(x: torch.Tensor, wde_frags: torch.Tensor, bias_de4: torch.Tensor, w5_frags: torch.Tensor, bias5: torch.Tensor) -> torch.Tensor:
+    """The tail of Mask.forward (model.py:906-914) in ONE launch, plain-fp16 path (csrc/mask_tail_f16.hip): deconv 2x2 stride 2
+    + bias + ReLU (fp16, in registers) -> conv5 1x1 + bias -> sigmoid. x fp16 NHWC [R,h,w,256]; wde_frags: pack_afrags_f16 of the
+    deconv's GEMM weight [4*256,1,1,256]; w5_frags: pack_afrags_f16 of conv5's weight zero-padded to 96 rows; → fp32 [R,2h,2w,classes]."""
+    _need_gpu(x, wde_frags, bias_de4, w5_frags, bias5)
+    assert x.dtype == torch.float16 and x.is_contiguous() and x.dim() == 4
+    r, h, w, cin = x.shape
+    classes = bias5.numel()
+    if wde_frags.numel() != 1024 * cin or w5_frags.numel() != 96 * cin or bias_de4.numel() != 1024:
+        raise RuntimeError("mask_tail_f16: weight fragments / biases do not belong to a 256 -> 256 deconv and a <= 96-class conv5")
+    assert bias_de4.dtype == torch.float32 and bias5.dtype == torch.float32 and bias_de4.is_contiguous() and bias5.is_contiguous()
+    y = torch.empty(r, 2 * h, 2 * w, classes, dtype=torch.float32, device=x.device)
+    prof = CONV_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.mrcnn_mask_tail_f16(x.data_ptr(), r, h, w, cin, wde_frags.data_ptr(), bias_de4.data_ptr(), 256, w5_frags.data_ptr(),
+                                  bias5.data_ptr(), classes, y.data_ptr(), _stream()))
+    if prof is not None:
+        e1.record()
+        m = r * h * w
+        kk = cin * 1024 + 4 * 256 * classes                                   # multiply-adds per input pixel
+        layers = [(2.0 * m * cin * 1024, 2 * (m * cin + m * 1024 + cin * 1024)),          # deconv as the per-layer path books it
+                  (2.0 * m * 4 * 256 * classes, 2 * m * 1024 + 4 * m * 4 * classes + 2 * 256 * classes)]
+        prof.append((e0, e1, 2.0 * m * kk, (m, 4 * classes, kk // (4 * classes)), x.numel() * 2 + y.numel() * 4 + 2 * (1024 + 96) * cin,
+                     "f16tail", 2.0 * m * kk, {"layers": layers}))
+    return y
+
+
 @_on_device
 def conv_f16_pipelined_heads(x: torch.Tensor, w: torch.Tensor, scale, shift, w_head32: torch.Tensor, pad=(1, 1, 1, 1),
                              relu: bool = True, tile_rows: int = 0, algo_cin: int | None = None) -> "HeadSums":

@@ -672,6 +672,53 @@ def test_bottleneck_c2_f16_rejects_other_blocks(dev):
                               c2.shift, f3, c3.scale, c3.shift)
 
 
+@pytest.mark.parametrize("shape", [(3, 14, 14, 81), (1, 5, 3, 81), (400, 14, 14, 81), (7, 14, 14, 2), (2, 9, 14, 96)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+def test_mask_tail_f16_one_launch(dev, shape):
+    """The "f16" mode's mask-head tail — deconv 2x2 s2 + bias + ReLU -> conv5 1x1 + bias -> sigmoid (model.py:906-914) — as ONE
+    launch (mrcnn_mask_tail_f16: the deconv's fp16 map is conv5's MFMA operand in registers) against (a) the two launches it
+    replaces on the same fp16 operands (they round the same values to fp16 at the same place; another MFMA shape sums in another
+    order, so a few deconv values land one fp16 ulp apart: <= 2e-3 abs on the sigmoid outputs), (b) torch-CPU fp32 on the
+    fp16-rounded operands at the mode's mask bar (3e-2 abs), (c) itself: RoI i of a batch == RoI i alone, repeats bit for bit.
+    Ragged pixel sets (256 pixels per work item), 400 RoIs (configs[4]), 2 and 96 classes (the store tails)."""
+    from maskrcnn_amd import modules, ops
+    r, h, w, classes = shape
+    g = torch.Generator().manual_seed(3000 + r + classes)
+    xi = torch.randn(r, 256, h, w, generator=g).half()
+    wt = torch.randn(256, 256, 2, 2, generator=g) * math.sqrt(2.0 / 256)     # [Cin, Cout, 2, 2]
+    bde = torch.randn(256, generator=g) * 0.1
+    w5 = torch.randn(classes, 256, 1, 1, generator=g) * math.sqrt(2.0 / 256)
+    b5 = torch.randn(classes, generator=g) * 0.1
+    x = xi.permute(0, 2, 3, 1).contiguous().to(dev)
+    w4 = wt.permute(2, 3, 1, 0).reshape(4 * 256, 1, 1, 256).contiguous().to(dev)
+    w4_hi, _ = ops.split_f16(w4)
+    w5_hi, _ = ops.split_f16(w5.permute(0, 2, 3, 1).contiguous().to(dev))
+    b4, b5d = bde.repeat(4).contiguous().to(dev), b5.to(dev)
+    w5p = torch.cat([w5_hi.reshape(classes, 256), w5_hi.new_zeros(96 - classes, 256)], 0).contiguous()
+    fde, f5 = ops.pack_afrags_f16(w4_hi), ops.pack_afrags_f16(w5p)
+    assert ops.mask_tail_f16_supported(r, h, w, 256, 256, classes)
+    got = ops.mask_tail_f16(x, fde, b4, f5, b5d)
+    assert got.dtype == torch.float32 and tuple(got.shape) == (r, 2 * h, 2 * w, classes)
+    assert torch.equal(got, ops.mask_tail_f16(x, fde, b4, f5, b5d))
+    for i in (0, r - 1):
+        assert torch.equal(ops.mask_tail_f16(x[i:i + 1].contiguous(), fde, b4, f5, b5d)[0], got[i]), i
+    # the two launches
+    y = ops.deconv2x2(x, (w4_hi, None), b4, 1, 1)
+    two = ops.conv_bn_act_f16mfma(y, w5_hi, None, None, b5d, 1, (0, 0, 0, 0), 2, None, 1, products=1, out_f16=False)
+    assert (got - two).abs().max().item() <= 2e-3
+    # the reference arithmetic
+    want = torch.sigmoid(F.conv2d(F.relu(F.conv_transpose2d(xi.float(), wt.half().float(), bde, stride=2)), w5.half().float(), b5))
+    assert (got.permute(0, 3, 1, 2).cpu() - want).abs().max().item() <= 3e-2
+
+
+def test_mask_tail_f16_rejects_other_shapes(dev):
+    from maskrcnn_amd import ops
+    assert not ops.mask_tail_f16_supported(4, 14, 14, 128, 256, 81)
+    assert not ops.mask_tail_f16_supported(4, 14, 14, 256, 128, 81)
+    assert not ops.mask_tail_f16_supported(4, 14, 14, 256, 256, 97)
+    assert not ops.mask_tail_f16_supported(30000, 14, 14, 256, 256, 81)     # past the 32-bit offsets
+
+
 def test_bottleneck_fused_rejects_other_shapes(dev):
     from maskrcnn_amd import ops
     from maskrcnn_amd._lib import MaskrcnnHipError

@@ -523,8 +523,9 @@ def test_config5_f16_kernel_routing_is_independent_of_the_batch(dev):
 
 
 # conv launches of one "f16" step at 832 x 1344, R101-FPN (measured on the MI355X, round 5): the three C2 blocks are one
-# launch each (csrc/bottleneck_f16.hip) — before that 4 + 6 of the per-layer launches (f16p 116, f16 11)
-F16_ROUTING_832x1344 = {"stem": 1, "f16blk": 3, "f16p": 112, "f16": 5}
+# launch each (csrc/bottleneck_f16.hip) — before that 4 + 6 of the per-layer launches (f16p 116, f16 11) — and the mask head's deconv +
+# conv5 are one (csrc/mask_tail_f16.hip)
+F16_ROUTING_832x1344 = {"stem": 1, "f16blk": 3, "f16tail": 1, "f16p": 112, "f16": 3}
 
 
 def _iou_matrix(a, b):

@@ -49,7 +49,13 @@ blk_id = modules.FusedBottleneck.from_state_dict(_block_sd(g, 256, 64, False), "
 blk_first = modules.FusedBottleneck.from_state_dict(_block_sd(g, 64, 64, True), "", 1, dev, "f16")
 x16c = torch.randn(4, 208, 336, 256, generator=g).half().to(dev)
 x16d = torch.randn(4, 208, 336, 64, generator=g).half().to(dev)
+xmt = torch.randn(400, 14, 14, 256, generator=g).half().to(dev)
+wde16 = (torch.randn(1024, 1, 1, 256, generator=g) * 0.05).half().to(dev)
+w5p16 = torch.zeros(96, 256, dtype=torch.float16); w5p16[:81] = (torch.randn(81, 256, generator=g) * 0.05).half()
+fde, f5 = ops.pack_afrags_f16(wde16), ops.pack_afrags_f16(w5p16.to(dev))
+bde4, b5 = torch.randn(1024, generator=g).to(dev), torch.randn(81, generator=g).to(dev)
 cases = {
+    "mask_tail_f16": lambda: ops.mask_tail_f16(xmt, fde, bde4, f5, b5),
     "c2_f16_block_identity": lambda: blk_id(x16c),
     "c2_f16_block_first": lambda: blk_first(x16d),
     "wino2_linear_mask_head": lambda: ops.conv3x3_winograd(xmk, u2, None, shift, True, None, "kblocked"),
