@@ -599,6 +599,7 @@ def main():
     if world == 1 and args.in_flight > 1 and not args.graph:
         strs = [torch.cuda.Stream() for _ in range(args.in_flight)]
         torch.cuda.synchronize()
+        sub_batches, net.sub_batches = net.sub_batches, 1   # whole batches in flight: the streams are already full of them
 
         def run_on(i):
             with torch.cuda.stream(strs[i % len(strs)]):
@@ -612,6 +613,7 @@ def main():
             run_on(i)
         torch.cuda.synchronize()
         el2 = time.perf_counter() - t0
+        net.sub_batches = sub_batches
         pipelined = {"batches_in_flight": args.in_flight, "value": round(args.batch * args.steps / el2, 2), "unit": "images/s",
                      "ms_per_step_amortised": round(el2 / args.steps * 1e3, 3), "steps": args.steps,
                      "note": "throughput with consecutive steps on alternating streams; the per-step latency is NOT this figure, "
@@ -735,6 +737,7 @@ def main():
                                       f"detections [{world * args.batch},{cfg.detection_max_instances},6]"
                                       + (" — REHEARSAL: all ranks on one GPU over gloo, not a measurement" if mdist.rehearsal() else ""),
                        "hipgraph": bool(args.graph),
+                       "concurrent_sub_batches": net.sub_batches,   # 1 = the batch as one launch sequence (every mode but "f16")
                        "conv3x3": (("winograd F(4x4,3x3) on maps of >= 8 tiles of 16x32 pixels per image"
                                     + ("" if modules.WINOGRAD4_TRUNK else " (FPN smoothing and RPN only)")
                                     + ", F(2x2,3x3) elsewhere; fp32 arithmetic on the fp32 MFMA"
@@ -897,6 +900,10 @@ def config5_entry(dev, args, ops, modules, InferenceConfig, MaskRCNNInference):
     return {"config": "BASELINE configs[4] geometry on 1 GPU: ResNet-101-FPN, 832x1344 (1333x800 padded to /64), batch 8, "
                       f"{args.proposals} proposals/img, fp16 MFMA path (fp16 operands + fp16 activations in HBM, fp32 accumulate)",
             "precision": "f16", "value": round(batch * args.steps / el, 2), "unit": "images/s",
+            "concurrent_sub_batches": net.sub_batches,
+            "concurrent_sub_batches_note": "the timed step runs the batch as this many equal sub-batches on concurrent HIP streams, "
+                                           "joined before predict() returns (same tensors bit for bit; the mode's default); the "
+                                           "per-launch pass below times whole-batch launches one at a time",
             "ms_per_step": round(el / args.steps * 1e3, 3), "steps": args.steps,
             "tolerance": "this mode's bars, not the 1e-4 one (tests/test_gpu_fullsize.py): trunk 2e-2 of the activation range vs the fp32 "
                          "oracle; masks on the same boxes 3e-2 abs (sigmoid outputs in [0,1]) vs the fp32 masks; detections: >= 95 % of "

@@ -15,6 +15,7 @@ gathers — is in libmaskrcnn_hip.so; torch does device memory and streams.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -58,8 +59,12 @@ def max_batch_per_launch(cfg: InferenceConfig) -> int:
 
 class MaskRCNNInference:
     def __init__(self, state_dict: dict, cfg: InferenceConfig | None = None, device="cuda:0",
-                 precision: str = "f32"):
-        """precision: contraction mode of every conv/GEMM (modules.ConvWeight): "f32" exact-fp32 MFMA (default,
+                 precision: str = "f32", concurrent_sub_batches: int | None = None):
+        """concurrent_sub_batches: predict() runs a batch as this many equal sub-batches on concurrent HIP streams (joined before
+        it returns; the result is the same tensor bit for bit — image i of a batch equals image i alone). None = the measured
+        default: 2 in the "f16" mode, whose launches are short and leave CUs idle at their edges (configs[4]: 875 → 918 images/s),
+        1 otherwise (the fp32 step loses 2 % to the smaller launches); MRCNN_SUB_BATCHES overrides.
+        precision: contraction mode of every conv/GEMM (modules.ConvWeight): "f32" exact-fp32 MFMA (default,
         the parity mode), "f16x3" fp16-operand MFMA with the error-compensated 3-product split (fp32-grade),
         "f16" plain fp16 operands (BASELINE config 5); "f32+f16x3" (modules.MIXED): fp32 Winograd / stem / k-blocked layers as in
         "f32", fp16x3 split for the long-K GEMM-shaped layers. Activations are fp32 in HBM in every mode but "f16"."""
@@ -77,6 +82,10 @@ class MaskRCNNInference:
         self.anchors = pyramid_anchors(c).to(self.device)
         self.image_area = float(c.image_height * c.image_width)
         self.max_batch = max_batch_per_launch(c)
+        env = os.environ.get("MRCNN_SUB_BATCHES")
+        self.sub_batches = int(env) if env else (concurrent_sub_batches if concurrent_sub_batches is not None
+                                                  else (2 if precision == "f16" else 1))
+        self._side_streams = []
 
     # ---------------------------------------------------------------- stage 1: proposals
     def rpn_heads(self, fms):
@@ -122,7 +131,7 @@ class MaskRCNNInference:
     # ---------------------------------------------------------------- whole step
     @torch.no_grad()
     def predict(self, images: torch.Tensor, windows: torch.Tensor, with_masks: bool = True,
-                return_intermediates: bool = False, rois_override=None, host_counts=None):
+                return_intermediates: bool = False, rois_override=None, host_counts=None, _whole: bool = False):
         """images [B,3,H,W] fp32 NCHW, already molded (resized/padded, mean-subtracted: model.py:1102-1110);
         windows [B,4] pixel (y1,x1,y2,x2) of the un-padded image area.
         rois_override = (rois [B,P,4] normalised, counts int32 [B]): measurement aid (SURVEY.md §8d "synthetic input —
@@ -148,6 +157,11 @@ class MaskRCNNInference:
                      for i in range(0, b, step)]
             cat = lambda f: torch.cat([getattr(p_, f) for p_ in parts], 0)
             return Detections(cat("class_ids"), cat("scores"), cat("boxes"), cat("counts"), cat("masks") if with_masks else None)
+        k = self.sub_batches
+        if (k > 1 and not _whole and b >= k and b % k == 0 and not return_intermediates and host_counts is None
+                and ops.CONV_PROFILE is None          # per-launch event passes time whole-batch launches, one at a time
+                and not torch.cuda.is_current_stream_capturing()):
+            return self._predict_concurrent(images, windows, with_masks, rois_override, k)
         fms = self.backbone(images)                                        # [P2..P6] NHWC
         scores, deltas = self.rpn_heads(fms)
         rois, roi_counts, rpn_dets = self.proposals(scores, deltas)
@@ -193,6 +207,33 @@ class MaskRCNNInference:
             return det, dict(feature_maps=fms, rpn_scores=scores, rpn_deltas=deltas, rois=rois,
                              roi_counts=roi_counts, rpn_dets=rpn_dets, logits=logits, bbox=bbox)
         return det
+
+    def _predict_concurrent(self, images, windows, with_masks, rois_override, k):
+        """The batch as k equal sub-batches, each on its own HIP stream (fork after the caller's stream, join before returning):
+        short launches of one sub-batch run beside the other's instead of leaving CUs idle at their edges. Every tensor of the
+        library is the caller's and every launch goes to the stream current at the call, so concurrent steps share nothing but the
+        weights. Same result as one batch, bit for bit."""
+        b = images.size(0)
+        n = b // k
+        cur = torch.cuda.current_stream(self.device)
+        while len(self._side_streams) < k:
+            self._side_streams.append(torch.cuda.Stream(self.device))
+        windows = windows.to(self.device)
+        parts = []
+        for i in range(k):
+            s = self._side_streams[i]
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                ro = None if rois_override is None else (rois_override[0][i * n:(i + 1) * n], rois_override[1][i * n:(i + 1) * n])
+                parts.append(self.predict(images[i * n:(i + 1) * n], windows[i * n:(i + 1) * n], with_masks, rois_override=ro,
+                                          _whole=True))
+        fields = ("class_ids", "scores", "boxes", "counts") + (("masks",) if with_masks else ())
+        for i, part in enumerate(parts):
+            cur.wait_stream(self._side_streams[i])
+            for f in fields:
+                getattr(part, f).record_stream(cur)      # allocated on the side stream, read (and later freed) on the caller's
+        cat = lambda f: torch.cat([getattr(p_, f) for p_ in parts], 0)
+        return Detections(cat("class_ids"), cat("scores"), cat("boxes"), cat("counts"), cat("masks") if with_masks else None)
 
     # ---------------------------------------------------------------- images in, full-size masks out
     @torch.no_grad()

@@ -243,6 +243,45 @@ def test_step_is_hipgraph_capturable():
     assert torch.equal(captured.masks, eager.masks)
 
 
+@pytest.mark.parametrize("precision", ["f16", "f32"])
+def test_concurrent_sub_batches_give_the_same_tensors(precision):
+    """predict() with concurrent_sub_batches=2 (the "f16" mode's default: the batch as two halves on two HIP streams, joined before
+    it returns) returns what one batch returns, bit for bit — detections and masks —, call after call (the side streams' tensors
+    are handed to the caller's stream), also with injected proposals; an odd batch, a per-launch profiling pass and a hipGraph
+    capture run the batch whole."""
+    from maskrcnn_amd import modules, ops
+    from maskrcnn_amd.config import InferenceConfig
+    from maskrcnn_amd.pipeline import MaskRCNNInference
+    dev = torch.device("cuda:0")
+    h, w = 128, 192
+    cfg = InferenceConfig(image_height=h, image_width=w, backbone="resnet50", pre_nms_limit=200, proposal_count=100,
+                          detection_max_instances=10)
+    sd = modules.synthetic_state_dict("resnet50", seed=0, bn_seed=1)
+    g = torch.Generator().manual_seed(21)
+    images = (torch.randint(0, 256, (4, h, w, 3), generator=g).float() - torch.tensor(cfg.mean_pixel)).permute(0, 3, 1, 2).contiguous().to(dev)
+    windows = torch.tensor([[0., 0., float(h), float(w)]] * 4, device=dev)
+    one = MaskRCNNInference(sd, cfg, dev, precision=precision, concurrent_sub_batches=1)
+    two = MaskRCNNInference(sd, cfg, dev, precision=precision, concurrent_sub_batches=2)
+    assert MaskRCNNInference(sd, cfg, dev, precision=precision).sub_batches == (2 if precision == "f16" else 1)
+    want = one.predict(images, windows)
+    for _ in range(3):
+        got = two.predict(images, windows)
+        for f in ("class_ids", "scores", "boxes", "counts", "masks"):
+            assert torch.equal(getattr(got, f), getattr(want, f)), f
+    assert len(two._side_streams) == 2
+    got3 = two.predict(images[:3], windows[:3])                            # odd batch: whole
+    assert torch.equal(got3.masks, want.masks[:3]) and torch.equal(got3.boxes, want.boxes[:3])
+    ops.CONV_PROFILE = []
+    try:
+        two.predict(images, windows)
+        n_split = len(ops.CONV_PROFILE)
+        ops.CONV_PROFILE = []
+        one.predict(images, windows)
+        assert n_split == len(ops.CONV_PROFILE)                            # profiled whole, launch for launch
+    finally:
+        ops.CONV_PROFILE = None
+
+
 def test_full_size_trunk_and_roialign_one_image(oracle):
     """BASELINE full size (1024x1024, ResNet-50-FPN, 1000 RoIs), one image: the CPU oracle needs a few seconds.
     Trunk activations within 1e-4 of the activation range; pyramid RoIAlign of 1000 seeded RoIs on the HIP

@@ -50,7 +50,7 @@ def main():
             calls[0] += 1
             return super().predict(images, windows, with_masks=True, **k)   # every pass runs the mask head too
 
-    make_net = lambda s: Counting(s, cfg, dev, precision=args.precision)
+    make_net = lambda s: Counting(s, cfg, dev, precision=args.precision, concurrent_sub_batches=1)   # counters: whole-batch launches
     gc = torch.Generator().manual_seed(999)
     cal = (torch.randint(0, 256, (args.batch, H, W, 3), generator=gc).float() - mean).permute(0, 3, 1, 2).contiguous()
     net = bench.calibrate_heads_(sd, make_net, cal.to(dev), windows)
