@@ -687,6 +687,7 @@ def main():
         except Exception as e:
             log(f"[bench] ERROR: detect entry failed: {e!r}")
             alt_configs = (alt_configs or []) + [{"config": "detect() on uint8 images", "error": repr(e)}]
+    sub_batches = net.sub_batches
     if rank == 0 and world == 1 and args.alt_config5:
         del net
         torch.cuda.empty_cache()
@@ -737,7 +738,7 @@ def main():
                                       f"detections [{world * args.batch},{cfg.detection_max_instances},6]"
                                       + (" — REHEARSAL: all ranks on one GPU over gloo, not a measurement" if mdist.rehearsal() else ""),
                        "hipgraph": bool(args.graph),
-                       "concurrent_sub_batches": net.sub_batches,   # 1 = the batch as one launch sequence (every mode but "f16")
+                       "concurrent_sub_batches": sub_batches,   # 1 = the batch as one launch sequence (every mode but "f16")
                        "conv3x3": (("winograd F(4x4,3x3) on maps of >= 8 tiles of 16x32 pixels per image"
                                     + ("" if modules.WINOGRAD4_TRUNK else " (FPN smoothing and RPN only)")
                                     + ", F(2x2,3x3) elsewhere; fp32 arithmetic on the fp32 MFMA"
