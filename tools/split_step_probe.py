@@ -50,6 +50,20 @@ def step(parts, streams):
 
 streams = [torch.cuda.Stream() for _ in range(4)]
 ref = step(1, streams)[0]
+if len(sys.argv) > 2 and sys.argv[2] == "soak":
+    # the pipeline's own concurrent path (MaskRCNNInference._predict_concurrent), N steps, every result compared with one whole batch
+    n_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+    net.sub_batches = 2
+    bad = 0
+    for i in range(n_steps):
+        d = net.predict(images, windows, with_masks=True)
+        if i % 7 == 0:
+            torch.empty(64 << 20, dtype=torch.uint8, device=dev).fill_(i & 255)   # churn the allocator between steps
+        if not (torch.equal(d.packed(), ref.packed()) and torch.equal(d.masks, ref.masks) and torch.equal(d.counts, ref.counts)):
+            bad += 1
+    torch.cuda.synchronize()
+    print(json.dumps({"workload": f"{arch} {H}x{W} {prec}", "concurrent_sub_batches": 2, "steps": n_steps, "steps_that_differ_from_one_batch": bad}))
+    sys.exit(0)
 for parts in (1, 2, 4, 1, 2):
     for _ in range(5):
         step(parts, streams)
