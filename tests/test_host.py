@@ -398,3 +398,18 @@ def test_bench_roofline_books_executed_rows_and_is_recomputable():
     bk = r["by_kernel"]
     again = sum(v["executed_gflop_per_step"] for v in bk.values()) * 1e9 / (sum(v["ms_per_step"] for v in bk.values()) * 1e-3) / peak
     assert abs(again - r["conv_path"]["executed_frac"]) < 1e-3 and abs(again - r["frac"]) < 1e-3
+
+
+def test_afrag_row_permutation_is_a_bijection_with_consecutive_lane_channels():
+    """The weight layout contract of the one-launch fp16 kernels (include/maskrcnn_hip.h: mrcnn_pack_afrags_f16; csrc/bottleneck_f16.hip,
+    csrc/mask_tail_f16.hip), restated: row rho of 16-channel block cb holds channel (cb>>1)*32 + (rho>>2)*8 + (cb&1)*4 + (rho&3).
+    (a) it is a permutation of the channels for every even block count; (b) a lane of v_mfma_f32_16x16x32_f16's accumulator holds
+    rows q*4 .. q*4+3 of a block (q = lane >> 4), so accumulators (2h, 2h+1) of a lane are channels h*32 + q*8 .. +7 in order —
+    the lane's B-operand fragment (k = h*32 + q*8 + j) of the next 1x1 conv and 16 contiguous bytes of NHWC fp16 output."""
+    ch = lambda cb, rho: (cb >> 1) * 32 + (rho >> 2) * 8 + (cb & 1) * 4 + (rho & 3)
+    for nb in (4, 6, 16, 64):
+        assert sorted(ch(cb, rho) for cb in range(nb) for rho in range(16)) == list(range(16 * nb))
+        for h in range(nb // 2):
+            for q in range(4):
+                lane_channels = [ch(2 * h + half, q * 4 + r) for half in (0, 1) for r in range(4)]
+                assert lane_channels == list(range(h * 32 + q * 8, h * 32 + q * 8 + 8))
