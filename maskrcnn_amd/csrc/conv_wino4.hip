@@ -92,11 +92,14 @@ struct Wino4Params {
 // profiles/r05_w4_reproducibility.jsonl). vmcnt(0) instead of vmcnt(3) does not help (3 of 20 000); neither the hazard table
 // nor the LDS-DMA ordering rules explain why an s_waitcnt that directly follows an LDS instruction, or LDS reads that directly
 // follow the barrier, should matter. -DMRCNN_W4_NO_RACE_FIX builds the kernel as it was (for the A/B).
-#ifdef MRCNN_W4_NO_RACE_FIX
+#if defined(MRCNN_W4_NO_RACE_FIX) || defined(MRCNN_W4_NO_STAGING_NOPS)
 #define W4_NOPS_AFTER_STAGING ""
-#define W4_NOPS_BEFORE_EPILOGUE_BARRIER ""
 #else
 #define W4_NOPS_AFTER_STAGING "\n\ts_nop 7"
+#endif
+#if defined(MRCNN_W4_NO_RACE_FIX) || defined(MRCNN_W4_NO_EPILOGUE_NOPS)
+#define W4_NOPS_BEFORE_EPILOGUE_BARRIER ""
+#else
 #define W4_NOPS_BEFORE_EPILOGUE_BARRIER "s_nop 7\n\t"
 #endif
 #ifdef MRCNN_W4_VMCNT0
@@ -578,7 +581,13 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                         const f32x16& a16 = acc[(i * 3 + j) * 2 + nb];
                         lds_f32* zp = Z + ((cg0 + i * 6 + j) * 8 + 4 * lh) * 64 + nb * 32 + ln;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) zp[e * 64] = a16[4 * g + e];
+                        for (int e = 0; e < 4; ++e) {
+                            float t = a16[4 * g + e];
+#ifdef MRCNN_W4_Z_FROM_VGPR
+                            asm volatile("" : "+v"(t));   // experiment: the LDS store sources a VGPR, not the accumulator register
+#endif
+                            zp[e * 64] = t;
+                        }
                         __builtin_amdgcn_sched_barrier(0);  // or all 72 accumulator registers of the round are copied out at once
                     }
             // barriers of the epilogue: LDS only. __syncthreads() would also wait (vmcnt(0)) for the previous round's global
