@@ -10,7 +10,9 @@ import os
 import re
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libmaskrcnn_hip.so")
+# MRCNN_LIB: load another build of the same library (an experiment / ablation build made by `build.py --variant NAME`,
+# which never overwrites the product file). Same ABI check, same no-fallback rule.
+LIB_PATH = os.environ.get("MRCNN_LIB") or os.path.join(PKG, "libmaskrcnn_hip.so")
 HEADER = os.path.join(os.path.dirname(PKG), "include", "maskrcnn_hip.h")
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p

@@ -1,6 +1,8 @@
 """Build libmaskrcnn_hip.so (hipcc, gfx950 only) in-tree: maskrcnn_amd/libmaskrcnn_hip.so.
 
     python maskrcnn_amd/build.py [--force] [--verbose]   (run as a script: importing the package needs the built library)
+    python maskrcnn_amd/build.py --variant NAME [--only a.hip,b.hip] [-DMACRO ...]   an experiment build: objects and library under
+        maskrcnn_amd/csrc/build/variants/NAME/ (printed; load it with MRCNN_LIB=<path>); the product library is not touched
 
 hipcc cross-compiles without a GPU. Objects are cached by mtime under maskrcnn_amd/csrc/build/.
 """
@@ -63,8 +65,17 @@ def _newer(target: str, deps: list[str]) -> bool:
     return os.path.exists(target) and os.path.getmtime(target) >= max(os.path.getmtime(d) for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, variant: str | None = None, defines: tuple = (),
+          only: tuple = ()) -> str:
+    """variant builds: `only` names the sources the defines apply to (compiled into the variant directory); every other
+    object is the product's (built first if need be)."""
+    if variant and only:
+        build(force=False, verbose=verbose)
+    obj_dir, lib_path = OBJ, LIB
+    if variant:
+        obj_dir = os.path.join(OBJ, "variants", variant)
+        lib_path = os.path.join(obj_dir, "libmaskrcnn_hip.so")
+    os.makedirs(obj_dir, exist_ok=True)
     cc = hipcc()
     headers = [os.path.join(ROOT, "include", "maskrcnn_hip.h"), os.path.abspath(__file__)]
     headers += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
@@ -75,8 +86,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
             continue
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        mine = not (variant and only) or src in only
+        o = os.path.join(obj_dir if mine else OBJ, src.replace(".hip", ".o"))
         objs.append(o)
+        if not mine:
+            continue
+        extra = [*extra, *defines]
         # an object is reused only when it was built with the same flags (e.g. MRCNN_W4_ABLATIONS toggles variants)
         flags = " ".join([*COMMON, *extra])
         stamp = o + ".flags"
@@ -99,10 +114,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for stamp, flags in stamps:   # only after every compile succeeded
         with open(stamp, "w") as fh:
             fh.write(flags)
-    if jobs or force or not _newer(LIB, objs):
-        run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB])
-    return LIB
+    if jobs or force or not _newer(lib_path, objs):
+        run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib_path])
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))
+    _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    _only = tuple(sys.argv[sys.argv.index("--only") + 1].split(",")) if "--only" in sys.argv else ()
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv, variant=_variant,
+                defines=tuple(a for a in sys.argv[1:] if a.startswith("-D")), only=_only))

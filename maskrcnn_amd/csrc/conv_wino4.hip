@@ -75,48 +75,14 @@ struct Wino4Params {
     int C3;
     unsigned w3_bytes, y3_bytes;
     int debug;  // MRCNN_W4_DEBUG: timing ablations (wrong results): 1 no DMA, 2 no transform, 4 no patch reads, 8 no B reads, 16 no raw staging
-    int diag;   // MRCNN_W4_DIAG builds only (tools/w4_diag_soak.py; results stay correct): 1 one tile per workgroup (host),
-                // 2 a second barrier behind every staging barrier, 4 vmcnt(0) in front of every epilogue barrier, 8 both
-                // buffers' worth of nops behind the staging barrier
 };
 
-// The two barriers of the kernel. STAGING (end of the prologue and of every k tile): every LDS-DMA of this wave has landed —
-// the three raw loads issued last may stay in flight —, every LDS access is retired, barrier. EPILOGUE (twice per round): LDS
-// only (a __syncthreads() would also drain the round's global stores).
-// Round 5: the eight wait states on either side are a measured fix, not an understood one. Soaked on constant inputs, the kernel
-// WITHOUT them returned a launch with a few wrong tiles (whole 16 x 32 x 64 tiles, or single 4-row rounds of the epilogue, all of
-// one iteration of the persistent loop) about once per 3 000 - 5 000 launches of 1 024 tiles — on every box, in every run of that
-// binary, while builds whose instruction stream differed by a few scalar instructions at these two places ran 720 000 launches
-// clean (tools/w4_race_probe.py, w4_diag_soak.py; same box, builds alternating, events per 40 000 launches: without 15 and 4,
-// nops behind the staging barrier only 12 and 5, nops in front of the epilogue barriers only 4 and 3, both 0 and 0;
-// profiles/r05_w4_reproducibility.jsonl). vmcnt(0) instead of vmcnt(3) does not help (3 of 20 000); neither the hazard table
-// nor the LDS-DMA ordering rules explain why an s_waitcnt that directly follows an LDS instruction, or LDS reads that directly
-// follow the barrier, should matter. -DMRCNN_W4_NO_RACE_FIX builds the kernel as it was (for the A/B).
-#if defined(MRCNN_W4_NO_RACE_FIX) || defined(MRCNN_W4_NO_STAGING_NOPS)
-#define W4_NOPS_AFTER_STAGING ""
-#else
-#define W4_NOPS_AFTER_STAGING "\n\ts_nop 7"
-#endif
-#if defined(MRCNN_W4_NO_RACE_FIX) || defined(MRCNN_W4_NO_EPILOGUE_NOPS)
-#define W4_NOPS_BEFORE_EPILOGUE_BARRIER ""
-#else
-#define W4_NOPS_BEFORE_EPILOGUE_BARRIER "s_nop 7\n\t"
-#endif
-#ifdef MRCNN_W4_VMCNT0
-#define W4_STAGE_WAIT_AND_BARRIER_() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" W4_NOPS_AFTER_STAGING ::: "memory")
-#else
-#define W4_STAGE_WAIT_AND_BARRIER_() asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" W4_NOPS_AFTER_STAGING ::: "memory")
-#endif
-#ifdef MRCNN_W4_DIAG
-#define W4_STAGE_WAIT_AND_BARRIER() do { W4_STAGE_WAIT_AND_BARRIER_(); \
-        if (p.diag & 2) asm volatile("s_barrier" ::: "memory"); \
-        if (p.diag & 8) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); } while (0)
-#define W4_EPILOGUE_BARRIER() do { if (p.diag & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-        asm volatile(W4_NOPS_BEFORE_EPILOGUE_BARRIER "s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } while (0)
-#else
-#define W4_STAGE_WAIT_AND_BARRIER() W4_STAGE_WAIT_AND_BARRIER_()
-#define W4_EPILOGUE_BARRIER() asm volatile(W4_NOPS_BEFORE_EPILOGUE_BARRIER "s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#endif
+// The barriers of the kernel, all by hand (a __syncthreads() would also drain the vector-memory queue: the raw loads that are
+// meant to stay in flight, the previous round's global stores). STAGING (end of the prologue and of every k tile that staged
+// something): every LDS-DMA this wave issued has landed — `vm` is the number of YOUNGER vector-memory operations, the raw
+// loads to registers, that may stay in flight —, every LDS access of the wave is retired, barrier. EPILOGUE: LDS only.
+#define W4_STAGE_WAIT_AND_BARRIER(vm) asm volatile("s_waitcnt vmcnt(" #vm ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define W4_EPILOGUE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 constexpr int W4_N = 64;                              // output channels per workgroup
 #ifndef MRCNN_W4_WALK_SHIFT
 #define MRCNN_W4_WALK_SHIFT 4
@@ -128,7 +94,8 @@ constexpr int W4_RPLANE = 18 * W4_RW + 8;             // pairs per (buffer, chan
 constexpr int W4_RS_FLOATS = 2 * 2 * W4_RPLANE * 2;   // raw region: [2 buffers][2 channel pairs][plane][2]
 constexpr int W4_UBUF = 36 * 256;                     // floats per U buffer: [36][2 channel pairs][64][2]
 constexpr int W4_Z_FLOATS = 36 * 8 * 64;              // epilogue exchange of a round: [36 components][8 positions][64 channels]
-constexpr size_t WINO4_LDS = sizeof(float) * (W4_RS_FLOATS + 2 * W4_UBUF);
+constexpr int W4_DUMP_FLOATS = 256;                   // where the LDS-DMAs of k tiles past the last land (dma_u1): behind everything else
+constexpr size_t WINO4_LDS = sizeof(float) * (W4_RS_FLOATS + 2 * W4_UBUF + W4_DUMP_FLOATS);
 // HEADS, epilogue: behind Z the round's transposed tile T (128 pixels x 64 channels; it overlaps U buffer 1, dead then), the
 // N tile's head weights (the 8 B-operand pieces [j][lane][4]) and — alive through the whole N-tile walk of an M tile, beyond
 // the staging area — the M tile's head sums [512 pixels][20] (18 real columns)
@@ -138,7 +105,7 @@ constexpr int W4_HP = 20;
 constexpr int W4_T_OFF = W4_Z_FLOATS;
 constexpr int W4_WH_OFF = W4_T_OFF + W4_T_FLOATS;
 constexpr int W4_H_OFF = W4_WH_OFF + W4_WH_FLOATS;
-constexpr size_t WINO4_HEADS_LDS = sizeof(float) * (W4_H_OFF + 512 * W4_HP);
+constexpr size_t WINO4_HEADS_LDS = sizeof(float) * (W4_H_OFF + 512 * W4_HP + W4_DUMP_FLOATS);
 static_assert(W4_H_OFF >= W4_RS_FLOATS + 2 * W4_UBUF && WINO4_HEADS_LDS <= 160 * 1024, "HEADS LDS map");
 // CONV3: the 1x1 expansion's weights W3 [<= 256][64] stay in LDS for the workgroup's whole life, ABOVE the staging area (the
 // k loop never touches them), as 64 B-operand pieces [column block][j][lane][4]; the epilogue's transposed tile T has no
@@ -146,7 +113,7 @@ static_assert(W4_H_OFF >= W4_RS_FLOATS + 2 * W4_UBUF && WINO4_HEADS_LDS <= 160 *
 // only the half-wave that owns position p8 reads (all 36 of its chunks, into registers) before it writes T there
 constexpr int W4_W3_OFF = W4_RS_FLOATS + 2 * W4_UBUF;
 constexpr int W4_W3_FLOATS = 256 * W4_N;
-constexpr size_t WINO4_CONV3_LDS = sizeof(float) * (W4_W3_OFF + W4_W3_FLOATS);
+constexpr size_t WINO4_CONV3_LDS = sizeof(float) * (W4_W3_OFF + W4_W3_FLOATS + W4_DUMP_FLOATS);
 static_assert(WINO4_CONV3_LDS <= 160 * 1024 && W4_Z_FLOATS <= W4_W3_OFF, "CONV3 LDS map");
 static_assert(W4_Z_FLOATS <= W4_RS_FLOATS + 2 * W4_UBUF, "the exchange buffer aliases the staging buffers");
 
@@ -265,10 +232,13 @@ __device__ __forceinline__ void at4p(const f32x2 m0, const f32x2 m1, const f32x2
 // conv_wino.hip): a workgroup owns whole M tiles and walks their N tiles, adding each N tile's contribution to the M tile's
 // head sums, which stay in LDS until the last N tile writes them out.
 // DBG: compile-time tuning variants (MRCNN_W4_ABLATIONS builds): bits 1..1024 leave parts out (wrong results, timing only),
-// 2048 records s_memtime stamps of a tile's phases (tools/w4_stamp.py). DBG = 0 is the product.
+// 2048 records s_memtime stamps of a tile's phases (tools/w4_stamp.py); 4096 delays wave 0 behind the prologue's staging
+// barrier and 8192 leaves out the barrier behind the prologue's operand reads (4096 alone: results unchanged; 4096 + 8192: round
+// 5's rare wrong tiles on every tile — tools/w4_war_demo.py). DBG = 0 is the product.
 template <int QA, int QB, int DBG, bool HEADS, bool ACT, bool CONV3 = false>
 __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) {
     static_assert(!(HEADS && CONV3), "one fused consumer at a time");
+    constexpr int W4_DUMP_OFF = HEADS ? W4_H_OFF + 512 * W4_HP : CONV3 ? W4_W3_OFF + W4_W3_FLOATS : W4_RS_FLOATS + 2 * W4_UBUF;
     lds_f32x2* Rs = (lds_f32x2*)smem;            // [2][2][W4_RPLANE] channel pairs
     lds_f32* Us = smem + W4_RS_FLOATS;           // [2][36][2][64][2]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -360,7 +330,10 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         const unsigned u_comp = static_cast<unsigned>(p.Cout) * 16u;  // bytes per component of a k tile
 
         u32x4 rr[3];
-        auto kclamp = [&](int kt) { return kt < nk ? kt : nk - 1; };  // past the end: reload the last k tile, never used
+        // The k loop runs one instruction stream for every k tile, the last two included — they stage "k tiles" nk and nk + 1.
+        // Raw pixels: the last k tile again, into registers and the raw buffers nobody reads any more (plain LDS stores,
+        // retired by the wave's own lgkmcnt(0) in front of the next barrier). U: see dma_u1.
+        auto kclamp = [&](int kt) { return kt < nk ? kt : nk - 1; };
         auto load_raw1 = [&](int kt, int i) {
             const int k = kclamp(kt);
             const int soff = static_cast<int>(static_cast<unsigned>(k >> 1) * p.x_plane + static_cast<unsigned>(k & 1) * 16u);
@@ -372,10 +345,17 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
             base[r_lds[i]] = f32x2{v.x, v.y};
             base[W4_RPLANE + r_lds[i]] = f32x2{v.z, v.w};
         };
+        // An LDS-DMA for a k tile that does not exist (kt >= nk: the last two k tiles of the loop) lands in the DUMP — 1 KB that
+        // nothing ever reads and nothing aliases — never in the U buffers: those are the bytes the epilogue's exchange area Z
+        // (and HEADS' T) is about to occupy, and no byte that a DMA targets may be one that somebody else writes or reads
+        // without a covering vmcnt + barrier in between. (Round 5 let these dummies land in the U buffers.) The load itself
+        // stays, so that the k tile's vector-memory count (9 DMAs, then 3 raw loads) is the same in every k tile.
+        lds_f32* const dump = smem + W4_DUMP_OFF;
         auto dma_u1 = [&](int kt, int buf, int j) {
             const int c = wave * 9 + j;
             const int soff = static_cast<int>(static_cast<unsigned>(kclamp(kt)) * p.u_ktile + static_cast<unsigned>(c) * u_comp);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rsrc, Us + buf * W4_UBUF + c * 256, 16, static_cast<int>(u_voff), soff, 0, 0);
+            lds_f32* dst = kt < nk ? Us + buf * W4_UBUF + c * 256 : dump;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(u_rsrc, dst, 16, static_cast<int>(u_voff), soff, 0, 0);
         };
 
         // the lane's position: px = ln & 7, py = ln >> 3; raw rows 4 py + dy, columns 4 px + dx
@@ -467,7 +447,10 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) load_raw1(2, i);
-        W4_STAGE_WAIT_AND_BARRIER();
+        W4_STAGE_WAIT_AND_BARRIER(3);
+        if constexpr ((DBG & 4096) != 0) {  // ablation builds: wave 0 falls about 8 000 cycles behind the others here
+            if (wave == 0) __builtin_amdgcn_s_sleep(127);
+        }
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
             read_col(0, c);
@@ -477,7 +460,14 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         for (int i = 0; i < 3; ++i) col_stage(0, i);
 #pragma unroll
         for (int q = 0; q < 18; ++q) read_b(0, 0, q);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // THE barrier round 5's rare wrong tiles were missing (round 6, tools/w4_forensics.py): the reads above are
+        // of buffer 0 (raw k tile 0, U(0)) AFTER the staging barrier, and k tile 0 below re-stages buffer 0 — U(2) by LDS-DMA
+        // from MFMA slot 10 on, raw k tile 2 in slots 27-29. In steady state a k tile's operands are read during the k tile
+        // before, in front of ITS closing barrier; here nothing separated a slow wave's reads from the other waves' writes
+        // except those 10 slots (about 700 cycles). Every captured wrong tile (50 of 50) was wave 0's quadrant of k tile 0
+        // computed from another wave's U(2) pieces (exactly) or raw k tile 2 pixels. All reads retired, then the barrier.
+        if constexpr ((DBG & 8192) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ablation builds: round 5's kernel
+        else W4_EPILOGUE_BARRIER();
         tie_b(0);
 
         // ---- one k tile. 36 MFMA slots, the order pinned (sched_barrier after every slot); beside the MFMAs of k tile kt:
@@ -513,7 +503,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            W4_STAGE_WAIT_AND_BARRIER();
+            W4_STAGE_WAIT_AND_BARRIER(3);
             tie_b(NXT);
         };
         STAMP();  // 2: prologue done
@@ -524,7 +514,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         // The MFMAs are inline asm: the compiler's hazard recogniser does not see them. Guarantee — rather than rely on the
         // instructions that happen to sit in between — the wait states a 16-pass MFMA needs before its accumulator is read
         // (18 for a VALU / vector-memory read of the result): 20 here, once per tile.
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 3" ::: "memory");
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
         STAMP();  // 3: k loop done
 
         // ---- epilogue: four rounds of 8 positions (accumulator registers 4g..4g+3 of both lane halves)
@@ -582,11 +572,7 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                         lds_f32* zp = Z + ((cg0 + i * 6 + j) * 8 + 4 * lh) * 64 + nb * 32 + ln;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float t = a16[4 * g + e];
-#ifdef MRCNN_W4_Z_FROM_VGPR
-                            asm volatile("" : "+v"(t));   // experiment: the LDS store sources a VGPR, not the accumulator register
-#endif
-                            zp[e * 64] = t;
+                            zp[e * 64] = a16[4 * g + e];
                         }
                         __builtin_amdgcn_sched_barrier(0);  // or all 72 accumulator registers of the round are copied out at once
                     }
@@ -888,12 +874,8 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
     p.w_head = nullptr; p.head_part = nullptr; p.head_bytes = 0;
     p.w3 = nullptr; p.scale3 = nullptr; p.shift3 = nullptr; p.res3 = nullptr; p.y3 = nullptr; p.C3 = 0; p.w3_bytes = 0; p.y3_bytes = 0;
     p.debug = 0;
-    p.diag = 0;
 #ifdef MRCNN_W4_ABLATIONS
     p.debug = getenv("MRCNN_W4_DEBUG") ? atoi(getenv("MRCNN_W4_DEBUG")) : 0;
-#endif
-#ifdef MRCNN_W4_DIAG
-    p.diag = getenv("MRCNN_W4_DIAG") ? atoi(getenv("MRCNN_W4_DIAG")) : 0;
 #endif
     const long long grid = 8LL * ((p.tiles_m + 7) / 8) * p.tiles_n;
     MRCNN_REQUIRE(grid <= 0x7fffffffLL, "conv3x3_winograd4: grid too large");
@@ -907,6 +889,8 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
         case 16: kern = conv3x3_wino4_f32<16, false>; break;
         case 31: kern = conv3x3_wino4_f32<31, false>; break;
         case 2048: kern = conv3x3_wino4_f32<2048, false>; break;
+        case 4096: kern = conv3x3_wino4_f32<4096, false, false>; break;
+        case 12288: kern = conv3x3_wino4_f32<12288, false, false>; break;
         case 63: kern = conv3x3_wino4_f32<63, false>; break;
         case 95: kern = conv3x3_wino4_f32<95, false>; break;
         default: break;
@@ -917,7 +901,7 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
     const int cus = mrcnn::device_cu_count();
     if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd4: cannot query the device");
     const int ncu = cus >= 8 ? (cus / 8) * 8 : 8;
-    const long long launch = (grid > ncu && !(p.diag & 1)) ? ncu : grid;
+    const long long launch = grid > ncu ? ncu : grid;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(launch)), dim3(256), WINO4_LDS, mrcnn::as_stream(stream), p);
     return mrcnn::check_launch("conv3x3_wino4_f32");
 }
@@ -957,12 +941,8 @@ extern "C" int mrcnn_conv3x3_winograd4_heads_f32(const float* x_kblocked, int32_
     p.head_bytes = static_cast<unsigned>(4LL * rows * 32);
     p.w3 = nullptr; p.scale3 = nullptr; p.shift3 = nullptr; p.res3 = nullptr; p.y3 = nullptr; p.C3 = 0; p.w3_bytes = 0; p.y3_bytes = 0;
     p.debug = 0;
-    p.diag = 0;
 #ifdef MRCNN_W4_ABLATIONS
     p.debug = getenv("MRCNN_W4_DEBUG") ? atoi(getenv("MRCNN_W4_DEBUG")) : 0;
-#endif
-#ifdef MRCNN_W4_DIAG
-    p.diag = getenv("MRCNN_W4_DIAG") ? atoi(getenv("MRCNN_W4_DIAG")) : 0;
 #endif
     void (*kern)(const Wino4Params) = activation ? conv3x3_wino4_f32<0, true, true> : conv3x3_wino4_f32<0, true, false>;
 #ifdef MRCNN_W4_ABLATIONS
@@ -1021,10 +1001,6 @@ extern "C" int mrcnn_conv3x3_winograd4_conv3_f32(const float* x_kblocked, int32_
     p.w3_bytes = static_cast<unsigned>(4LL * c3 * W4_N);
     p.y3_bytes = static_cast<unsigned>(4LL * px * c3);
     p.debug = 0;
-    p.diag = 0;
-#ifdef MRCNN_W4_DIAG
-    p.diag = getenv("MRCNN_W4_DIAG") ? atoi(getenv("MRCNN_W4_DIAG")) : 0;
-#endif
     void (*kern)(const Wino4Params) = conv3x3_wino4_f32<0, false, true, true>;
     if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(kern), WINO4_CONV3_LDS, "conv3x3_winograd4_conv3"))
         return rc;
@@ -1032,7 +1008,7 @@ extern "C" int mrcnn_conv3x3_winograd4_conv3_f32(const float* x_kblocked, int32_
     if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd4_conv3: cannot query the device");
     const int ncu = cus >= 8 ? (cus / 8) * 8 : 8;
     const long long grid = 8LL * ((p.tiles_m + 7) / 8);
-    const long long launch = (grid > ncu && !(p.diag & 1)) ? ncu : grid;
+    const long long launch = grid > ncu ? ncu : grid;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(launch)), dim3(256), WINO4_CONV3_LDS, mrcnn::as_stream(stream), p);
     return mrcnn::check_launch("conv3x3_wino4_f32<conv3>");
 }
