@@ -77,6 +77,7 @@ struct BParams {
 
 __device__ __forceinline__ void lds_barrier() {   // LDS-only: outstanding global loads / stores stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    MRCNN_SYNC_FUZZ_POINT();
 }
 
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }

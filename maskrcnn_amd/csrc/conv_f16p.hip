@@ -32,6 +32,9 @@
 //     in their prologue and epilogue, and a second workgroup is what covers them.
 #include "common.hpp"
 
+// every workgroup barrier of this file (schedule-fuzz builds sleep a pseudo-random time behind each: common.hpp)
+#define P8_BARRIER() do { __builtin_amdgcn_s_barrier(); MRCNN_SYNC_FUZZ_POINT(); } while (0)
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -222,8 +225,8 @@ __global__ __launch_bounds__(512, (P8Geom<TMW, NWT>::WGS)) void conv_f16p(const 
     c2 = c1;
     c2.advance(p);
     wait_vm<G::WAITN>();
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second group runs one barrier behind
+    P8_BARRIER();
+    if (wr == 1) P8_BARRIER();  // the second group runs one barrier behind
 
     f16x8 wf[NWT], xf[T0];
     // one phase: S = 0..3 of k tile kt with LDS parity PAR
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(512, (P8Geom<TMW, NWT>::WGS)) void conv_f16p(const 
         if constexpr ((S) == 2) dma_b(kt + 2, 0);                                                                    \
         if constexpr ((S) == 3) dma_a(kt + 2, 0, c2);                                                                \
         wait_vm<G::WAITN>();                                                                                         \
-        __builtin_amdgcn_s_barrier();                                                                                \
+        P8_BARRIER();                                                                                \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         __builtin_amdgcn_s_setprio(1);                                                                               \
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(512, (P8Geom<TMW, NWT>::WGS)) void conv_f16p(const 
         }                                                                                                            \
         __builtin_amdgcn_s_setprio(0);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        __builtin_amdgcn_s_barrier();                                                                                \
+        P8_BARRIER();                                                                                \
     }
 
     for (int kt = 0; kt < nk; kt += 2) {
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(512, (P8Geom<TMW, NWT>::WGS)) void conv_f16p(const 
         }
     }
 #undef P8_PHASE
-    if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with the second group's last barrier
+    if (wr == 0) P8_BARRIER();  // pairs with the second group's last barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: lane (pixel l16 of a pixel tile, channel group lq) holds, per 32-channel half h, the channels ----------

@@ -81,8 +81,9 @@ struct Wino4Params {
 // meant to stay in flight, the previous round's global stores). STAGING (end of the prologue and of every k tile that staged
 // something): every LDS-DMA this wave issued has landed — `vm` is the number of YOUNGER vector-memory operations, the raw
 // loads to registers, that may stay in flight —, every LDS access of the wave is retired, barrier. EPILOGUE: LDS only.
-#define W4_STAGE_WAIT_AND_BARRIER(vm) asm volatile("s_waitcnt vmcnt(" #vm ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#define W4_EPILOGUE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define W4_STAGE_WAIT_AND_BARRIER(vm) \
+    do { asm volatile("s_waitcnt vmcnt(" #vm ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); MRCNN_SYNC_FUZZ_POINT(); } while (0)
+#define W4_EPILOGUE_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); MRCNN_SYNC_FUZZ_POINT(); } while (0)
 constexpr int W4_N = 64;                              // output channels per workgroup
 #ifndef MRCNN_W4_WALK_SHIFT
 #define MRCNN_W4_WALK_SHIFT 4
@@ -374,6 +375,11 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         for (int i = 0; i < 18; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        // acc[0] is in its register class BEFORE the k loop: left to the loop's first MFMA, the HEADS and CONV3 instantiations
+        // copied a[0:15] to VGPRs and back at the head of every loop trip (32 v_accvgpr_* per two k tiles) — and a build whose
+        // register allocation moved that copy INTO the loop read the accumulator 6 wait states behind an asm MFMA, which the
+        // compiler cannot see: wrong sums (tools/isa_audit.py checks C and D pin both)
+        asm volatile("" : "+a"(acc[0]));
 
         // A: operand sets of the k tile in flight and the next one. B: ONE set, refreshed in place — the MFMAs run in
         // groups of four (two accumulators x two k steps, alternating, so that no MFMA waits for the one before it), Bv[2g]
@@ -890,6 +896,7 @@ extern "C" int mrcnn_conv3x3_winograd4_f32(const float* x_kblocked, int32_t batc
         case 31: kern = conv3x3_wino4_f32<31, false>; break;
         case 2048: kern = conv3x3_wino4_f32<2048, false>; break;
         case 4096: kern = conv3x3_wino4_f32<4096, false, false>; break;
+        case 8192: kern = conv3x3_wino4_f32<8192, false, false>; break;
         case 12288: kern = conv3x3_wino4_f32<12288, false, false>; break;
         case 63: kern = conv3x3_wino4_f32<63, false>; break;
         case 95: kern = conv3x3_wino4_f32<95, false>; break;

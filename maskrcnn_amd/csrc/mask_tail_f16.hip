@@ -49,7 +49,10 @@ struct MTParams {
     unsigned x_bytes, y_bytes;
 };
 
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    MRCNN_SYNC_FUZZ_POINT();
+}
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
 __global__ __launch_bounds__(512, 1) void mask_tail_f16(const MTParams p) {

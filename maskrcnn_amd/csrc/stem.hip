@@ -289,7 +289,10 @@ __global__ __launch_bounds__(SP_THREADS, 1) void stem7x7_s2_pool_f16(const StemP
     // by 39 * 71 and 71 made the kernel VALU-bound.
     // barriers are LDS-only: __syncthreads() also waits for vector memory (vmcnt(0)), i.e. for the prefetched patch and for the
     // pool's stores
-    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        MRCNN_SYNC_FUZZ_POINT();
+    };
     constexpr int NE = 3 * SP_IH * (SP_IW - 1);
     constexpr int NL = (NE + SP_THREADS - 1) / SP_THREADS;   // 15
     int s_rel[NL];        // (c * H + py) * W + px
@@ -503,7 +506,10 @@ __global__ __launch_bounds__(256, 1) void stem7x7_s2_pool_f32(const StemPool32Pa
     }
     const int b_base = ln * 4 + lh * 2;   // + 32 * 4 for the second channel half
 
-    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto lds_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        MRCNN_SYNC_FUZZ_POINT();
+    };
     // patch elements of a thread: fixed offsets relative to the tile's origin and fixed places in the LDS patch (computed once)
     constexpr int NE = 3 * S3_IH * S3_IW;                     // 7455
     constexpr int NL = (NE + 255) / 256;                      // 30
