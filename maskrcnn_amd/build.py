@@ -36,11 +36,7 @@ SOURCES = {
     "conv_f16p.hip": [],
     "conv_wino.hip": ABL,
     "conv_wino4.hip": (["-DMRCNN_W4_ABLATIONS"] if (os.environ.get("MRCNN_W4_ABLATIONS") or os.environ.get("MRCNN_ABLATIONS")) else [])
-                      + ([f"-DMRCNN_W4_WALK_SHIFT={int(os.environ['MRCNN_W4_WALK_SHIFT'])}"] if os.environ.get("MRCNN_W4_WALK_SHIFT") else [])
-                      + (["-DMRCNN_W4_VMCNT0"] if os.environ.get("MRCNN_W4_VMCNT0") else [])
-                      + (["-DMRCNN_W4_DIAG"] if os.environ.get("MRCNN_W4_DIAG_BUILD") else [])
-                      + (["-DMRCNN_W4_NO_RACE_FIX"] if os.environ.get("MRCNN_W4_NO_RACE_FIX") else [])
-                      + [f"-D{m}" for m in ("MRCNN_W4_NO_STAGING_NOPS", "MRCNN_W4_NO_EPILOGUE_NOPS", "MRCNN_W4_Z_FROM_VGPR") if os.environ.get(m)],
+                      + ([f"-DMRCNN_W4_WALK_SHIFT={int(os.environ['MRCNN_W4_WALK_SHIFT'])}"] if os.environ.get("MRCNN_W4_WALK_SHIFT") else []),
     "stem.hip": [],
     "bottleneck.hip": [],
     "bottleneck_op.hip": [],

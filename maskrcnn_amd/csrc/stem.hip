@@ -728,7 +728,9 @@ extern "C" int mrcnn_stem_conv7x7_s2_pool_f32(const float* x_nchw, int32_t batch
     // (an odd conv size would give SamePad2d(3, 2) a top / left component — model.py:64-87 — and shift the pooling windows)
     MRCNN_REQUIRE(batch >= 1 && height >= 4 && width >= 4 && height % 4 == 0 && width % 4 == 0,
                   "stem_pool_f32: B=%d H=%d W=%d (multiples of 4 required)", batch, height, width);
-    MRCNN_REQUIRE(1LL * batch * height * width * 3 < (1LL << 30), "stem_pool_f32: tensor too large (32-bit buffer byte offsets)");
+    // input 12 B and output 16 B per input pixel (64 fp32 channels per 4 x 4 pixels): the output is the larger tensor
+    MRCNN_REQUIRE(1LL * batch * height * width * 3 < (1LL << 30) && 16LL * batch * height * width < (1LL << 31),
+                  "stem_pool_f32: tensor too large (32-bit buffer byte offsets: B*H*W < 2^27 pixels)");
     StemPool32Params p;
     p.x = x_nchw; p.w = w; p.scale = scale; p.shift = shift; p.y = y;
     p.B = batch; p.H = height; p.W = width; p.OH = height / 2; p.OW = width / 2;

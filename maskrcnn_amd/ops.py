@@ -1492,6 +1492,7 @@ def stem_pool_f32(x: torch.Tensor, w: torch.Tensor, scale, shift, algo_cin: int 
     assert w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (64, 7, 7, 4)
     b, _, h, wd = x.shape
     assert h % 4 == 0 and wd % 4 == 0
+    assert b * h * wd < (1 << 27), "stem_pool_f32: B*H*W < 2^27 pixels (32-bit byte offsets of the fp32 output)"
     y = torch.empty(b, h // 4, wd // 4, 64, dtype=torch.float32, device=x.device)
     prof = CONV_PROFILE
     if prof is not None:

@@ -229,13 +229,17 @@ class MaskRCNNInference:
         # own; in bench.py's alt entry it cost a quarter of the throughput: 700 against 920 - 950 images/s.)
         self._keep = None
         parts = []
-        for i in range(k):
-            with torch.cuda.stream(self._side_streams[i]):
-                ro = None if rois_override is None else (rois_override[0][i * n:(i + 1) * n], rois_override[1][i * n:(i + 1) * n])
-                parts.append(self.predict(images[i * n:(i + 1) * n], windows[i * n:(i + 1) * n], with_masks, rois_override=ro,
-                                          _whole=True))
-        for i in range(k):
-            cur.wait_stream(self._side_streams[i])
+        try:
+            for i in range(k):
+                with torch.cuda.stream(self._side_streams[i]):
+                    ro = None if rois_override is None else (rois_override[0][i * n:(i + 1) * n], rois_override[1][i * n:(i + 1) * n])
+                    parts.append(self.predict(images[i * n:(i + 1) * n], windows[i * n:(i + 1) * n], with_masks, rois_override=ro,
+                                              _whole=True))
+        finally:
+            # also when a sub-batch raised: the side streams may still be reading the caller's images / windows / RoIs, which the
+            # caller (or the allocator, on the caller's stream) is free to reuse as soon as this call returns
+            for i in range(k):
+                cur.wait_stream(self._side_streams[i])
         cat = lambda f: torch.cat([getattr(p_, f) for p_ in parts], 0)
         out = Detections(cat("class_ids"), cat("scores"), cat("boxes"), cat("counts"), cat("masks") if with_masks else None)
         self._keep, self._keep_event = parts, torch.cuda.Event()

@@ -93,3 +93,16 @@ def test_product_never_imports_oracle():
                 if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                     text = open(os.path.join(dirpath, f)).read()
                     assert not pat.search(text), f"{pkg}/{f} references oracle/"
+
+
+def test_entry_points_refuse_tensors_beyond_32bit_offsets():
+    """Argument validation runs before any HIP call (no GPU needed, the pointers are never touched): the fp32 stem + pool entry
+    point writes 16 B per input pixel through 32-bit buffer byte offsets — 256 images of 1024 x 1024 (2^28 pixels, a 4 GiB
+    output) must be refused, not wrapped (round-5 advice)."""
+    from maskrcnn_amd import _lib
+    lib = _lib.lib
+    dummy = ctypes.c_void_p(16)
+    rc = lib.mrcnn_stem_conv7x7_s2_pool_f32(dummy, 256, 1024, 1024, dummy, None, None, dummy, None)
+    assert rc != 0 and b"too large" in lib.mrcnn_last_error()
+    rc = lib.mrcnn_conv3x3_winograd4_f32(dummy, 1, 64, 64, 12, dummy, 64, None, None, 1, dummy, None, None)
+    assert rc != 0 and b"Cin" in lib.mrcnn_last_error()
