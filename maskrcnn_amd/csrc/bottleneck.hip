@@ -497,7 +497,7 @@ extern "C" int mrcnn_bottleneck_fused_f32(const float* x, int32_t batch, int32_t
     p.w3 = w3; p.s3 = scale3; p.t3 = shift3; p.y = y;
     p.B = batch; p.H = height; p.W = width; p.Cin = cin;
     p.tiles_y = height / TS; p.tiles_x = width / TS; p.total = batch * p.tiles_y * p.tiles_x;
-    static const int debug = getenv("MRCNN_BNECK_DEBUG") ? atoi(getenv("MRCNN_BNECK_DEBUG")) : 0;
+    static const int debug = mrcnn::tuning_env("MRCNN_BNECK_DEBUG") ? atoi(mrcnn::tuning_env("MRCNN_BNECK_DEBUG")) : 0;
     p.debug = debug;
     p.x_bytes = static_cast<unsigned>(4LL * px * cin);
     p.y_bytes = static_cast<unsigned>(4LL * px * CO);

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "maskrcnn_hip.h"
 
@@ -32,6 +33,18 @@ constexpr int kWave = 64;  // gfx950 wavefront
 //   device_cu_count:    multiProcessorCount of the current device (persistent-grid sizing), 0 on failure.
 int ensure_dynamic_lds(const void* kernel, size_t lds_bytes, const char* who);
 int device_cu_count();
+
+// Tuning switches of the launch paths (tile overrides, kernel A/B routes): environment variables honoured ONLY in -DMRCNN_TUNING
+// builds (`build.py --variant tuning -DMRCNN_TUNING`, which tools/ load through MRCNN_LIB); the product library ignores them —
+// it reads three variables in all: MRCNN_CROP_STAGED, MRCNN_WINO_SPATIAL (documented modes) and MRCNN_CONV_NO_SPLIT (numerics A/B).
+inline const char* tuning_env(const char* name) {
+#ifdef MRCNN_TUNING
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 }  // namespace mrcnn
 

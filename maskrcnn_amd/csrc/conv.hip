@@ -599,15 +599,15 @@ static int run_conv_f32(const float* x, int32_t batch, int32_t height, int32_t w
     p.head_n = 0;
     const long long M = p.M;
     const bool generic = (cin % 32) != 0;
-    static const bool no_pw = getenv("MRCNN_CONV_NO_PW") != nullptr;   // tuning aid, read once per process
+    static const bool no_pw = mrcnn::tuning_env("MRCNN_CONV_NO_PW") != nullptr;   // tuning aid, read once per process
     const bool pointwise = !generic && kh == 1 && kw == 1 && pad_top == 0 && pad_left == 0 && pad_bottom == 0 &&
                            pad_right == 0 && !no_pw;
     const int mode = generic ? 1 : pointwise ? 2 : 0;
     hipStream_t s = mrcnn::as_stream(stream);
-    static const int force = getenv("MRCNN_CONV_TILE") ? atoi(getenv("MRCNN_CONV_TILE")) : 0;  // tuning aid
+    static const int force = mrcnn::tuning_env("MRCNN_CONV_TILE") ? atoi(mrcnn::tuning_env("MRCNN_CONV_TILE")) : 0;  // tuning aid
     // ResNet C2's 1x1 layers without a residual (conv1 256 -> 64 / 64 -> 64, downsample 64 -> 256) on large maps: the streaming
     // kernel (bit-identical results; chosen by size only because a persistent wave needs several blocks to pipeline)
-    static const bool no_stream = getenv("MRCNN_CONV_NO_STREAM") != nullptr;
+    static const bool no_stream = mrcnn::tuning_env("MRCNN_CONV_NO_STREAM") != nullptr;
     if (pointwise && !no_stream && !row_counts && stride == 1 && !residual && relu <= 1 && out_mode != 1 && p.M >= 131072) {
         if (cin == 256 && cout > 32 && cout <= 64) return launch_pw_stream<32, 2, 2>(p, s);
         if (cin == 64 && cout > 32 && cout <= 64) return launch_pw_stream<8, 2, 2>(p, s);

@@ -501,7 +501,7 @@ static int run_conv_f16io(const void* x, int32_t x_f16, int32_t batch, int32_t h
     const bool generic = (cin % BK) != 0;
     hipStream_t s = mrcnn::as_stream(stream);
     if (p.Cout <= 64) return launch16<256, 64, 4, 1>(p, generic, x_f16 != 0, y_f16 != 0, s);
-    static const int big = [] { const char* e = getenv("MRCNN_F16_BIG"); return e ? atoi(e) : 0; }();
+    static const int big = [] { const char* e = mrcnn::tuning_env("MRCNN_F16_BIG"); return e ? atoi(e) : 0; }();
     if (big == 1 && p.Cout % 256 == 0 && p.K >= 1024) return launch16<256, 256, 2, 2>(p, generic, x_f16 != 0, y_f16 != 0, s);
     if (big == 2 && p.Cout % 128 == 0 && p.K >= 1024) return launch16<256, 128, 2, 2>(p, generic, x_f16 != 0, y_f16 != 0, s);
     return launch16<128, 128, 2, 2>(p, generic, x_f16 != 0, y_f16 != 0, s);

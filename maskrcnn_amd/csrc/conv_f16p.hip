@@ -561,7 +561,7 @@ extern "C" int mrcnn_conv_f16_pipelined(const void* x_f16, int32_t batch, int32_
         int got = 0, r = 0, c = 0;
         long long mlo = 0, mhi = 1LL << 40;
         ForcedTile() {
-            if (const char* e = getenv("MRCNN_F16P_TILE")) got = sscanf(e, "%dx%d:%lld-%lld", &r, &c, &mlo, &mhi);
+            if (const char* e = mrcnn::tuning_env("MRCNN_F16P_TILE")) got = sscanf(e, "%dx%d:%lld-%lld", &r, &c, &mlo, &mhi);
         }
     };
     static const ForcedTile forced;

@@ -1166,7 +1166,7 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
         return mrcnn::check_launch("conv3x3_wino8s_f32");
     }
 #ifdef MRCNN_ABLATIONS
-    static const bool four_waves = getenv("MRCNN_WINO_WAVES") && atoi(getenv("MRCNN_WINO_WAVES")) == 4;
+    static const bool four_waves = mrcnn::tuning_env("MRCNN_WINO_WAVES") && atoi(mrcnn::tuning_env("MRCNN_WINO_WAVES")) == 4;
     if (four_waves) {
         if (int rc = mrcnn::ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wino_f32), WINO_LDS, "conv3x3_winograd"))
             return rc;
@@ -1178,7 +1178,7 @@ extern "C" int mrcnn_conv3x3_winograd_f32(const float* x, int32_t x_layout, int3
         const int cus = mrcnn::device_cu_count();
         if (cus <= 0) return mrcnn::fail(MRCNN_ERR_LAUNCH, "conv3x3_winograd: cannot query the device");
         const int num_cu = cus >= 8 ? (cus / 8) * 8 : 8;
-        static const bool persistent = !(getenv("MRCNN_WINO_PERSISTENT") && atoi(getenv("MRCNN_WINO_PERSISTENT")) == 0);
+        static const bool persistent = !(mrcnn::tuning_env("MRCNN_WINO_PERSISTENT") && atoi(mrcnn::tuning_env("MRCNN_WINO_PERSISTENT")) == 0);
         const long long launch = (persistent && grid > num_cu) ? num_cu : grid;
         hipLaunchKernelGGL(conv3x3_wino8_f32<false>, dim3(static_cast<unsigned>(launch)), dim3(512), WINO_LDS, st, p);
     }

@@ -578,11 +578,11 @@ struct CropTuning {
     CropTuning() {
         const char* e = getenv("MRCNN_CROP_STAGED");
         staged = !(e && e[0] == '0');
-        e = getenv("MRCNN_CROP_CPW");
+        e = mrcnn::tuning_env("MRCNN_CROP_CPW");
         cpw = (e && atoi(e) > 0) ? atoi(e) : 0;
-        e = getenv("MRCNN_CROP_MAP");
+        e = mrcnn::tuning_env("MRCNN_CROP_MAP");
         linear_map = e && atoi(e) == 0;
-        e = getenv("MRCNN_CROP_RING");
+        e = mrcnn::tuning_env("MRCNN_CROP_RING");
         ring_slots = (e && atoi(e) >= 512 && atoi(e) % 256 == 0 && atoi(e) <= 4096) ? atoi(e) : 0;
     }
 };

@@ -166,26 +166,34 @@ def layer_precision(precision: str, k: int, gemm_out_nhwc: bool = True) -> str:
     return "f16x3" if (gemm_out_nhwc and k >= MIX_MIN_K) else "f32"
 
 
+def _tuning(name: str, default: str) -> str:
+    """A/B switches of the routing below. Three are for users and always honoured (MRCNN_WINOGRAD, MRCNN_WINOGRAD4,
+    MRCNN_SUB_BATCHES — a numerically different or differently scheduled mode each); every other one is a measurement aid and is
+    read ONLY when MRCNN_TUNING=1 is set beside it (tools/ and bench.py's alt entries do that): a stray variable in a user's
+    environment cannot re-route the product. Tests set the module attributes instead."""
+    return os.environ.get(name, default) if os.environ.get("MRCNN_TUNING") == "1" else default
+
+
 # f32 mode: 3x3 stride-1 SAME convs run the fused Winograd F(2x2,3x3) kernel (fp32 MFMA, 2.25x fewer multiply-adds;
 # results differ from the direct kernel by the transforms' rounding, ~1e-5 abs on unit-scale activations).
 # MRCNN_WINOGRAD=0 keeps every conv on the direct implicit-GEMM kernel (bitwise an fmaf chain).
 WINOGRAD = os.environ.get("MRCNN_WINOGRAD", "1") != "0"
 # f32 mode: the 7x7 stride-2 stem runs its own kernel (same fp32 MFMA arithmetic as the generic one, 3x faster);
 # MRCNN_STEM_KERNEL=0 sends it through the generic implicit-GEMM kernel.
-STEM_KERNEL = os.environ.get("MRCNN_STEM_KERNEL", "1") != "0"
+STEM_KERNEL = _tuning("MRCNN_STEM_KERNEL", "1") != "0"
 # f32 Winograd mode: with MRCNN_FUSED_BOTTLENECK=1 the stride-1 identity Bottlenecks with planes = 64 (ResNet C2 blocks
 # 1, 2) run as ONE launch of the whole-block kernel (csrc/bottleneck.hip; bit-identical to the three-launch path, 0.8x its
 # fabric traffic). Off by default: at batch 8 x 256^2 x 256 it measures 0.735 ms per block against 0.704 ms for the three
 # launches (DESIGN.md §5.1c) — one workgroup per CU runs its three GEMM phases back to back, so nothing overlaps the
 # HBM-bound conv3 epilogue, while the per-layer kernels overlap five workgroups per CU there.
-FUSED_BOTTLENECK = os.environ.get("MRCNN_FUSED_BOTTLENECK", "0") == "1"
+FUSED_BOTTLENECK = _tuning("MRCNN_FUSED_BOTTLENECK", "0") == "1"
 # f32 Winograd mode: on the large pyramid levels the RPN's two 1x1 heads run inside the Winograd kernel of conv_shared
 # (ops.conv3x3_winograd_heads): the 512-channel shared activation never reaches HBM. A workgroup then owns whole M tiles
 # (64 tile positions each), so only levels with many of them qualify: at least RPN_HEADS_MIN_TILES PER IMAGE — P2 and P3
 # of a 1024^2 or 832 x 1344 input. The rule looks at the image size only, never at the batch: the two forms add the 512
 # channels up in different groupings, and image i of a batch must equal image i alone bit for bit.
 # MRCNN_RPN_FUSED_HEADS=0 keeps the separate 18-channel head conv everywhere.
-RPN_FUSED_HEADS = os.environ.get("MRCNN_RPN_FUSED_HEADS", "1") != "0"
+RPN_FUSED_HEADS = _tuning("MRCNN_RPN_FUSED_HEADS", "1") != "0"
 RPN_HEADS_MIN_TILES = 64
 # Winograd F(4x4,3x3) (ops.conv3x3_winograd4: 4x instead of 2.25x fewer multiply-adds, max |err| ~2e-5 at unit scale) for
 # the layers that ask for it — the FPN smoothing convs and the RPN's shared conv, the big 3x3 layers at the END of the
@@ -193,13 +201,13 @@ RPN_HEADS_MIN_TILES = 64
 # (16 x 32 output pixels) PER IMAGE (never a function of the batch: image i alone == slice i of the batch); the RPN heads
 # are fused into it from WINOGRAD4_HEADS_MIN_TILES per image. MRCNN_WINOGRAD4=0 keeps F(2x2) everywhere.
 WINOGRAD4 = os.environ.get("MRCNN_WINOGRAD4", "1") != "0"
-WINOGRAD4_TRUNK = os.environ.get("MRCNN_WINOGRAD4_TRUNK", "1") != "0"   # also the Bottleneck conv2 layers (C2-C4 sizes)
-WINOGRAD4_MIN_TILES = int(os.environ.get("MRCNN_W4_MIN_TILES", "8"))             # (the environment forms: tuning sweeps only)
-WINOGRAD4_HEADS_MIN_TILES = int(os.environ.get("MRCNN_W4_HEADS_MIN_TILES", "32"))
+WINOGRAD4_TRUNK = _tuning("MRCNN_WINOGRAD4_TRUNK", "1") != "0"   # also the Bottleneck conv2 layers (C2-C4 sizes)
+WINOGRAD4_MIN_TILES = int(_tuning("MRCNN_W4_MIN_TILES", "8"))             # (the environment forms: tuning sweeps only)
+WINOGRAD4_HEADS_MIN_TILES = int(_tuning("MRCNN_W4_HEADS_MIN_TILES", "32"))
 # Bottlenecks with planes = 64 (ResNet C2) whose conv2 takes the F(4x4) kernel: conv3 (1x1 expansion + BN + residual + ReLU)
 # runs inside that kernel's epilogue (ops.conv3x3_winograd4_conv3) — the 64-channel map between them never reaches HBM and
 # one launch per block is gone; bit-identical to the two launches it replaces. MRCNN_FUSED_CONV3=0 keeps them apart.
-FUSED_CONV3 = os.environ.get("MRCNN_FUSED_CONV3", "1") != "0"
+FUSED_CONV3 = _tuning("MRCNN_FUSED_CONV3", "1") != "0"
 
 
 def winograd4_tiles_per_image(h: int, w: int) -> int:
@@ -211,27 +219,27 @@ def winograd4_tiles_per_image(h: int, w: int) -> int:
 # The classifier head (RoIAlign 7x7 + three GEMMs) skips the RoI slots beyond each image's proposal count — the reference's rois
 # tensor holds only the boxes NMS kept (model.py:1366-1374), this pipeline's has proposal_count slots per image with a count.
 # MRCNN_SKIP_EMPTY_ROI_TILES=0 computes every slot (same valid rows bit for bit; A/B measurements).
-SKIP_EMPTY_ROI_TILES = os.environ.get("MRCNN_SKIP_EMPTY_ROI_TILES", "1") != "0"
-F16_ACT = os.environ.get("MRCNN_F16_ACT", "1") != "0"
+SKIP_EMPTY_ROI_TILES = _tuning("MRCNN_SKIP_EMPTY_ROI_TILES", "1") != "0"
+F16_ACT = _tuning("MRCNN_F16_ACT", "1") != "0"
 # f32 mode: the stem's conv + BN + ReLU + SamePad + max-pool as ONE exact-fp32 launch on three real channels (csrc/stem.hip:
 # stem7x7_s2_pool_f32, round 5) when H and W are multiples of 4; MRCNN_STEM_POOL=0 keeps the stem kernel + the separate max-pool.
-STEM_POOL = os.environ.get("MRCNN_STEM_POOL", "1") != "0"
+STEM_POOL = _tuning("MRCNN_STEM_POOL", "1") != "0"
 # The large stride-1 layers of the "f16" mode (fp16 NHWC input, Cin % 64 == 0, Cout % 256 == 0) run the pipelined kernel
 # (csrc/conv_f16p.hip: eight waves, LDS-DMA in flight across barriers — 1.4-1.5x the 128x128-tile kernel on the 3x3 layers);
 # MRCNN_F16_PIPELINED=0 keeps them on conv_igemm_f16.
-F16_PIPELINED = os.environ.get("MRCNN_F16_PIPELINED", "1") != "0"
+F16_PIPELINED = _tuning("MRCNN_F16_PIPELINED", "1") != "0"
 # "f16" mode: the stem's conv + BN + ReLU + max-pool as one fp16-MFMA launch (csrc/stem.hip: stem7x7_s2_pool_f16). 0 = the
 # exact-fp32 stem with an fp16 store + the separate fp16 max-pool (rounds 2-3).
-F16_STEM_POOL = os.environ.get("MRCNN_F16_STEM_POOL", "1") != "0"
+F16_STEM_POOL = _tuning("MRCNN_F16_STEM_POOL", "1") != "0"
 # "f16" mode: a ResNet C2 block (planes 64, stride 1) as ONE launch (csrc/bottleneck_f16.hip: both 64-channel maps stay on chip,
 # x is read once). MRCNN_F16_FUSED_C2=0 keeps the three / four per-layer launches.
-F16_FUSED_C2 = os.environ.get("MRCNN_F16_FUSED_C2", "1") != "0"
+F16_FUSED_C2 = _tuning("MRCNN_F16_FUSED_C2", "1") != "0"
 # "f16" mode: the mask head's deconv + ReLU + conv5 + sigmoid as ONE launch (csrc/mask_tail_f16.hip: the deconv's fp16 map stays in
 # registers). MRCNN_F16_FUSED_MASK_TAIL=0 keeps the two launches.
-F16_FUSED_MASK_TAIL = os.environ.get("MRCNN_F16_FUSED_MASK_TAIL", "1") != "0"
+F16_FUSED_MASK_TAIL = _tuning("MRCNN_F16_FUSED_MASK_TAIL", "1") != "0"
 # the RPN heads run inside that kernel on levels of at least this many pixels PER IMAGE (never a function of the batch: the two
 # forms round differently, and image i of a batch must equal image i alone); below it the 18-channel conv is a launch of its own
-F16_HEADS_MIN_PIXELS = int(os.environ.get("MRCNN_F16_HEADS_MIN_PIXELS", "4096"))
+F16_HEADS_MIN_PIXELS = int(_tuning("MRCNN_F16_HEADS_MIN_PIXELS", "4096"))
 
 
 class ConvWeight:

@@ -763,7 +763,8 @@ def bottleneck_fused(x, w1, s1, t1, u2, s2, t2, w3, s3, t3) -> torch.Tensor:
 # when BOTH switches say so — MRCNN_FUSED_BOTTLENECK=1 and Winograd not disabled (MRCNN_WINOGRAD=0 promises "every conv on the
 # direct kernel, bitwise an fmaf chain"); otherwise the op is the exact three/four-launch composite. modules.py keeps this in
 # step with its own flags.
-BOTTLENECK_OP_FUSED = (os.environ.get("MRCNN_FUSED_BOTTLENECK", "0") == "1" and os.environ.get("MRCNN_WINOGRAD", "1") != "0")
+BOTTLENECK_OP_FUSED = (os.environ.get("MRCNN_TUNING") == "1" and os.environ.get("MRCNN_FUSED_BOTTLENECK", "0") == "1"
+                       and os.environ.get("MRCNN_WINOGRAD", "1") != "0")
 _U2_CACHE: dict = {}   # data_ptr -> (weakref to the conv2 weight tensor, its version, its Winograd transform)
 
 

@@ -672,18 +672,44 @@ def test_config5_fp16_detection_agreement_rate(dev):
     sd["rpn.conv_bbox.bias"] = torch.randn(12, generator=g) * 0.3
     windows = torch.tensor([[16., 5., 816., 1338.]] * (nb // 2) + [[0., 0., 832., 1344.]] * (nb - nb // 2))
     best_all, ds_all, per_seed, unmatched = [], [], {}, []
+    fixed_best, fixed_ds, fixed_unmatched, roi_overlap, unmatched_roi_iou = [], [], [], [], []
     net = net16 = None
     for seed in (55, 56, 57):
         g0 = torch.Generator().manual_seed(seed)
         images = (torch.randint(0, 256, (nb, h, w, 3), generator=g0).float() - torch.tensor(cfg.mean_pixel))
         images = images.permute(0, 3, 1, 2).contiguous()
         if net is None:   # the heads are calibrated ONCE (first seed); both modes and all seeds then share the weights
-            net, det, _ = _calibrated(cfg, sd, images, windows, dev, "f32")
+            net, det, mid32 = _calibrated(cfg, sd, images, windows, dev, "f32")
             net16 = MaskRCNNInference(sd, cfg, dev, precision="f16")
         else:
-            det = net.predict(images.to(dev), windows.to(dev))
+            det, mid32 = net.predict(images.to(dev), windows.to(dev), return_intermediates=True)
         det16, mid16 = net16.predict(images.to(dev), windows.to(dev), return_intermediates=True)
+        # (round 6) the same fp16 path on the fp32 path's PROPOSALS: its trunk, RoIAlign, heads, decode and NMS, with the one
+        # thing the end-to-end comparison cannot hold fixed held fixed
+        det16h = net16.predict(images.to(dev), windows.to(dev), rois_override=(mid32["rois"].contiguous(), mid32["roi_counts"].contiguous()))
         torch.cuda.synchronize()
+        scale4 = torch.tensor([h, w, h, w], dtype=torch.float64)
+        for b in range(nb):
+            # proposal sets after the RPN's NMS: fraction of the fp32 path's RoIs with an fp16-path RoI at IoU >= 0.95
+            n32, n16 = int(mid32["roi_counts"][b]), int(mid16["roi_counts"][b])
+            r32, r16 = mid32["rois"][b, :n32].cpu().double() * scale4, mid16["rois"][b, :n16].cpu().double() * scale4
+            roi_overlap.append(float((_iou_matrix(r32, r16).max(1).values >= 0.95).double().mean()) if n32 and n16 else 0.0)
+            # heads on fixed proposals
+            k, kh = int(det.counts[b]), int(det16h.counts[b])
+            sel = (det.scores[b, :k] > 0.5).nonzero().flatten().cpu()
+            if sel.numel() == 0:
+                continue
+            if kh == 0:
+                fixed_best += [0.0] * sel.numel()
+                continue
+            iou = _iou_matrix(det.boxes[b, :k].cpu()[sel], det16h.boxes[b, :kh].cpu())
+            same = det.class_ids[b, :k].cpu()[sel][:, None] == det16h.class_ids[b, :kh].cpu()[None, :]
+            fb, fa = (iou * same).max(1)
+            fixed_best += fb.tolist()
+            fixed_ds += (det.scores[b, :k].cpu()[sel] - det16h.scores[b, :kh].cpu()[fa]).abs()[fb >= 0.9].tolist()
+            for j in (fb < 0.9).nonzero().flatten().tolist():
+                fixed_unmatched.append({"seed": seed, "image": b, "class": int(det.class_ids[b, sel[j]]), "f32_score": float(det.scores[b, sel[j]]),
+                                        "best_same_class_iou": float(fb[j]), "any_class_iou": float(iou[j].max())})
         # the fp16 path's candidates BEFORE its per-class NMS: decoded boxes, argmax class and score of every proposal
         from maskrcnn_amd import ops as _ops
         cand, _, cand_cls = _ops.detection_decode(mid16["logits"], mid16["bbox"], mid16["rois"].contiguous(), mid16["roi_counts"],
@@ -709,7 +735,19 @@ def test_config5_fp16_detection_agreement_rate(dev):
                 nv = int(mid16["roi_counts"][b])
                 ci = _iou_matrix(box[None], cand[b, :nv, :4])[0] * (cand_cls[b, :nv] == cls_)
                 cb, ca = ci.max(0)
+                # (round 6) the explanation, measured: does the fp32 path's RoI behind this detection exist in the fp16 path's
+                # proposal set at all? (the detection's box is a refinement of ONE of the fp32 path's RoIs: the one whose decoded
+                # candidate it is — found through the fp32 candidates)
+                cand32, _, cls32 = _ops.detection_decode(mid32["logits"], mid32["bbox"], mid32["rois"].contiguous(), mid32["roi_counts"],
+                                                         windows.to(dev).float().contiguous(), cfg.rpn_bbox_std_dev, h, w, 0.0)
+                nv32 = int(mid32["roi_counts"][b])
+                src = int((_iou_matrix(box[None], cand32[b, :nv32, :4].cpu())[0] * (cls32[b, :nv32].cpu() == cls_)).argmax())
+                n16 = int(mid16["roi_counts"][b])
+                scale4 = torch.tensor([h, w, h, w], dtype=torch.float64)
+                src_iou = float(_iou_matrix(mid32["rois"][b, src].cpu().double()[None] * scale4, mid16["rois"][b, :n16].cpu().double() * scale4).max())
+                unmatched_roi_iou.append(src_iou)
                 unmatched.append({"seed": seed, "image": b, "class": cls_, "f32_score": sc_, "best_same_class_f16_detection_iou": float(best[j]),
+                                  "source_roi_best_iou_in_f16_proposal_set": src_iou,
                                   "f16_candidate_iou": float(cb), "f16_candidate_score": float(cand[b, ca, 4]),
                                   "any_class_f16_detection_iou": float(_iou_matrix(box[None], det16.boxes[b, :k16].cpu()).max())})
             ds = (det.scores[b, :k].cpu()[sel] - det16.scores[b, :k16].cpu()[arg]).abs()
@@ -728,11 +766,34 @@ def test_config5_fp16_detection_agreement_rate(dev):
         "abs_score_diff_of_matched_histogram": {"edges": ds_edges, "counts": hist(ds_t, ds_edges)},
         "max_abs_score_diff_of_matched": float(ds_t.max()) if ds_t.numel() else None,
         "without_a_match_iou_ge_0.5": unmatched}
+    fb_t, fds_t, ov_t = torch.tensor(fixed_best, dtype=torch.float64), torch.tensor(fixed_ds, dtype=torch.float64), torch.tensor(roi_overlap, dtype=torch.float64)
+    ov_edges = [0.0, 0.5, 0.8, 0.9, 0.95, 0.98, 0.99, 1.0 + 1e-9]
+    REPORT["config5/f16/heads_on_fp32_proposals"] = {
+        "what": "the fp16 path run on the fp32 path's RoIs (predict rois_override): every fp32 detection with score > 0.5 looked up among the same-class fp16 detections of its image",
+        "f32_detections_score_gt_0.5": int(fb_t.numel()), "matched_same_class_iou_ge_0.9": int((fb_t >= 0.9).sum()),
+        "worst_best_iou": float(fb_t.min()) if fb_t.numel() else None, "best_iou_histogram": {"edges": iou_edges[:-1] + [1.0], "counts": hist(fb_t, iou_edges)},
+        "abs_score_diff_of_matched_histogram": {"edges": ds_edges, "counts": hist(fds_t, ds_edges)},
+        "max_abs_score_diff_of_matched": float(fds_t.max()) if fds_t.numel() else None, "below_0.9": fixed_unmatched}
+    REPORT["config5/f16/proposal_set_overlap"] = {
+        "what": "per image (3 seeds x 8): fraction of the fp32 path's RoIs (after the RPN's NMS, <= 1000) that have an fp16-path RoI with IoU >= 0.95",
+        "per_image": [round(v, 4) for v in roi_overlap], "min": float(ov_t.min()), "mean": float(ov_t.mean()),
+        "histogram": {"edges": ov_edges[:-1] + [1.0], "counts": hist(ov_t, ov_edges)},
+        "source_roi_iou_of_the_end_to_end_unmatched": unmatched_roi_iou}
+    # (round 6) with the proposal set held fixed NOTHING may be missing: the heads' fp16 arithmetic moves a score by <= 1e-2 and a
+    # box by a fraction of a pixel — it does not lose or displace a confident detection
+    assert fb_t.numel() >= 100 and int((fb_t >= 0.9).sum()) == fb_t.numel(), (
+        f"fp16 heads on the fp32 path's proposals: {int((fb_t < 0.9).sum())} of {fb_t.numel()} confident fp32 detections without a "
+        f"same-class fp16 detection at IoU >= 0.9: {fixed_unmatched[:4]}")
+    # the proposal sets themselves: what the end-to-end allowance below is made of
+    assert float(ov_t.min()) >= 0.90 and float(ov_t.mean()) >= 0.95, f"fp16 vs fp32 proposal sets: per-image overlap min {float(ov_t.min()):.3f}, mean {float(ov_t.mean()):.3f}"
     assert n >= 100, f"only {n} confident fp32 detections over three seeds x eight images"
     assert n90 >= 0.95 * n, f"fp16 path: {n90} of {n} confident fp32 detections matched at IoU >= 0.9 ({n90 / n:.3f} < 0.95)"
     assert n - n50 <= 0.03 * n, f"fp16 path: {n - n50} of {n} confident fp32 detections have NO same-class fp16 detection with IoU >= 0.5"
-    for u in unmatched:   # never a confident detection that vanished: the unmatched ones sit at the confidence cut
-        assert u["f32_score"] <= 0.6, u
+    for u in unmatched:
+        # (round 6) an end-to-end miss is a PROPOSAL-SET difference, measured: the fp32 path's RoI behind the detection has no
+        # counterpart (IoU >= 0.95) among the fp16 path's RoIs — with it present, the fixed-proposal assertion above says the
+        # heads would have found the detection. (Round 5 bounded these cases by their fp32 score instead.)
+        assert u["source_roi_best_iou_in_f16_proposal_set"] < 0.95, u
 
 
 # ------------------------------------------------------------------------------------------------------------
