@@ -587,13 +587,20 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
             if (g == 0 || g == 1) STAMP();  // after the Z writes
             W4_EPILOGUE_BARRIER();
             if (g == 0 || g == 1) STAMP();  // after the first barrier
-            f32x2 w[6][4];
+            // the six reads of row xi + 1 are issued BEFORE row xi is transformed (round 6: read, wait for all, transform, six times
+            // over, left five LDS latencies of ~150 cycles exposed per round at one wave per SIMD)
+            f32x2 w[6][4], m[2][6];
+            auto read_row = [&](int xi) {
+#pragma unroll
+                for (int nu = 0; nu < 6; ++nu) m[xi & 1][nu] = *(const lds_f32x2*)(Z + ((xi * 6 + nu) * 8 + p8) * 64 + n);
+            };
+            read_row(0);
 #pragma unroll
             for (int xi = 0; xi < 6; ++xi) {
-                f32x2 m[6];
-#pragma unroll
-                for (int nu = 0; nu < 6; ++nu) m[nu] = *(const lds_f32x2*)(Z + ((xi * 6 + nu) * 8 + p8) * 64 + n);
-                at4p(m[0], m[1], m[2], m[3], m[4], m[5], kout, w[xi][0], w[xi][1], w[xi][2], w[xi][3]);
+                if (xi + 1 < 6) read_row(xi + 1);
+                __builtin_amdgcn_sched_barrier(0);   // (or the scheduler sinks the reads behind the transform again)
+                at4p(m[xi & 1][0], m[xi & 1][1], m[xi & 1][2], m[xi & 1][3], m[xi & 1][4], m[xi & 1][5], kout, w[xi][0], w[xi][1],
+                     w[xi][2], w[xi][3]);
             }
             // second stage per output column j: its four pixels (i = 0..3) leave right away
             const int pos = 8 * g + p8;
