@@ -33,7 +33,8 @@ def _write_report():
     yield
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "parity_fullsize.json"), "w") as fh:
+    name = "parity_fullsize_sync_fuzz.json" if os.environ.get("MRCNN_SYNC_FUZZ_CHILD") == "1" else "parity_fullsize.json"
+    with open(os.path.join(out, name), "w") as fh:
         json.dump(REPORT, fh, indent=1, sort_keys=True)
 
 

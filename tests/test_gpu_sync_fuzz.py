@@ -31,6 +31,16 @@ def test_kernel_parity_tests_pass_under_schedule_fuzzing():
 
 
 @pytest.mark.skipif(os.environ.get("MRCNN_SYNC_FUZZ_CHILD") == "1", reason="this IS the fuzzed child run")
+def test_full_size_and_pipeline_tests_pass_under_schedule_fuzzing():
+    """The same at BASELINE's full sizes: the whole trunk / RPN / heads / detections against the oracle, batch-slice bit identity, the
+    fp16 mode's agreement tests and the pipeline tests (80 tests, about two minutes) on the fuzzed build."""
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_fullsize.py", "tests/test_gpu_pipeline.py",
+                        "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=_env(), capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+
+
+@pytest.mark.skipif(os.environ.get("MRCNN_SYNC_FUZZ_CHILD") == "1", reason="this IS the fuzzed child run")
 def test_fuzzing_finds_round5_kernel():
     """The detector detects: the same build with the barrier behind the prologue's operand reads left out (MRCNN_W4_DEBUG=8192,
     an ablation variant of the plain F(4x4) kernel = round 5's kernel) is wrong on every launch, the shipped kernel on none."""
