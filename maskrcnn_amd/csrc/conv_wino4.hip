@@ -564,6 +564,10 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         const __amdgpu_buffer_rsrc_t hp_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.head_part, 0, HEADS ? p.head_bytes : 0u, 0x00020000);
         const int pixstep_y = p.Cout * 4, rowstep_y = p.W * pixstep_y, rowstep_k = p.W * 32;  // scalar store offsets
         const W4OutConsts kout = w4_out_consts();
+        // exchange-area write addresses of the lane: [channel half nb][components >= 32] — position rows 4 lh .. + 3 of a component
+        // start (4 lh * 64 + nb * 32 + ln) floats into its 2 KB chunk; the component and the position row are the immediates
+        const unsigned z_lane[2][2] = {{lds0 + static_cast<unsigned>((4 * lh * 64 + ln) * 4), lds0 + static_cast<unsigned>((4 * lh * 64 + ln) * 4 + 32 * 2048)},
+                                       {lds0 + static_cast<unsigned>((4 * lh * 64 + 32 + ln) * 4), lds0 + static_cast<unsigned>((4 * lh * 64 + 32 + ln) * 4 + 32 * 2048)}};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             // Z[component][position][channel]: a lane's four positions (registers 4g..4g+3) are four 4-byte writes (32
@@ -574,11 +578,22 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
                 for (int j = 0; j < 3; ++j)
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
-                        const f32x16& a16 = acc[(i * 3 + j) * 2 + nb];
-                        lds_f32* zp = Z + ((cg0 + i * 6 + j) * 8 + 4 * lh) * 64 + nb * 32 + ln;
+                        // two positions per instruction (ds_write2st64_b32: both dwords 256 B = one position row apart): 36 LDS
+                        // instructions per round instead of 72 — the phase is bound by their issue, not by LDS bandwidth
+                        constexpr int q = 0;
+                        const int acc_i = (i * 3 + j) * 2 + nb;
+                        const int comp = cg0 + i * 6 + j;
+                        const unsigned zaddr = z_lane[nb][comp >= 32 ? 1 : 0];
+                        const int unit = (comp & 31) * 8;   // 256-byte units: component stride 2 KB
+                        (void)q;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            zp[e * 64] = a16[4 * g + e];
+                        for (int e = 0; e < 4; e += 2) {
+                            if (acc_i < 16)
+                                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4"
+                                             :: "v"(zaddr), "a"(acc[acc_i][4 * g + e]), "a"(acc[acc_i][4 * g + e + 1]), "n"(unit + e), "n"(unit + e + 1) : "memory");
+                            else
+                                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4"
+                                             :: "v"(zaddr), "v"(acc[acc_i][4 * g + e]), "v"(acc[acc_i][4 * g + e + 1]), "n"(unit + e), "n"(unit + e + 1) : "memory");
                         }
                         __builtin_amdgcn_sched_barrier(0);  // or all 72 accumulator registers of the round are copied out at once
                     }

@@ -15,7 +15,7 @@ number somebody counted by hand. This tool re-derives those counts from the gene
   D  accumulators    inside the innermost loop that holds asm MFMAs (the k loop) the compiler touches no accumulator register
                      (no v_accvgpr_*, no copy) and places no spill code;
   E  M0              at least one instruction between a write of M0 and the LDS-DMA that reads it;
-  F  metadata        vgpr_spill_count / scratch size per kernel as expected (0, or the pinned exception).
+  F  metadata        vgpr_spill_count == 0 and no scratch in every kernel under contract.
 
 Usage: tools/isa_audit.py [--mutations]    (tests/test_isa_contract.py runs both)
 """
@@ -273,12 +273,9 @@ def has_asm_contract(insts) -> bool:
 SOURCES = {
     # conv3x3_wino4_f32: asm MFMAs with pinned accumulator classes, asm ds_read_b64 with counted lgkmcnt, staging waits vmcnt(3)
     "conv_wino4.hip": {"dma_free_behind_asm_vmcnt": True,
-                       # pinned exceptions: the conv2 + conv3 instantiation keeps <= 16 tile-invariant values in scratch, the
-                       # HEADS ones <= 3 — all stored in the tile set-up and reloaded in the epilogue (check D: none in the k loop;
-                       # check A: none touches a register an asm load is still writing); the plain instantiations spill nothing
-                       "spills": lambda name, meta: (meta["vgpr_spill_count"] <= 16 and meta["private_segment_fixed_size"] <= 64) if name.endswith("ILi0ELb0ELb1ELb1EEEvNS_11Wino4ParamsE")
-                       else (meta["vgpr_spill_count"] <= 3 and meta["private_segment_fixed_size"] <= 12) if "ILi0ELb1E" in name
-                       else (meta["vgpr_spill_count"] == 0 and meta["private_segment_fixed_size"] == 0)},
+                       # no instantiation spills (round 6: the exchange-area writes as ds_write2st64_b32 with immediate component /
+                       # position offsets freed the ~20 address registers that had cost HEADS 2 and CONV3 15 spilled values)
+                       "spills": lambda name, meta: meta["vgpr_spill_count"] == 0 and meta["private_segment_fixed_size"] == 0},
     # conv_f16p: asm ds_read_b128 behind lgkmcnt(0), counted vmcnt(N) that deliberately leaves later tiles' DMAs in flight
     "conv_f16p.hip": {"dma_free_behind_asm_vmcnt": False,
                       "spills": lambda name, meta: meta["vgpr_spill_count"] == 0 and meta["private_segment_fixed_size"] == 0},
