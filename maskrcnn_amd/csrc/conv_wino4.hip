@@ -457,15 +457,19 @@ __device__ __forceinline__ void wino4_wave(const Wino4Params& p, lds_f32* smem) 
         if constexpr ((DBG & 4096) != 0) {  // ablation builds: wave 0 falls about 8 000 cycles behind the others here
             if (wave == 0) __builtin_amdgcn_s_sleep(127);
         }
+        // The 18 B reads first, then the patch one column AHEAD of the column being transformed (LDS returns in order: with
+        // the next column's five reads in flight, lgkmcnt(5) retires this column and every B read): round 6 — read, wait for
+        // all, transform, five times over and the B reads last, left six LDS latencies exposed in every tile's prologue
+#pragma unroll
+        for (int q = 0; q < 18; ++q) read_b(0, 0, q);
+        read_col(0, 0);
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
-            read_col(0, c);
-            row_stage(c, 0);
+            if (c + 1 < 5) read_col(0, c + 1);
+            row_stage(c, c + 1 < 5 ? 5 : 0);
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) col_stage(0, i);
-#pragma unroll
-        for (int q = 0; q < 18; ++q) read_b(0, 0, q);
         // THE barrier round 5's rare wrong tiles were missing (round 6, tools/w4_forensics.py): the reads above are
         // of buffer 0 (raw k tile 0, U(0)) AFTER the staging barrier, and k tile 0 below re-stages buffer 0 — U(2) by LDS-DMA
         // from MFMA slot 10 on, raw k tile 2 in slots 27-29. In steady state a k tile's operands are read during the k tile
