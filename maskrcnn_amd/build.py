@@ -61,12 +61,8 @@ def _newer(target: str, deps: list[str]) -> bool:
     return os.path.exists(target) and os.path.getmtime(target) >= max(os.path.getmtime(d) for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, variant: str | None = None, defines: tuple = (),
-          only: tuple = ()) -> str:
-    """variant builds: `only` names the sources the defines apply to (compiled into the variant directory); every other
-    object is the product's (built first if need be)."""
-    if variant and only:
-        build(force=False, verbose=verbose)
+def _plan(force, variant, defines, only):
+    """(compile commands, flag stamps, object list, library path) of one build; compiles nothing."""
     obj_dir, lib_path = OBJ, LIB
     if variant:
         obj_dir = os.path.join(OBJ, "variants", variant)
@@ -75,9 +71,7 @@ def build(force: bool = False, verbose: bool = False, variant: str | None = None
     cc = hipcc()
     headers = [os.path.join(ROOT, "include", "maskrcnn_hip.h"), os.path.abspath(__file__)]
     headers += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
-    jobs = []
-    objs = []
-    stamps = []
+    jobs, objs, stamps = [], [], []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
@@ -95,6 +89,15 @@ def build(force: bool = False, verbose: bool = False, variant: str | None = None
         if force or not same_flags or not _newer(o, [s] + headers):
             jobs.append([cc, *COMMON, *extra, "-c", s, "-o", o])
             stamps.append((stamp, flags))
+    return jobs, stamps, objs, lib_path
+
+
+def build_many(builds, force: bool = False, verbose: bool = False) -> list:
+    """Several builds — [(variant or None, defines, only), ...] — with ALL their translation units in one pool (the two builds
+    __graft_entry__.build() makes, product + schedule-fuzz variant, are 34 compiles: one after the other they leave the machine idle
+    behind each build's longest unit). Returns the library paths."""
+    plans = [_plan(force, v, tuple(d), tuple(o)) for v, d, o in builds]
+    cc = hipcc()
 
     def run(cmd):
         if verbose:
@@ -105,14 +108,29 @@ def build(force: bool = False, verbose: bool = False, variant: str | None = None
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
-    with cf.ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    jobs = [j for p in plans for j in p[0]]
+    # longest units first (the Winograd and direct kernels: tens of seconds each), so that they do not end up last in the pool
+    jobs.sort(key=lambda c: -os.path.getsize(c[-3]))
+    with cf.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    for stamp, flags in stamps:   # only after every compile succeeded
-        with open(stamp, "w") as fh:
-            fh.write(flags)
-    if jobs or force or not _newer(lib_path, objs):
-        run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib_path])
-    return lib_path
+    out = []
+    for pj, stamps, objs, lib_path in plans:
+        for stamp, flags in stamps:   # only after every compile succeeded
+            with open(stamp, "w") as fh:
+                fh.write(flags)
+        if pj or force or not _newer(lib_path, objs):
+            run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib_path])
+        out.append(lib_path)
+    return out
+
+
+def build(force: bool = False, verbose: bool = False, variant: str | None = None, defines: tuple = (),
+          only: tuple = ()) -> str:
+    """variant builds: `only` names the sources the defines apply to (compiled into the variant directory); every other
+    object is the product's (built first if need be)."""
+    if variant and only:
+        build(force=False, verbose=verbose)
+    return build_many([(variant, defines, only)], force=force, verbose=verbose)[0]
 
 
 if __name__ == "__main__":
