@@ -413,3 +413,25 @@ def test_afrag_row_permutation_is_a_bijection_with_consecutive_lane_channels():
             for q in range(4):
                 lane_channels = [ch(2 * h + half, q * 4 + r) for half in (0, 1) for r in range(4)]
                 assert lane_channels == list(range(h * 32 + q * 8, h * 32 + q * 8 + 8))
+
+
+def test_w4_forensics_decomposition_identifies_synthesised_causes(tmp_path):
+    """tools/w4_forensics.py (the analysis behind DESIGN 5.1a'': what exactly is wrong in a wrong F(4x4) tile) on differences
+    synthesised from three known causes — one component of one k tile multiplied with another k tile's U, one wave's nine
+    components computed from another k tile's input, four positions of one component overwritten in the exchange buffer — and
+    its restated transforms against a direct convolution. The tool must name each cause."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("w4_forensics", os.path.join(ROOT, "tools", "w4_forensics.py"))
+    f = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(f)
+    err, reps = f.selftest(str(tmp_path / "selftest.npz"))
+    assert err < 1e-12                                     # B^T, G, A^T at the points 0, +-3/4, +-3/2, inf == a 3x3 convolution
+    a, b, c = reps
+    assert a["single_component_fit"]["component"] == [2, 4] and a["single_component_fit"]["residual"] < 1e-9
+    ca = a["components"][0]
+    assert ca["B_operand_fit"]["k_tile"] == 17 and ca["B_operand_fit"]["residual"] < 1e-6
+    assert ca["U_used"]["best_other_U_[k_tile, xi, nu]"]["which"] == [15, 2, 4]
+    assert b["quadrant_fit"]["wave"] == 2 and min(b["quadrant_fit"]["residuals"]) < 1e-9 and len(b["components"]) == 9
+    assert all(cb["A_operand_fit"]["k_tile"] == 40 and cb["V_used"]["best_other_k_tile"]["k_tile"] == 38 for cb in b["components"])
+    assert c["positions"] == [8, 9, 10, 11] and c["rounds"] == [1] and c["single_component_fit"]["component"] == [1, 1]
+    assert "M_replaced" in c["components"][0]

@@ -167,6 +167,7 @@ def analyze(path):
                           "persistent_loop_iterations": sorted({ty % 4 for (b, ty, tx, nt), _ in e["tiles"]}),
                           "counts": sorted({c for _, c in e["tiles"]})}))
     m = Model()
+    reports = []
     quads = [[(3 * qa + i) * 6 + 3 * qb + j for i in range(3) for j in range(3)] for qa in range(2) for qb in range(2)]
     for t in range(len(ids)):
         it, b, ty, tx, nt, cnt = [int(v) for v in ids[t]]
@@ -267,6 +268,8 @@ def analyze(path):
                 comps.append(info)
             rep["components"] = comps
         print(json.dumps(rep), flush=True)
+        reports.append(rep)
+    return reports
 
 
 
@@ -299,7 +302,7 @@ def selftest(path="/tmp/w4_selftest.npz"):
     ids = np.array([[i, b, ty, tx, nt, int((bad[i] != first).sum())] for i in range(len(cases))])
     np.savez_compressed(path, tile_ids=ids, bad=bad, badk=bad, first=np.array([first] * len(cases)),
                         events=json.dumps([]), launches=0, lib="selftest")
-    analyze(path)
+    return float(np.abs(direct - ref).max()), analyze(path)
 
 
 if __name__ == "__main__":
