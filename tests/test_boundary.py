@@ -106,3 +106,21 @@ def test_entry_points_refuse_tensors_beyond_32bit_offsets():
     assert rc != 0 and b"too large" in lib.mrcnn_last_error()
     rc = lib.mrcnn_conv3x3_winograd4_f32(dummy, 1, 64, 64, 12, dummy, 64, None, None, 1, dummy, None, None)
     assert rc != 0 and b"Cin" in lib.mrcnn_last_error()
+
+
+def test_native_cxx_module_loads_and_registers():
+    """maskrcnn/_C_native.so (maskrcnn/csrc/vision_hip.cpp): the reference's pybind module — the three names and doc strings of
+    c++ext/maskrcnn/csrc/vision.cpp:11-15 — built on the C ABI, plus the TORCH_LIBRARY registration maskrcnn_native::* a C++ /
+    TorchScript caller uses. No GPU here: it must import, expose the functions and the dispatcher schemas, and refuse CPU tensors
+    the way the reference built without CPU support would (nms.h:24)."""
+    from maskrcnn import build_native
+    build_native.build()
+    m = build_native.load()
+    assert m.nms.__doc__.strip().endswith("non-maximum suppression")
+    assert m.crop_forward.__doc__.strip().endswith("crop forward") and m.crop_backward.__doc__.strip().endswith("crop backward")
+    s = torch.ops.maskrcnn_native.nms.default._schema
+    assert str(s) == "maskrcnn_native::nms(Tensor dets, float threshold) -> Tensor"
+    assert "Tensor(a!) crops" in str(torch.ops.maskrcnn_native.crop_forward.default._schema)
+    assert "Tensor(a!) grads_image" in str(torch.ops.maskrcnn_native.crop_backward.default._schema)
+    with pytest.raises(RuntimeError, match="Not compiled with CPU support"):
+        m.nms(torch.zeros(3, 5), 0.5)
