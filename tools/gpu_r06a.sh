@@ -1,5 +1,8 @@
 #!/bin/bash
-# round 6, call A: (1) wrong tiles of the round-5 kernel WITHOUT its wait states captured whole (tools/w4_forensics.py);
+# round 6, call A (provenance of profiles/r06_w4_root_cause.jsonl): (1) wrong tiles of the round-5 kernel WITHOUT its wait states
+# captured whole (tools/w4_forensics.py). The variant "w4_nofix" was round 5's conv_wino4.hip (commit 7c66b25) built with
+# -DMRCNN_W4_NO_RACE_FIX; that macro is gone with the pads — today the same kernel is MRCNN_W4_DEBUG=8192 of an ablation build
+# (maskrcnn_amd/build.py --variant w4_abl --only conv_wino4.hip -DMRCNN_W4_ABLATIONS; tools/w4_war_demo.py);
 # (2) the restructured kernel (no pads, dummy DMAs into the dump): Winograd tests, then the reproducibility soak
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r06a; mkdir -p $OUT
